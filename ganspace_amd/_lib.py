@@ -1,0 +1,83 @@
+"""ctypes binding of the C-ABI in include/ganspace_hip.h.
+
+The product path has NO CPU fallback: if the shared library is missing or cannot be
+loaded, :func:`load` raises ``RuntimeError`` (build it with
+``python -m ganspace_amd._build`` / ``__graft_entry__.build()``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+from . import _build
+
+GS_OK, GS_EINVAL, GS_EHIP, GS_ENOMEM, GS_ESTATE, GS_ENOTIMPL = 0, -1, -2, -3, -4, -5
+GS_MODE_EXACT, GS_MODE_FAITHFUL = 0, 1
+GS_PREC_F32 = 0
+
+_vp, _i64, _int, _f32 = C.c_void_p, C.c_int64, C.c_int, C.c_float
+
+# name -> (restype, argtypes): must list every symbol include/ganspace_hip.h declares
+SIGNATURES = {
+    "gs_version": (_int, []),
+    "gs_last_error": (C.c_char_p, []),
+    "gs_device_count": (_int, []),
+    "gs_ipca_create": (_int, [_i64, _int, _int, _int, _int, C.POINTER(_vp)]),
+    "gs_ipca_destroy": (_int, [_vp]),
+    "gs_ipca_reset": (_int, [_vp]),
+    "gs_ipca_update": (_int, [_vp, _vp, _i64, _i64, _vp]),
+    "gs_ipca_state_nbytes": (_i64, [_vp]),
+    "gs_ipca_state_export": (_int, [_vp, _vp, _vp]),
+    "gs_ipca_state_import": (_int, [_vp, _vp, _vp]),
+    "gs_state_recenter": (_int, [_vp, _i64, _vp, _vp]),
+    "gs_ipca_finalize": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "gs_ipca_components_device": (_int, [_vp, C.POINTER(_vp), C.POINTER(_vp)]),
+    "gs_gram_accumulate": (_int, [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp]),
+    "gs_gram_kernel_time": (_int, [_vp, _vp, _i64, _i64, _int, _vp, _vp, _vp]),
+    "gs_eigh_sym": (_int, [_vp, _vp, _int, _vp, _vp]),
+    "gs_mapping_forward": (_int, [_vp, _vp, _vp, _vp, _vp, _int, _int, _f32, _f32, _f32, _f32, _int, _i64, _vp]),
+    "gs_linear_forward": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _int, _vp]),
+}
+
+_lib = None
+
+
+class GanspaceHipError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"ganspace_hip error {code}: {msg}")
+        self.code = code
+
+
+def load():
+    """Load (once) and return the ctypes library; raise loudly if it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = os.environ.get("GANSPACE_HIP_LIB", _build.lib_path())
+    if not os.path.exists(path):
+        raise RuntimeError(
+            f"{path} not found: the HIP extension is required (no CPU fallback). "
+            "Build it with `python -m ganspace_amd._build`.")
+    lib = C.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the .so does not export it
+        fn.restype, fn.argtypes = res, args
+    if lib.gs_version() != 1:
+        raise RuntimeError(f"ABI version mismatch: library reports {lib.gs_version()}")
+    _lib = lib
+    return lib
+
+
+def check(rc: int):
+    if rc != GS_OK:
+        msg = load().gs_last_error()
+        raise GanspaceHipError(rc, msg.decode() if msg else "")
+    return rc
+
+
+def current_stream_ptr():
+    """hipStream_t of torch's current stream (0 = null stream if torch has no GPU)."""
+    import torch
+    if torch.cuda.is_available():
+        return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return C.c_void_p(0)

@@ -1,0 +1,74 @@
+// Internal helpers shared by the gfx950 kernels (not part of the C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+
+#include "ganspace_hip.h"
+
+namespace gs {
+
+void set_error(const std::string &msg);
+
+#define GS_HIP_CHECK(expr)                                                              \
+    do {                                                                                \
+        hipError_t _e = (expr);                                                         \
+        if (_e != hipSuccess) {                                                         \
+            ::gs::set_error(std::string(#expr) + ": " + hipGetErrorString(_e));         \
+            return GS_EHIP;                                                             \
+        }                                                                               \
+    } while (0)
+
+#define GS_REQUIRE(cond, code, msg)                                                     \
+    do {                                                                                \
+        if (!(cond)) {                                                                  \
+            ::gs::set_error(msg);                                                       \
+            return (code);                                                              \
+        }                                                                               \
+    } while (0)
+
+inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+inline int64_t ceil_div(int64_t x, int64_t m) { return (x + m - 1) / m; }
+
+// ---- Gram (X^T X) accumulation: gs_gram.hip -------------------------------------------
+constexpr int kMacroTile = 128;   // output tile of one workgroup (2x2 waves of 64x64)
+constexpr int kWaveTile = 64;
+
+struct GramWorkspace {
+    float *partial = nullptr;      // [chunks][dp][dp] f32 per-chunk partial Grams (upper wave tiles)
+    float *colsum_partial = nullptr;  // [chunks][dp]
+    int64_t dp = 0;                // d rounded up to kMacroTile
+    int max_chunks = 0;
+};
+
+int gram_workspace_alloc(GramWorkspace &ws, int64_t d);
+void gram_workspace_free(GramWorkspace &ws);
+
+// Launch colsum+Gram partials for X[rows, ld] and fold them in float64 into
+// G64 (upper 64x64 wave tiles of a [dp][dp] row-major array) and S1[dp].
+// accumulate=false overwrites G64/S1 instead of adding.
+int gram_update(const GramWorkspace &ws, const float *X, int64_t rows, int64_t ld, int64_t d,
+                const float *shift, double *G64, double *S1, bool accumulate, hipStream_t stream);
+
+// average duration of the partial-Gram kernel alone (HIP events on `stream`)
+int gram_partial_time(const GramWorkspace &ws, const float *X, int64_t rows, int64_t ld, int64_t d,
+                      const float *shift, int iters, float *avg_ms, hipStream_t stream);
+
+// column means of X[rows, ld] -> out[dp] f32 (padded columns zero)
+int column_means_f32(const float *X, int64_t rows, int64_t ld, int64_t d, int64_t dp, float *out,
+                     double *scratch, hipStream_t stream);
+
+// ---- symmetric eigensolver: gs_eigh.hip --------------------------------------------------
+struct EighWorkspace {
+    double *norms = nullptr;       // [n] squared column norms
+    int *rank = nullptr;           // [n]
+    double *offmax = nullptr;      // [1] device convergence measure
+    int n_alloc = 0;
+};
+int eigh_workspace_alloc(EighWorkspace &ws, int n);
+void eigh_workspace_free(EighWorkspace &ws);
+// W: n x n, leading dimension ldw (doubles), symmetric; on return column j (W[j*ldw + :])
+// holds lambda_j * v_j (unsorted).  norms[j] = lambda_j^2.
+int eigh_jacobi(const EighWorkspace &ws, double *W, int n, int64_t ldw, int *sweeps_out, hipStream_t stream);
+
+}  // namespace gs

@@ -1,0 +1,371 @@
+// Fused column-sum + X^T X accumulation for the incremental-PCA update (gfx950 / CDNA4).
+//
+// Replaces the arithmetic core of IncrementalPCA.partial_fit
+// (sklearn/decomposition/_incremental_pca.py:335-362, reached from the reference through
+// estimators.py:68-76): instead of an SVD of the (k+m+1) x d stacked matrix on the host,
+// the d x d scatter  sum_r (x_r - s)(x_r - s)^T  and the column sums  sum_r (x_r - s)
+// of the [rows, d] float32 activation block are accumulated on the matrix cores.
+//
+// Work decomposition (one launch per <= 48 x 512 rows):
+//   * output: upper-triangle 128 x 128 macro tiles of the d x d Gram (symmetry: the lower
+//     triangle is never computed); one workgroup (4 waves) per (macro tile, row chunk);
+//     wave (wi, wj) owns a 64 x 64 tile = 2 x 2 accumulators of v_mfma_f32_32x32x2_f32;
+//     on diagonal macro tiles the strictly-lower wave tile is skipped.
+//   * split-K over row chunks: each chunk's partial tile goes to a float32 slab; a second
+//     kernel folds the slabs in float64 into the persistent accumulator, so float32
+//     fma chains never exceed 512 rows.
+//   * X is row-major [rows, d]; for X^T X both MFMA operands are "row k, 32 consecutive
+//     columns" (A[i][k] = X[k][I+i], B[k][j] = X[k][J+j]) so global reads are fully
+//     coalesced 512-B row segments and LDS reads are conflict-free ds_read_b32 without
+//     any transpose or swizzle.  Tiles are register-staged (global_load_dwordx4 ->
+//     subtract shift -> ds_write_b128) and double-buffered in LDS (64 KiB / workgroup).
+//   * XCD-aware block mapping: block b lands on XCD b % 8, so all macro tiles of a row
+//     chunk are given to the same XCD and the chunk's rows are fetched from HBM once and
+//     re-read from that XCD's L2.
+//   * the shift s (running mean, float32) is subtracted while staging, which keeps the
+//     accumulated scatter centred (no catastrophic cancellation for |mean| >> stdev).
+#include "gs_common.h"
+
+namespace gs {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+constexpr int kKB = 32;        // rows per LDS stage
+constexpr int kThreads = 256;
+constexpr int kMaxChunkRows = 512;
+
+__device__ __forceinline__ void decode_upper(int idx, int T, int &I, int &J) {
+    int i = 0, len = T;
+    while (idx >= len) {
+        idx -= len;
+        ++i;
+        --len;
+    }
+    I = i;
+    J = i + idx;
+}
+
+template <bool VEC>
+__device__ __forceinline__ float4 load_shifted(const float *__restrict__ X, int64_t row, int64_t r1,
+                                               int64_t ld, int col, int d, float4 sh) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row < r1) {
+        const float *p = X + row * ld + col;
+        if (VEC) {
+            if (col < d) {
+                v = *reinterpret_cast<const float4 *>(p);
+                v.x -= sh.x;
+                v.y -= sh.y;
+                v.z -= sh.z;
+                v.w -= sh.w;
+            }
+        } else {
+            if (col + 0 < d) v.x = p[0] - sh.x;
+            if (col + 1 < d) v.y = p[1] - sh.y;
+            if (col + 2 < d) v.z = p[2] - sh.z;
+            if (col + 3 < d) v.w = p[3] - sh.w;
+        }
+    }
+    return v;
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(kThreads, 2) void gram_partial_kernel(
+    const float *__restrict__ X, int64_t rows, int64_t ld, int d, const float *__restrict__ shift,
+    float *__restrict__ P, float *__restrict__ CS, int dp, int nchunks, int64_t chunk_rows, int nmt,
+    int T) {
+    __shared__ __attribute__((aligned(16))) float lds[2][2][kKB][kMacroTile];  // 64 KiB
+
+    const int b = blockIdx.x;
+    const int xcd = b & 7, local = b >> 3;
+    const int chunk = (local / nmt) * 8 + xcd;
+    const int mt = local % nmt;
+    if (chunk >= nchunks) return;
+
+    int I, J;
+    decode_upper(mt, T, I, J);
+    const bool diag = (I == J);
+    const int64_t r0 = (int64_t)chunk * chunk_rows;
+    const int64_t r1 = (r0 + chunk_rows < rows) ? r0 + chunk_rows : rows;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wi = wave >> 1, wj = wave & 1;
+    const bool active = !(diag && wi == 1 && wj == 0);
+
+    const int c4 = tid & 31, rr = tid >> 5;
+    const int colA = I * kMacroTile + c4 * 4, colB = J * kMacroTile + c4 * 4;
+    const float4 shA = *reinterpret_cast<const float4 *>(shift + colA);
+    const float4 shB = *reinterpret_cast<const float4 *>(shift + colB);
+
+    float4 ra[4], rb[4];
+    float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    auto fetch = [&](int64_t rbase) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            ra[i] = load_shifted<VEC>(X, rbase + rr + 8 * i, r1, ld, colA, d, shA);
+            if (!diag) rb[i] = load_shifted<VEC>(X, rbase + rr + 8 * i, r1, ld, colB, d, shB);
+        }
+    };
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<float4 *>(&lds[buf][0][rr + 8 * i][c4 * 4]) = ra[i];
+            if (!diag) *reinterpret_cast<float4 *>(&lds[buf][1][rr + 8 * i][c4 * 4]) = rb[i];
+            if (diag) {
+                cs.x += ra[i].x;
+                cs.y += ra[i].y;
+                cs.z += ra[i].z;
+                cs.w += ra[i].w;
+            }
+        }
+    };
+
+    f32x16 acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};
+    const int nst = (int)((r1 - r0 + kKB - 1) / kKB);
+    const int arow = lane >> 5;
+    const int acol = wi * kWaveTile + (lane & 31);
+    const int bcol = wj * kWaveTile + (lane & 31);
+
+    if (nst > 0) {
+        fetch(r0);
+        stash(0);
+    }
+    __syncthreads();
+    for (int s = 0; s < nst; ++s) {
+        const int buf = s & 1;
+        if (s + 1 < nst) fetch(r0 + (int64_t)(s + 1) * kKB);
+        if (active) {
+            const float *A = &lds[buf][0][0][0];
+            const float *B = diag ? A : &lds[buf][1][0][0];
+#pragma unroll
+            for (int k = 0; k < kKB; k += 2) {
+                const float a0 = A[(k + arow) * kMacroTile + acol];
+                const float a1 = A[(k + arow) * kMacroTile + acol + 32];
+                const float b0 = B[(k + arow) * kMacroTile + bcol];
+                const float b1 = B[(k + arow) * kMacroTile + bcol + 32];
+                acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc00, 0, 0, 0);
+                acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc01, 0, 0, 0);
+                acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc10, 0, 0, 0);
+                acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc11, 0, 0, 0);
+            }
+        }
+        if (s + 1 < nst) stash(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: 64x64 wave tile -> this chunk's float32 slab --------------------------
+    if (active) {
+        float *Pc = P + (int64_t)chunk * dp * dp;
+        const int row_base = I * kMacroTile + wi * kWaveTile + 4 * (lane >> 5);
+        const int col_base = J * kMacroTile + wj * kWaveTile + (lane & 31);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = row_base + (r & 3) + 8 * (r >> 2);
+            Pc[(int64_t)row * dp + col_base] = acc00[r];
+            Pc[(int64_t)row * dp + col_base + 32] = acc01[r];
+            Pc[(int64_t)(row + 32) * dp + col_base] = acc10[r];
+            Pc[(int64_t)(row + 32) * dp + col_base + 32] = acc11[r];
+        }
+    }
+    // ---- column sums of panel I (diagonal macro tiles only; each panel is diagonal once) --
+    if (diag) {
+        float *scr = &lds[0][0][0][0];
+        scr[rr * kMacroTile + c4 * 4 + 0] = cs.x;
+        scr[rr * kMacroTile + c4 * 4 + 1] = cs.y;
+        scr[rr * kMacroTile + c4 * 4 + 2] = cs.z;
+        scr[rr * kMacroTile + c4 * 4 + 3] = cs.w;
+        __syncthreads();
+        if (tid < kMacroTile) {
+            float t = 0.f;
+#pragma unroll
+            for (int g = 0; g < 8; ++g) t += scr[g * kMacroTile + tid];
+            CS[(int64_t)chunk * dp + I * kMacroTile + tid] = t;
+        }
+    }
+}
+
+// Fold the per-chunk float32 slabs into the float64 accumulators (upper 64x64 wave tiles).
+__global__ __launch_bounds__(256) void gram_fold_kernel(const float *__restrict__ P,
+                                                        const float *__restrict__ CS,
+                                                        double *__restrict__ G64,
+                                                        double *__restrict__ S1, int dp, int nchunks,
+                                                        int T64, int ntiles, int accumulate) {
+    const int bid = blockIdx.x;
+    const int tid = threadIdx.x;
+    if (bid < ntiles * 4) {
+        int ti, tj;
+        decode_upper(bid >> 2, T64, ti, tj);
+        const int e = (bid & 3) * 1024 + tid * 4;
+        const int row = ti * kWaveTile + (e >> 6), col = tj * kWaveTile + (e & 63);
+        const int64_t off = (int64_t)row * dp + col;
+        double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+        for (int c = 0; c < nchunks; ++c) {
+            const float4 v = *reinterpret_cast<const float4 *>(P + (int64_t)c * dp * dp + off);
+            s0 += v.x;
+            s1 += v.y;
+            s2 += v.z;
+            s3 += v.w;
+        }
+        double *g = G64 + off;
+        if (accumulate) {
+            g[0] += s0;
+            g[1] += s1;
+            g[2] += s2;
+            g[3] += s3;
+        } else {
+            g[0] = s0;
+            g[1] = s1;
+            g[2] = s2;
+            g[3] = s3;
+        }
+    } else {
+        const int col = (bid - ntiles * 4) * 256 + tid;
+        if (col < dp) {
+            double s = 0;
+            for (int c = 0; c < nchunks; ++c) s += CS[(int64_t)c * dp + col];
+            if (accumulate)
+                S1[col] += s;
+            else
+                S1[col] = s;
+        }
+    }
+}
+
+int gram_workspace_alloc(GramWorkspace &ws, int64_t d) {
+    ws.dp = round_up(d, kMacroTile);
+    const int64_t T = ws.dp / kMacroTile;
+    const int64_t nmt = T * (T + 1) / 2;
+    int64_t mc = round_up(ceil_div(1024, nmt), 8);
+    if (mc > 64) mc = 64;
+    if (mc < 8) mc = 8;
+    ws.max_chunks = (int)mc;
+    GS_HIP_CHECK(hipMalloc(&ws.partial, sizeof(float) * ws.max_chunks * ws.dp * ws.dp));
+    GS_HIP_CHECK(hipMalloc(&ws.colsum_partial, sizeof(float) * ws.max_chunks * ws.dp));
+    return GS_OK;
+}
+
+void gram_workspace_free(GramWorkspace &ws) {
+    if (ws.partial) (void)hipFree(ws.partial);
+    if (ws.colsum_partial) (void)hipFree(ws.colsum_partial);
+    ws = GramWorkspace();
+}
+
+// Launch geometry of one partial-Gram launch over n rows.
+struct GramGeom {
+    int nmt, T, want, nchunks, grid;
+    int64_t chunk_rows, rows_per_launch;
+};
+
+static GramGeom gram_geometry(const GramWorkspace &ws, int64_t n) {
+    GramGeom g;
+    const int dp = (int)ws.dp;
+    g.T = dp / kMacroTile;
+    g.nmt = g.T * (g.T + 1) / 2;
+    // target ~2 workgroups per CU; chunks are multiples of 8 (one group of chunks per XCD)
+    g.want = (int)round_up(ceil_div(512, g.nmt), 8);
+    if (g.want > ws.max_chunks) g.want = ws.max_chunks;
+    g.rows_per_launch = (int64_t)g.want * kMaxChunkRows;
+    if (n > g.rows_per_launch) n = g.rows_per_launch;
+    g.chunk_rows = round_up(ceil_div(n, g.want), 8);
+    if (g.chunk_rows < 64) g.chunk_rows = 64;
+    g.nchunks = (int)ceil_div(n, g.chunk_rows);
+    g.grid = (int)round_up(g.nchunks, 8) * g.nmt;
+    return g;
+}
+
+static void launch_partial(const GramWorkspace &ws, const GramGeom &g, const float *Xb, int64_t n, int64_t ld,
+                           int64_t d, const float *shift, hipStream_t stream) {
+    const bool vec = (ld % 4 == 0) && (d % 4 == 0) && ((reinterpret_cast<uintptr_t>(Xb) & 15) == 0);
+    const int dp = (int)ws.dp;
+    if (vec)
+        hipLaunchKernelGGL(gram_partial_kernel<true>, dim3(g.grid), dim3(kThreads), 0, stream, Xb, n, ld, (int)d,
+                           shift, ws.partial, ws.colsum_partial, dp, g.nchunks, g.chunk_rows, g.nmt, g.T);
+    else
+        hipLaunchKernelGGL(gram_partial_kernel<false>, dim3(g.grid), dim3(kThreads), 0, stream, Xb, n, ld, (int)d,
+                           shift, ws.partial, ws.colsum_partial, dp, g.nchunks, g.chunk_rows, g.nmt, g.T);
+}
+
+int gram_update(const GramWorkspace &ws, const float *X, int64_t rows, int64_t ld, int64_t d,
+                const float *shift, double *G64, double *S1, bool accumulate, hipStream_t stream) {
+    if (rows <= 0) return GS_OK;
+    const int dp = (int)ws.dp;
+    const int T64 = dp / kWaveTile, ntiles = T64 * (T64 + 1) / 2;
+    const int64_t rows_per_launch = gram_geometry(ws, rows).rows_per_launch;
+
+    bool acc = accumulate;
+    for (int64_t base = 0; base < rows; base += rows_per_launch) {
+        const int64_t n = (rows - base < rows_per_launch) ? rows - base : rows_per_launch;
+        const GramGeom g = gram_geometry(ws, n);
+        const int nchunks = g.nchunks;
+        launch_partial(ws, g, X + base * ld, n, ld, d, shift, stream);
+        const int fold_grid = ntiles * 4 + (int)ceil_div(dp, 256);
+        hipLaunchKernelGGL(gram_fold_kernel, dim3(fold_grid), dim3(256), 0, stream, ws.partial,
+                           ws.colsum_partial, G64, S1, dp, nchunks, T64, ntiles, acc ? 1 : 0);
+        acc = true;
+    }
+    GS_HIP_CHECK(hipGetLastError());
+    return GS_OK;
+}
+
+// Average duration (ms) of the partial-Gram kernel alone, HIP events on `stream`.
+int gram_partial_time(const GramWorkspace &ws, const float *X, int64_t rows, int64_t ld, int64_t d,
+                      const float *shift, int iters, float *avg_ms, hipStream_t stream) {
+    const GramGeom g = gram_geometry(ws, rows);
+    const int64_t n = rows < g.rows_per_launch ? rows : g.rows_per_launch;
+    hipEvent_t e0, e1;
+    GS_HIP_CHECK(hipEventCreate(&e0));
+    GS_HIP_CHECK(hipEventCreate(&e1));
+    launch_partial(ws, g, X, n, ld, d, shift, stream);  // warm-up
+    GS_HIP_CHECK(hipEventRecord(e0, stream));
+    for (int i = 0; i < iters; ++i) launch_partial(ws, g, X, n, ld, d, shift, stream);
+    GS_HIP_CHECK(hipEventRecord(e1, stream));
+    GS_HIP_CHECK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    GS_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *avg_ms = ms / (float)iters;
+    return GS_OK;
+}
+
+// ---- column means (first block only: seeds the shift) -----------------------------------
+__global__ __launch_bounds__(256) void colsum_f64_kernel(const float *__restrict__ X, int64_t rows,
+                                                         int64_t ld, int d, double *__restrict__ out,
+                                                         int64_t rows_per_block) {
+    __shared__ double scr[8][32];
+    const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
+    const int col = blockIdx.x * 32 + cx;
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
+    const int64_t r1 = (r0 + rows_per_block < rows) ? r0 + rows_per_block : rows;
+    double s = 0;
+    if (col < d)
+        for (int64_t r = r0 + ry; r < r1; r += 8) s += X[r * ld + col];
+    scr[ry][cx] = s;
+    __syncthreads();
+    if (ry == 0 && col < d) {
+        double t = 0;
+        for (int g = 0; g < 8; ++g) t += scr[g][cx];
+        atomicAdd(out + col, t);
+    }
+}
+
+__global__ void mean_from_sum_kernel(const double *__restrict__ sum, float *__restrict__ out, int d,
+                                     int dp, double inv_n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < dp) out[i] = (i < d) ? (float)(sum[i] * inv_n) : 0.f;
+}
+
+int column_means_f32(const float *X, int64_t rows, int64_t ld, int64_t d, int64_t dp, float *out,
+                     double *scratch, hipStream_t stream) {
+    GS_HIP_CHECK(hipMemsetAsync(scratch, 0, sizeof(double) * dp, stream));
+    const int64_t rpb = 256;
+    dim3 grid((unsigned)ceil_div(d, 32), (unsigned)ceil_div(rows, rpb));
+    hipLaunchKernelGGL(colsum_f64_kernel, grid, dim3(256), 0, stream, X, rows, ld, (int)d, scratch, rpb);
+    hipLaunchKernelGGL(mean_from_sum_kernel, dim3((unsigned)ceil_div(dp, 256)), dim3(256), 0, stream, scratch,
+                       out, (int)d, (int)dp, 1.0 / (double)rows);
+    GS_HIP_CHECK(hipGetLastError());
+    return GS_OK;
+}
+
+}  // namespace gs

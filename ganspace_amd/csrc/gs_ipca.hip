@@ -1,0 +1,619 @@
+// Incremental-PCA estimator state machine + C ABI (gfx950).
+//
+// Replaces IPCAEstimator (reference estimators.py:55-81) and the sklearn
+// IncrementalPCA.partial_fit arithmetic it delegates to
+// (sklearn/decomposition/_incremental_pca.py:257-379, extmath.py:895-953,1064-1187).
+// Two modes share the Gram kernels of gs_gram.hip and the eigensolver of gs_eigh.hip:
+//
+//   EXACT     S2 += sum (x-s)(x-s)^T, S1 += sum (x-s) over all blocks (float64 across
+//             chunks), one eigensolve of C = S2 - S1 S1^T / n in finalize.
+//   FAITHFUL  per block:  Gc = sum (x-bm)(x-bm)^T
+//                                          Gc += V^T diag(S^2) V + mc mc^T   (n > 0)
+//             eigh(Gc) -> S' = sqrt(w_top), V' = sign-fixed rows; Chan update of mean/var.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "gs_common.h"
+
+namespace gs {
+static thread_local std::string g_last_error;
+void set_error(const std::string &msg) { g_last_error = msg; }
+}  // namespace gs
+
+using namespace gs;
+
+struct gs_ipca {
+    int64_t d = 0, dp = 0;
+    int k = 0, mode = 0, prec = 0, device = 0;
+    int n2 = 0;  // eigensolver size (= d)
+    int64_t n_seen = 0;
+    int64_t blocks = 0;
+    bool finalized = false;
+    int last_sweeps = 0;
+    GramWorkspace gws;
+    EighWorkspace ews;
+    float *shift = nullptr;      // [dp]
+    double *S1 = nullptr;        // [dp]    sum (x - shift)
+    double *G64 = nullptr;       // [dp*dp] upper 64x64 tiles: sum (x-shift)(x-shift)^T
+    double *W = nullptr;         // [dp*dp] eigensolver workspace, leading dim dp
+    double *mean = nullptr;      // [dp]
+    double *m2 = nullptr;        // [dp]    per-feature sum of squared deviations
+    double *vec = nullptr;       // [4*dp]  scratch vectors (bm', mc, ...)
+    double *Vk = nullptr;        // [k*dp]  float64 components (rows)
+    double *lam = nullptr;       // [k]     top-k eigenvalues of the last solve (= S^2)
+    double *scal = nullptr;      // [8]     device scalars: [0]=trace
+    double *outs = nullptr;      // [3*k]   sv, ev, evr
+    float *comp32 = nullptr;     // [k*d]
+    float *mean32 = nullptr;     // [d]
+};
+
+namespace {
+
+__device__ __forceinline__ double upper_get(const double *G, int dp, int i, int j) {
+    // G holds the upper 64x64 wave tiles (tile(i) <= tile(j)); inside a tile everything is valid
+    return ((i >> 6) <= (j >> 6)) ? G[(int64_t)i * dp + j] : G[(int64_t)j * dp + i];
+}
+
+// ---- EXACT: C = S2 - S1 S1^T / n  (full symmetric), mean, var, trace -------------------
+__global__ void exact_assemble_kernel(const double *__restrict__ G, const double *__restrict__ S1,
+                                      const float *__restrict__ shift, double *__restrict__ W,
+                                      double *__restrict__ mean, double *__restrict__ m2,
+                                      double *__restrict__ trace, int d, int dp, double n) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = blockIdx.y;
+    if (j >= d) return;
+    const double c = upper_get(G, dp, i, j) - S1[i] * S1[j] / n;
+    W[(int64_t)i * dp + j] = c;
+    if (i == j) {
+        mean[i] = (double)shift[i] + S1[i] / n;
+        m2[i] = c;
+        atomicAdd(trace, c);
+    }
+}
+
+// ---- FAITHFUL: per-block statistics -----------------------------------------------------
+// vec[0..dp)   bm' = S1/m          (block mean relative to the shift)
+// vec[dp..2dp) mc  = sqrt(n0/n1*m) * (mean_old - bm)
+// vec[2dp..)   delta = bm - mean_old
+__global__ void faithful_stats_kernel(const double *__restrict__ S1, const float *__restrict__ shift,
+                                      double *__restrict__ mean, double *__restrict__ vec, int d, int dp,
+                                      double n0, double m) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= d) return;
+    const double n1 = n0 + m;
+    const double bmp = S1[i] / m;
+    const double bm = (double)shift[i] + bmp;
+    vec[i] = bmp;
+    if (n0 > 0) {
+        const double mu = mean[i];
+        const double delta = bm - mu;
+        vec[dp + i] = sqrt(n0 / n1 * m) * (mu - bm);
+        vec[2 * dp + i] = delta;
+        mean[i] = mu + delta * (m / n1);
+    } else {
+        vec[dp + i] = 0;
+        vec[2 * dp + i] = 0;
+        mean[i] = bm;
+    }
+}
+
+__global__ void faithful_assemble_kernel(const double *__restrict__ G, const double *__restrict__ vec,
+                                         const double *__restrict__ Vk, const double *__restrict__ lam,
+                                         double *__restrict__ W, double *__restrict__ m2, int d, int dp,
+                                         int k, double n0, double m) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = blockIdx.y;
+    if (j >= d) return;
+    const double gc = upper_get(G, dp, i, j) - m * vec[i] * vec[j];
+    double c = gc;
+    if (n0 > 0) {
+        c += vec[dp + i] * vec[dp + j];
+        double acc = 0;
+        for (int t = 0; t < k; ++t) acc += lam[t] * Vk[(int64_t)t * dp + i] * Vk[(int64_t)t * dp + j];
+        c += acc;
+    }
+    W[(int64_t)i * dp + j] = c;
+    if (i == j) {
+        const double n1 = n0 + m;
+        const double dl = vec[2 * dp + i];
+        m2[i] = (n0 > 0 ? m2[i] : 0.0) + gc + dl * dl * (n0 * m / n1);
+    }
+}
+
+// rank of every column by decreasing squared norm (ties: lower index first)
+__global__ void rank_kernel(const double *__restrict__ norms, int *__restrict__ rank, int n) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const double v = norms[j];
+    int r = 0;
+    for (int i = 0; i < n; ++i) {
+        const double u = norms[i];
+        r += (u > v) || (u == v && i < j);
+    }
+    rank[j] = r;
+}
+
+// Column j of W (= lambda_j v_j) with rank r < k  ->  row r of Vk, unit norm, sign fixed so the
+// entry of largest magnitude is positive (sklearn svd_flip(u_based_decision=False),
+// extmath.py:943-951; first index wins ties like np.argmax).
+__global__ __launch_bounds__(256) void select_topk_kernel(const double *__restrict__ W,
+                                                          const double *__restrict__ norms,
+                                                          const int *__restrict__ rank,
+                                                          double *__restrict__ Vk, double *__restrict__ lam,
+                                                          int n, int64_t ldw, int dp, int k) {
+    const int lane = threadIdx.x & 63;
+    const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (j >= n) return;
+    const int r = rank[j];
+    if (r >= k) return;
+    const double *c = W + (int64_t)j * ldw;
+    double best = -1.0, bestv = 0.0;
+    int besti = 0x7fffffff;
+    for (int e = lane; e < n; e += 64) {
+        const double v = c[e], a = fabs(v);
+        if (a > best) {
+            best = a;
+            bestv = v;
+            besti = e;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const double ob = __shfl_xor(best, o, 64), ov = __shfl_xor(bestv, o, 64);
+        const int oi = __shfl_xor(besti, o, 64);
+        if (ob > best || (ob == best && oi < besti)) {
+            best = ob;
+            bestv = ov;
+            besti = oi;
+        }
+    }
+    const double nrm2 = norms[j];
+    const double inv = (nrm2 > 0) ? 1.0 / sqrt(nrm2) : 0.0;
+    const double sgn = (bestv < 0) ? -inv : inv;
+    double *out = Vk + (int64_t)r * dp;
+    for (int e = lane; e < dp; e += 64) out[e] = (e < n) ? c[e] * sgn : 0.0;
+    if (lane == 0) lam[r] = sqrt(nrm2);
+}
+
+// sv = sqrt(lambda), ev = lambda/(n-1), evr = lambda/total
+__global__ void derive_outputs_kernel(const double *__restrict__ lam, const double *__restrict__ total_src,
+                                      int total_len, double *__restrict__ outs, int k, double n) {
+    __shared__ double tot;
+    if (threadIdx.x == 0) {
+        double t = 0;
+        for (int i = 0; i < total_len; ++i) t += total_src[i];
+        tot = t;
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < k; t += blockDim.x) {
+        const double l = lam[t];
+        outs[t] = sqrt(l);
+        outs[k + t] = l / (n - 1.0);
+        outs[2 * k + t] = l / tot;
+    }
+}
+
+__global__ void to_f32_kernel(const double *__restrict__ Vk, const double *__restrict__ mean,
+                              float *__restrict__ comp32, float *__restrict__ mean32, int d, int dp, int k) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int t = blockIdx.y;
+    if (j >= d) return;
+    if (t < k)
+        comp32[(int64_t)t * d + j] = (float)Vk[(int64_t)t * dp + j];
+    else
+        mean32[j] = (float)mean[j];
+}
+
+__global__ void mean_to_shift_kernel(const double *__restrict__ mean, float *__restrict__ shift, int d,
+                                     int dp) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < dp) shift[i] = (i < d) ? (float)mean[i] : 0.f;
+}
+
+// ---- state export / import (EXACT) -------------------------------------------------------
+// state = [ n | mean(d) | C(d*d) ], C = centred scatter
+__global__ void state_export_kernel(const double *__restrict__ W, const double *__restrict__ mean,
+                                    double *__restrict__ state, int d, int dp, double n) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = blockIdx.y;
+    if (j >= d) return;
+    state[1 + d + (int64_t)i * d + j] = W[(int64_t)i * dp + j];
+    if (i == 0) {
+        state[1 + j] = mean[j];
+        if (j == 0) state[0] = n;
+    }
+}
+
+__global__ void state_import_kernel(const double *__restrict__ state, double *__restrict__ G,
+                                    double *__restrict__ S1, float *__restrict__ shift, int d, int dp) {
+    // shift = f32(mean); S1 = n (mean - shift); S2 = C + S1 S1^T / n
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = blockIdx.y;
+    if (j >= dp) return;
+    const double n = state[0];
+    auto s1 = [&](int a) -> double {
+        if (a >= d) return 0.0;
+        const double mu = state[1 + a];
+        return n * (mu - (double)(float)mu);
+    };
+    double v = 0.0;
+    if (i < d && j < d) v = state[1 + d + (int64_t)i * d + j] + (n > 0 ? s1(i) * s1(j) / n : 0.0);
+    G[(int64_t)i * dp + j] = v;
+    if (i == 0) {
+        S1[j] = s1(j);
+        shift[j] = (j < d) ? (float)state[1 + j] : 0.f;
+    }
+}
+
+__global__ void state_recenter_kernel(double *__restrict__ state, const double *__restrict__ new_mean,
+                                      int d) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = blockIdx.y;
+    if (j >= d) return;
+    const double n = state[0];
+    const double di = state[1 + i] - new_mean[i], dj = state[1 + j] - new_mean[j];
+    state[1 + d + (int64_t)i * d + j] += n * di * dj;
+}
+
+__global__ void state_setmean_kernel(double *__restrict__ state, const double *__restrict__ new_mean, int d) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < d) state[1 + j] = new_mean[j];
+}
+
+// expand the upper 64x64 wave tiles to a full symmetric row-major [d*d] matrix
+__global__ void symmetrize_out_kernel(const double *__restrict__ G, double *__restrict__ out, int d, int dp,
+                                      int accumulate) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = blockIdx.y;
+    if (j >= d) return;
+    const double v = upper_get(G, dp, i, j);
+    if (accumulate)
+        out[(int64_t)i * d + j] += v;
+    else
+        out[(int64_t)i * d + j] = v;
+}
+
+__global__ void add_vec_kernel(const double *__restrict__ src, double *__restrict__ dst, int d) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < d) dst[j] += src[j];
+}
+
+int select_and_derive(gs_ipca *h, const double *total_src, int total_len, hipStream_t stream) {
+    const int n = h->n2, dp = (int)h->dp, k = h->k;
+    hipLaunchKernelGGL(rank_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, stream, h->ews.norms,
+                       h->ews.rank, n);
+    hipLaunchKernelGGL(select_topk_kernel, dim3((unsigned)ceil_div(n, 4)), dim3(256), 0, stream, h->W,
+                       h->ews.norms, h->ews.rank, h->Vk, h->lam, n, (int64_t)dp, dp, k);
+    hipLaunchKernelGGL(derive_outputs_kernel, dim3(1), dim3(256), 0, stream, h->lam, total_src, total_len,
+                       h->outs, k, (double)h->n_seen);
+    hipLaunchKernelGGL(to_f32_kernel, dim3((unsigned)ceil_div(h->d, 256), (unsigned)(k + 1)), dim3(256), 0,
+                       stream, h->Vk, h->mean, h->comp32, h->mean32, (int)h->d, dp, k);
+    GS_HIP_CHECK(hipGetLastError());
+    return GS_OK;
+}
+
+int exact_solve(gs_ipca *h, hipStream_t stream) {
+    const int d = (int)h->d, dp = (int)h->dp;
+    GS_HIP_CHECK(hipMemsetAsync(h->scal, 0, sizeof(double) * 8, stream));
+    hipLaunchKernelGGL(exact_assemble_kernel, dim3((unsigned)ceil_div(d, 256), (unsigned)d), dim3(256), 0,
+                       stream, h->G64, h->S1, h->shift, h->W, h->mean, h->m2, h->scal, d, dp,
+                       (double)h->n_seen);
+    return GS_OK;
+}
+
+}  // namespace
+
+// ===========================================================================================
+extern "C" {
+
+int gs_version(void) { return GS_ABI_VERSION; }
+const char *gs_last_error(void) { return gs::g_last_error.c_str(); }
+
+int gs_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        set_error("hipGetDeviceCount failed");
+        return GS_EHIP;
+    }
+    return n;
+}
+
+int gs_ipca_create(int64_t d, int k, int mode, int precision, int device, gs_ipca_t **out) {
+    GS_REQUIRE(out != nullptr, GS_EINVAL, "gs_ipca_create: out is NULL");
+    *out = nullptr;
+    GS_REQUIRE(d >= 1 && d <= 8192, d > 8192 ? GS_ENOTIMPL : GS_EINVAL,
+               "gs_ipca_create: feature dim must be in [1, 8192] for the Gram-side solver");
+    // sklearn: n_components must be <= n_features (_incremental_pca.py:300-305)
+    GS_REQUIRE(k >= 1 && k <= d, GS_EINVAL, "gs_ipca_create: n_components invalid for n_features");
+    GS_REQUIRE(mode == GS_MODE_EXACT || mode == GS_MODE_FAITHFUL, GS_EINVAL, "gs_ipca_create: bad mode");
+    GS_REQUIRE(precision == GS_PREC_F32, GS_ENOTIMPL, "gs_ipca_create: only GS_PREC_F32 is implemented");
+    GS_HIP_CHECK(hipSetDevice(device));
+    gs_ipca *h = new (std::nothrow) gs_ipca();
+    GS_REQUIRE(h != nullptr, GS_ENOMEM, "gs_ipca_create: out of host memory");
+    h->d = d;
+    h->k = k;
+    h->mode = mode;
+    h->prec = precision;
+    h->device = device;
+    h->n2 = (int)d;
+    int rc = gram_workspace_alloc(h->gws, d);
+    if (rc == GS_OK) rc = eigh_workspace_alloc(h->ews, (int)d + 2);
+    h->dp = h->gws.dp;
+    const int64_t dp = h->dp;
+    auto alloc = [&](void **p, size_t bytes) {
+        if (rc != GS_OK) return;
+        if (hipMalloc(p, bytes) != hipSuccess) {
+            set_error("gs_ipca_create: hipMalloc failed");
+            rc = GS_ENOMEM;
+        } else if (hipMemset(*p, 0, bytes) != hipSuccess) {
+            rc = GS_EHIP;
+        }
+    };
+    alloc((void **)&h->shift, sizeof(float) * dp);
+    alloc((void **)&h->S1, sizeof(double) * dp);
+    alloc((void **)&h->G64, sizeof(double) * dp * dp);
+    alloc((void **)&h->W, sizeof(double) * dp * dp);
+    alloc((void **)&h->mean, sizeof(double) * dp);
+    alloc((void **)&h->m2, sizeof(double) * dp);
+    alloc((void **)&h->vec, sizeof(double) * dp * 4);
+    alloc((void **)&h->Vk, sizeof(double) * k * dp);
+    alloc((void **)&h->lam, sizeof(double) * k);
+    alloc((void **)&h->scal, sizeof(double) * 8);
+    alloc((void **)&h->outs, sizeof(double) * 3 * k);
+    alloc((void **)&h->comp32, sizeof(float) * k * d);
+    alloc((void **)&h->mean32, sizeof(float) * d);
+    if (rc != GS_OK) {
+        gs_ipca_destroy(h);
+        return rc;
+    }
+    *out = h;
+    return GS_OK;
+}
+
+int gs_ipca_destroy(gs_ipca_t *h) {
+    if (!h) return GS_OK;
+    (void)hipSetDevice(h->device);
+    gram_workspace_free(h->gws);
+    eigh_workspace_free(h->ews);
+    void *ptrs[] = {h->shift, h->S1, h->G64, h->W,   h->mean,   h->m2,    h->vec,
+                    h->Vk,    h->lam, h->scal, h->outs, h->comp32, h->mean32};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    delete h;
+    return GS_OK;
+}
+
+int gs_ipca_reset(gs_ipca_t *h) {
+    GS_REQUIRE(h != nullptr, GS_EINVAL, "gs_ipca_reset: NULL handle");
+    h->n_seen = 0;
+    h->blocks = 0;
+    h->finalized = false;
+    return GS_OK;
+}
+
+int gs_ipca_update(gs_ipca_t *h, const float *X, int64_t rows, int64_t ld, void *stream_) {
+    GS_REQUIRE(h != nullptr && X != nullptr, GS_EINVAL, "gs_ipca_update: NULL argument");
+    GS_REQUIRE(rows >= 1 && ld >= h->d, GS_EINVAL, "gs_ipca_update: need rows >= 1 and ld >= d");
+    hipStream_t stream = (hipStream_t)stream_;
+    const int d = (int)h->d, dp = (int)h->dp;
+    if (h->n_seen == 0) {
+        // sklearn _incremental_pca.py:306-311: first batch must hold at least k samples
+        GS_REQUIRE(h->k <= rows, GS_EINVAL,
+                   "n_components must be less or equal to the batch number of samples for the first "
+                   "partial_fit call");
+        int rc = column_means_f32(X, rows, ld, d, dp, h->shift, h->vec, stream);
+        if (rc != GS_OK) return rc;
+    }
+    if (h->mode == GS_MODE_EXACT) {
+        int rc = gram_update(h->gws, X, rows, ld, d, h->shift, h->G64, h->S1, h->n_seen > 0, stream);
+        if (rc != GS_OK) return rc;
+        h->n_seen += rows;
+        h->blocks += 1;
+        h->finalized = false;
+        return GS_OK;
+    }
+    // ---- FAITHFUL: close the block ---------------------------------------------------------
+    int rc = gram_update(h->gws, X, rows, ld, d, h->shift, h->G64, h->S1, false, stream);
+    if (rc != GS_OK) return rc;
+    const double n0 = (double)h->n_seen, m = (double)rows;
+    hipLaunchKernelGGL(faithful_stats_kernel, dim3((unsigned)ceil_div(d, 256)), dim3(256), 0, stream, h->S1,
+                       h->shift, h->mean, h->vec, d, dp, n0, m);
+    hipLaunchKernelGGL(faithful_assemble_kernel, dim3((unsigned)ceil_div(d, 256), (unsigned)d), dim3(256), 0,
+                       stream, h->G64, h->vec, h->Vk, h->lam, h->W, h->m2, d, dp, h->k, n0, m);
+    rc = eigh_jacobi(h->ews, h->W, h->n2, dp, &h->last_sweeps, stream);
+    if (rc != GS_OK) return rc;
+    h->n_seen += rows;
+    h->blocks += 1;
+    rc = select_and_derive(h, h->m2, d, stream);
+    if (rc != GS_OK) return rc;
+    hipLaunchKernelGGL(mean_to_shift_kernel, dim3((unsigned)ceil_div(dp, 256)), dim3(256), 0, stream, h->mean,
+                       h->shift, d, dp);
+    GS_HIP_CHECK(hipGetLastError());
+    h->finalized = true;
+    return GS_OK;
+}
+
+int64_t gs_ipca_state_nbytes(const gs_ipca_t *h) {
+    if (!h) return GS_EINVAL;
+    return (int64_t)sizeof(double) * (1 + h->d + h->d * h->d);
+}
+
+int gs_ipca_state_export(gs_ipca_t *h, double *state, void *stream_) {
+    GS_REQUIRE(h && state, GS_EINVAL, "gs_ipca_state_export: NULL argument");
+    GS_REQUIRE(h->mode == GS_MODE_EXACT, GS_ESTATE, "state export is defined for GS_MODE_EXACT");
+    hipStream_t stream = (hipStream_t)stream_;
+    const int d = (int)h->d, dp = (int)h->dp;
+    if (h->n_seen == 0) {
+        GS_HIP_CHECK(hipMemsetAsync(state, 0, (size_t)gs_ipca_state_nbytes(h), stream));
+        return GS_OK;
+    }
+    int rc = exact_solve(h, stream);  // assembles C into W and mean
+    if (rc != GS_OK) return rc;
+    hipLaunchKernelGGL(state_export_kernel, dim3((unsigned)ceil_div(d, 256), (unsigned)d), dim3(256), 0, stream,
+                       h->W, h->mean, state, d, dp, (double)h->n_seen);
+    GS_HIP_CHECK(hipGetLastError());
+    return GS_OK;
+}
+
+int gs_ipca_state_import(gs_ipca_t *h, const double *state, void *stream_) {
+    GS_REQUIRE(h && state, GS_EINVAL, "gs_ipca_state_import: NULL argument");
+    GS_REQUIRE(h->mode == GS_MODE_EXACT, GS_ESTATE, "state import is defined for GS_MODE_EXACT");
+    hipStream_t stream = (hipStream_t)stream_;
+    const int d = (int)h->d, dp = (int)h->dp;
+    double n = 0;
+    GS_HIP_CHECK(hipMemcpyAsync(&n, state, sizeof(double), hipMemcpyDeviceToHost, stream));
+    GS_HIP_CHECK(hipStreamSynchronize(stream));
+    GS_REQUIRE(n >= 0 && n == std::floor(n), GS_EINVAL, "gs_ipca_state_import: bad sample count");
+    hipLaunchKernelGGL(state_import_kernel, dim3((unsigned)ceil_div(dp, 256), (unsigned)dp), dim3(256), 0,
+                       stream, state, h->G64, h->S1, h->shift, d, dp);
+    GS_HIP_CHECK(hipGetLastError());
+    h->n_seen = (int64_t)n;
+    h->blocks = (n > 0) ? 1 : 0;
+    h->finalized = false;
+    return GS_OK;
+}
+
+int gs_state_recenter(double *state, int64_t d, const double *new_mean, void *stream_) {
+    GS_REQUIRE(state && new_mean && d >= 1, GS_EINVAL, "gs_state_recenter: bad argument");
+    hipStream_t stream = (hipStream_t)stream_;
+    hipLaunchKernelGGL(state_recenter_kernel, dim3((unsigned)ceil_div(d, 256), (unsigned)d), dim3(256), 0,
+                       stream, state, new_mean, (int)d);
+    hipLaunchKernelGGL(state_setmean_kernel, dim3((unsigned)ceil_div(d, 256)), dim3(256), 0, stream, state,
+                       new_mean, (int)d);
+    GS_HIP_CHECK(hipGetLastError());
+    return GS_OK;
+}
+
+int gs_ipca_finalize(gs_ipca_t *h, float *components_host, double *singular_values_host, double *mean_host,
+                     double *var_host, double *explained_variance_host,
+                     double *explained_variance_ratio_host, int64_t *n_seen_host, void *stream_) {
+    GS_REQUIRE(h != nullptr, GS_EINVAL, "gs_ipca_finalize: NULL handle");
+    GS_REQUIRE(h->n_seen >= 2, GS_ESTATE, "gs_ipca_finalize: fewer than 2 samples seen");
+    hipStream_t stream = (hipStream_t)stream_;
+    const int d = (int)h->d, k = h->k;
+    if (h->mode == GS_MODE_EXACT && !h->finalized) {
+        int rc = exact_solve(h, stream);
+        if (rc != GS_OK) return rc;
+        rc = eigh_jacobi(h->ews, h->W, h->n2, h->dp, &h->last_sweeps, stream);
+        if (rc != GS_OK) return rc;
+        rc = select_and_derive(h, h->scal, 1, stream);
+        if (rc != GS_OK) return rc;
+        h->finalized = true;
+    }
+    GS_REQUIRE(h->finalized, GS_ESTATE, "gs_ipca_finalize: nothing fitted");
+    std::vector<double> outs(3 * (size_t)k);
+    GS_HIP_CHECK(hipMemcpyAsync(outs.data(), h->outs, sizeof(double) * 3 * k, hipMemcpyDeviceToHost, stream));
+    if (components_host)
+        GS_HIP_CHECK(hipMemcpyAsync(components_host, h->comp32, sizeof(float) * (size_t)k * d,
+                                    hipMemcpyDeviceToHost, stream));
+    if (mean_host)
+        GS_HIP_CHECK(hipMemcpyAsync(mean_host, h->mean, sizeof(double) * d, hipMemcpyDeviceToHost, stream));
+    std::vector<double> m2;
+    if (var_host) {
+        m2.resize(d);
+        GS_HIP_CHECK(hipMemcpyAsync(m2.data(), h->m2, sizeof(double) * d, hipMemcpyDeviceToHost, stream));
+    }
+    GS_HIP_CHECK(hipStreamSynchronize(stream));
+    if (singular_values_host) std::memcpy(singular_values_host, outs.data(), sizeof(double) * k);
+    if (explained_variance_host) std::memcpy(explained_variance_host, outs.data() + k, sizeof(double) * k);
+    if (explained_variance_ratio_host)
+        std::memcpy(explained_variance_ratio_host, outs.data() + 2 * k, sizeof(double) * k);
+    if (var_host)
+        for (int i = 0; i < d; ++i) var_host[i] = m2[i] / (double)h->n_seen;
+    if (n_seen_host) *n_seen_host = h->n_seen;
+    return GS_OK;
+}
+
+int gs_ipca_components_device(gs_ipca_t *h, const float **components, const float **mean) {
+    GS_REQUIRE(h != nullptr, GS_EINVAL, "gs_ipca_components_device: NULL handle");
+    GS_REQUIRE(h->finalized, GS_ESTATE, "gs_ipca_components_device: call finalize first");
+    if (components) *components = h->comp32;
+    if (mean) *mean = h->mean32;
+    return GS_OK;
+}
+
+int gs_gram_accumulate(const float *X, int64_t rows, int64_t ld, int64_t d, const float *shift, double *G,
+                       double *colsum, void *stream_) {
+    GS_REQUIRE(X && G && colsum, GS_EINVAL, "gs_gram_accumulate: NULL argument");
+    GS_REQUIRE(d >= 1 && d <= 8192 && rows >= 0 && ld >= d, GS_EINVAL, "gs_gram_accumulate: bad shape");
+    hipStream_t stream = (hipStream_t)stream_;
+    GramWorkspace ws;
+    int rc = gram_workspace_alloc(ws, d);
+    if (rc != GS_OK) return rc;
+    const int64_t dp = ws.dp;
+    float *shp = nullptr;
+    double *G64 = nullptr, *S1 = nullptr;
+    auto cleanup = [&]() {
+        (void)hipStreamSynchronize(stream);
+        gram_workspace_free(ws);
+        if (shp) (void)hipFree(shp);
+        if (G64) (void)hipFree(G64);
+        if (S1) (void)hipFree(S1);
+    };
+    if (hipMalloc(&shp, sizeof(float) * dp) != hipSuccess || hipMalloc(&G64, sizeof(double) * dp * dp) != hipSuccess ||
+        hipMalloc(&S1, sizeof(double) * dp) != hipSuccess) {
+        cleanup();
+        set_error("gs_gram_accumulate: hipMalloc failed");
+        return GS_ENOMEM;
+    }
+    (void)hipMemsetAsync(shp, 0, sizeof(float) * dp, stream);
+    (void)hipMemsetAsync(G64, 0, sizeof(double) * dp * dp, stream);
+    (void)hipMemsetAsync(S1, 0, sizeof(double) * dp, stream);
+    if (shift) (void)hipMemcpyAsync(shp, shift, sizeof(float) * d, hipMemcpyDeviceToDevice, stream);
+    rc = gram_update(ws, X, rows, ld, d, shp, G64, S1, false, stream);
+    if (rc == GS_OK) {
+        hipLaunchKernelGGL(symmetrize_out_kernel, dim3((unsigned)ceil_div(d, 256), (unsigned)d), dim3(256), 0,
+                           stream, G64, G, (int)d, (int)dp, 1);
+        hipLaunchKernelGGL(add_vec_kernel, dim3((unsigned)ceil_div(d, 256)), dim3(256), 0, stream, S1, colsum,
+                           (int)d);
+        if (hipGetLastError() != hipSuccess) rc = GS_EHIP;
+    }
+    cleanup();
+    return rc;
+}
+
+int gs_gram_kernel_time(gs_ipca_t *h, const float *X, int64_t rows, int64_t ld, int iters, float *avg_ms_host,
+                        int64_t *rows_timed_host, void *stream_) {
+    GS_REQUIRE(h && X && avg_ms_host && iters >= 1 && rows >= 1 && ld >= h->d, GS_EINVAL,
+               "gs_gram_kernel_time: bad argument");
+    const int64_t cap = (int64_t)24576;
+    if (rows_timed_host) *rows_timed_host = rows < cap ? rows : cap;
+    return gram_partial_time(h->gws, X, rows < cap ? rows : cap, ld, h->d, h->shift, iters, avg_ms_host,
+                             (hipStream_t)stream_);
+}
+
+int gs_eigh_sym(double *A, double *w, int n, int *sweeps_out_host, void *stream_) {
+    GS_REQUIRE(A && w && n >= 1 && n <= 8192, GS_EINVAL, "gs_eigh_sym: bad argument");
+    hipStream_t stream = (hipStream_t)stream_;
+    EighWorkspace ws;
+    int rc = eigh_workspace_alloc(ws, n + 2);
+    if (rc != GS_OK) return rc;
+    double *tmp = nullptr, *lam = nullptr;
+    if (hipMalloc(&tmp, sizeof(double) * (size_t)n * n) != hipSuccess ||
+        hipMalloc(&lam, sizeof(double) * n) != hipSuccess) {
+        eigh_workspace_free(ws);
+        if (tmp) (void)hipFree(tmp);
+        set_error("gs_eigh_sym: hipMalloc failed");
+        return GS_ENOMEM;
+    }
+    rc = eigh_jacobi(ws, A, n, n, sweeps_out_host, stream);
+    if (rc == GS_OK) {
+        hipLaunchKernelGGL(rank_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, stream, ws.norms, ws.rank,
+                           n);
+        hipLaunchKernelGGL(select_topk_kernel, dim3((unsigned)ceil_div(n, 4)), dim3(256), 0, stream, A, ws.norms,
+                           ws.rank, tmp, lam, n, (int64_t)n, n, n);
+        (void)hipMemcpyAsync(A, tmp, sizeof(double) * (size_t)n * n, hipMemcpyDeviceToDevice, stream);
+        (void)hipMemcpyAsync(w, lam, sizeof(double) * n, hipMemcpyDeviceToDevice, stream);
+        if (hipGetLastError() != hipSuccess) rc = GS_EHIP;
+    }
+    (void)hipStreamSynchronize(stream);
+    eigh_workspace_free(ws);
+    (void)hipFree(tmp);
+    (void)hipFree(lam);
+    return rc;
+}
+
+}  // extern "C"

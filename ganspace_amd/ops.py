@@ -1,0 +1,91 @@
+"""Thin tensor-level wrappers over the C-ABI building blocks (device tensors in/out).
+
+PyTorch is plumbing here (device memory + the current HIP stream); all arithmetic runs in
+the hand-written kernels of ``ganspace_amd/csrc``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+
+from . import _lib
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("ganspace_amd ops need device tensors (no CPU fallback)")
+
+
+def gram_accumulate(X, G=None, colsum=None, shift=None):
+    """``G += (X-shift)^T (X-shift)`` (float64 ``[d,d]``), ``colsum += sum(X-shift)`` (float64 ``[d]``)."""
+    import torch
+    lib = _lib.load()
+    _need_cuda(X, G, colsum, shift)
+    assert X.dtype == torch.float32 and X.dim() == 2 and X.stride(1) == 1
+    rows, d = X.shape
+    if G is None:
+        G = torch.zeros((d, d), dtype=torch.float64, device=X.device)
+    if colsum is None:
+        colsum = torch.zeros(d, dtype=torch.float64, device=X.device)
+    assert G.is_contiguous() and colsum.is_contiguous()
+    if shift is not None:
+        shift = shift.to(torch.float32).contiguous()
+    _lib.check(lib.gs_gram_accumulate(_p(X), rows, X.stride(0), d, _p(shift), _p(G), _p(colsum),
+                                      _lib.current_stream_ptr()))
+    return G, colsum
+
+
+def eigh_sym(A):
+    """Eigen-decomposition of a symmetric PSD float64 matrix: returns ``(w, V, sweeps)`` with
+    ``w`` descending and eigenvectors as the ROWS of ``V``."""
+    import torch
+    lib = _lib.load()
+    _need_cuda(A)
+    assert A.dtype == torch.float64 and A.dim() == 2 and A.shape[0] == A.shape[1]
+    V = A.contiguous().clone()
+    n = V.shape[0]
+    w = torch.empty(n, dtype=torch.float64, device=A.device)
+    sweeps = C.c_int(0)
+    _lib.check(lib.gs_eigh_sym(_p(V), _p(w), n, C.cast(C.byref(sweeps), C.c_void_p), _lib.current_stream_ptr()))
+    return w, V, sweeps.value
+
+
+def mapping_forward(z, weights, bias=None, lr_mul=0.01, slope=0.2, gain=math.sqrt(2.0), pixelnorm=True):
+    """StyleGAN2 mapping network ``style(z)``: ``weights [L, dim, dim]``, ``bias [L, dim]``."""
+    import torch
+    lib = _lib.load()
+    _need_cuda(z, weights, bias)
+    z = z.to(torch.float32).contiguous()
+    weights = weights.to(torch.float32).contiguous()
+    L, dim, dim2 = weights.shape
+    assert dim == dim2 and z.shape[1] == dim
+    if bias is not None:
+        bias = bias.to(torch.float32).contiguous()
+    w = torch.empty_like(z)
+    scratch = torch.empty_like(z)
+    _lib.check(lib.gs_mapping_forward(_p(z), _p(w), _p(scratch), _p(weights), _p(bias), L, dim,
+                                      lr_mul / math.sqrt(dim), lr_mul, slope, gain, 1 if pixelnorm else 0,
+                                      z.shape[0], _lib.current_stream_ptr()))
+    return w
+
+
+def linear_forward(x, weight, bias=None):
+    """``torch.nn.functional.linear`` on the f32 matrix cores."""
+    import torch
+    lib = _lib.load()
+    _need_cuda(x, weight, bias)
+    x = x.to(torch.float32).contiguous()
+    weight = weight.to(torch.float32).contiguous()
+    if bias is not None:
+        bias = bias.to(torch.float32).contiguous()
+    out_f, in_f = weight.shape
+    assert x.shape[1] == in_f
+    y = torch.empty((x.shape[0], out_f), dtype=torch.float32, device=x.device)
+    _lib.check(lib.gs_linear_forward(_p(x), _p(weight), _p(bias), _p(y), x.shape[0], in_f, out_f,
+                                     _lib.current_stream_ptr()))
+    return y

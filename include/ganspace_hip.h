@@ -1,0 +1,147 @@
+/*
+ * ganspace_hip.h - C ABI of the MI355X (gfx950) GANSpace component-discovery library.
+ *
+ * This is the drop-in boundary for ONE hot path of harskish/ganspace: the
+ * "sample N latents -> partial_forward to a layer -> incremental PCA" loop
+ * (decomposition.py + estimators.py).  The reference has no FFI layer of its own -
+ * its operator API for this path is a set of duck-typed Python surfaces - so each
+ * entry point below cites the reference interface it replaces; the Python shell in
+ * ganspace_amd/ (estimators.py, wrappers.py) binds them with ctypes and keeps the
+ * reference's names, argument meaning and error behaviour.
+ *
+ * Conventions
+ *  - plain C types only; every pointer is a DEVICE pointer unless the name ends in
+ *    _host; `stream` is a hipStream_t passed as void* (NULL = the null stream);
+ *  - every function returns 0 on success and a negative GS_E* code on failure and
+ *    never throws; gs_last_error() returns a thread-local message;
+ *  - calls are asynchronous on `stream` except create/destroy and the *_host
+ *    outputs of gs_ipca_finalize (which synchronise the stream);
+ *  - a handle is not thread-safe.
+ */
+#ifndef GANSPACE_HIP_H
+#define GANSPACE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GS_ABI_VERSION 1
+
+enum {
+    GS_OK = 0,
+    GS_EINVAL = -1,   /* bad argument (also: n_components > rows on the first block,
+                         the ValueError of sklearn _incremental_pca.py:300-314 that
+                         estimators.py:74-76 turns into `return False`)               */
+    GS_EHIP = -2,     /* a HIP runtime call failed                                    */
+    GS_ENOMEM = -3,
+    GS_ESTATE = -4,   /* call order / mode mismatch                                   */
+    GS_ENOTIMPL = -5
+};
+
+/* PCA mode of a handle.
+ * GS_MODE_EXACT    one global centred scatter, ONE eigensolve in finalize (the north_star's
+ *                  Gram -> all-reduce -> eigensolve design); top components equal sklearn
+ *                  IPCA's to ~1e-6 cosine, trailing ones differ by IPCA's own truncation.
+ * GS_MODE_FAITHFUL sklearn's IncrementalPCA recurrence restated on the d x d Gram of its
+ *                  stacked matrix (one eigensolve per block) - reproduces ALL k components
+ *                  of the reference, signs included.                                       */
+enum { GS_MODE_EXACT = 0, GS_MODE_FAITHFUL = 1 };
+
+/* Arithmetic of the X^T X contraction.  GS_PREC_F32 = exact-f32 MFMA
+ * (v_mfma_f32_32x32x2_f32), f32 accumulate per row-chunk, f64 across chunks/blocks. */
+enum { GS_PREC_F32 = 0 };
+
+typedef struct gs_ipca gs_ipca_t;
+
+int         gs_version(void);
+const char *gs_last_error(void);
+/* number of visible HIP devices, or a negative error */
+int         gs_device_count(void);
+
+/* ---- incremental PCA estimator ------------------------------------------------------
+ * Replaces IPCAEstimator.__init__ (estimators.py:55-60): IncrementalPCA(k, whiten=False). */
+int gs_ipca_create(int64_t d, int k, int mode, int precision, int device, gs_ipca_t **out);
+int gs_ipca_destroy(gs_ipca_t *h);
+/* forget everything seen so far (a fresh estimator on the same buffers) */
+int gs_ipca_reset(gs_ipca_t *h);
+
+/* Replaces IPCAEstimator.fit_partial (estimators.py:68-76) ->
+ * IncrementalPCA.partial_fit (sklearn _incremental_pca.py:257-379).
+ * X: [rows, ld] float32 row-major on the device, ld >= d.  X is only read and is
+ * fully consumed when the call's work on `stream` completes (the reference caller
+ * overwrites its buffer for the next block, decomposition.py:243,261).
+ * Fused column-sum + X^T X MFMA accumulation; in FAITHFUL mode also closes the block
+ * (assemble + eigensolve + truncate).  Returns GS_EINVAL when k > rows on the first
+ * block (reference: ValueError -> fit_partial returns False).                          */
+int gs_ipca_update(gs_ipca_t *h, const float *X, int64_t rows, int64_t ld, void *stream);
+
+/* Sufficient statistics for resume and for the multi-GPU merge (new design):
+ * state = float64 [ n | mean(d) | C(d*d) ] with C the centred scatter sum (x-mean)(x-mean)^T
+ * (EXACT mode).  export/import move it to/from a caller (torch) buffer so that
+ * torch.distributed (RCCL) can all-reduce it; recenter re-expresses a state about a new
+ * mean (Chan merge:  C += n (mean-new)(mean-new)^T ; mean = new).                        */
+int64_t gs_ipca_state_nbytes(const gs_ipca_t *h);
+int     gs_ipca_state_export(gs_ipca_t *h, double *state, void *stream);
+int     gs_ipca_state_import(gs_ipca_t *h, const double *state, void *stream);
+int     gs_state_recenter(double *state, int64_t d, const double *new_mean, void *stream);
+
+/* Replaces IPCAEstimator.get_components (estimators.py:78-81) and the attribute reads
+ * transformer.mean_/components_/explained_variance_/... (decomposition.py:289-293).
+ * All outputs are HOST buffers (may be NULL to skip):
+ *   components_host [k*d] float32 row-major, rows sorted by decreasing variance, sign
+ *     convention of sklearn svd_flip(u_based_decision=False) (extmath.py:943-951);
+ *   singular_values/explained_variance/explained_variance_ratio [k] float64;
+ *   mean/var [d] float64 (var = biased per-feature variance, sklearn var_);
+ *   n_seen int64.  Synchronises `stream`.  EXACT mode runs the eigensolve here.         */
+int gs_ipca_finalize(gs_ipca_t *h, float *components_host, double *singular_values_host,
+                     double *mean_host, double *var_host, double *explained_variance_host,
+                     double *explained_variance_ratio_host, int64_t *n_seen_host, void *stream);
+
+/* Device-resident results of the last finalize/block close (float32 [k*d] components,
+ * float32 [d] mean) for projection without a host round trip.                            */
+int gs_ipca_components_device(gs_ipca_t *h, const float **components, const float **mean);
+
+/* ---- building blocks exposed for unit tests / benches ------------------------------- */
+
+/* G[d*d] (float64, row-major, FULL symmetric) += sum_r (x_r - shift)(x_r - shift)^T and
+ * colsum[d] (float64) += sum_r (x_r - shift); shift may be NULL (= 0).  Uses the same
+ * kernels as gs_ipca_update.  G/colsum must be zero-initialised by the caller if a fresh
+ * sum is wanted.                                                                         */
+int gs_gram_accumulate(const float *X, int64_t rows, int64_t ld, int64_t d,
+                       const float *shift, double *G, double *colsum, void *stream);
+
+/* Measurement hook for bench.py: average duration in ms of the dominant kernel alone (the
+ * partial X^T X MFMA kernel of gs_ipca_update, without the float64 fold), `iters`
+ * back-to-back launches bracketed by HIP events on `stream`.  rows_timed_host receives the
+ * number of rows one launch covers (min(rows, 24576)).  Results of the launches are
+ * discarded (they only touch the handle's scratch slabs).                                  */
+int gs_gram_kernel_time(gs_ipca_t *h, const float *X, int64_t rows, int64_t ld, int iters,
+                        float *avg_ms_host, int64_t *rows_timed_host, void *stream);
+
+/* Symmetric eigendecomposition, float64.  A: [n*n] symmetric (row- or column-major is
+ * the same), overwritten with eigenvectors stored as ROWS (V[i*n + :] = i-th vector),
+ * w[n] eigenvalue estimates, both sorted by decreasing w.  One-sided (Hestenes) Jacobi;
+ * intended for positive semi-definite matrices (covariances): eigenvalues are returned
+ * as |lambda|.  sweeps_out (host, optional) receives the number of sweeps used.         */
+int gs_eigh_sym(double *A, double *w, int n, int *sweeps_out_host, void *stream);
+
+/* z -> w: the StyleGAN2 mapping network `Generator.style` called from
+ * models/wrappers.py:177,200 (PixelNorm + L x EqualLinear(dim, dim, lr_mul,
+ * activation='fused_lrelu')); in-tree analogue models/stylegan/model.py:190-216.
+ * z,w: [rows, dim] float32; weights [L, dim, dim] (out,in) stored parameters; bias [L, dim];
+ * y = gain * lrelu(x @ (W*wscale)^T + b*bscale, slope).  scratch: [rows, dim] float32.   */
+int gs_mapping_forward(const float *z, float *w, float *scratch, const float *weights,
+                       const float *bias, int layers, int dim, float wscale, float bscale,
+                       float slope, float gain, int pixelnorm, int64_t rows, void *stream);
+
+/* y[rows, out] = x[rows, in] @ W[out, in]^T + b  (torch.nn.functional.linear); the BigGAN
+ * `generator.gen_z` layer (models/biggan/.../model.py:211-212, wrappers.py:636).          */
+int gs_linear_forward(const float *x, const float *W, const float *b, float *y,
+                      int64_t rows, int in_features, int out_features, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GANSPACE_HIP_H */

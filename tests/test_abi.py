@@ -1,0 +1,74 @@
+"""CPU-side checks of the drop-in boundary: the shared library builds, loads and exports
+every symbol include/ganspace_hip.h declares (no compute calls without a GPU)."""
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from ganspace_amd import _build, _lib
+    _build.build()
+    return _lib.load()
+
+
+def _declared_symbols():
+    src = open(os.path.join(ROOT, "include", "ganspace_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(gs_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_and_binding_agree(lib):
+    from ganspace_amd import _lib
+    declared = _declared_symbols()
+    assert declared, "no symbols parsed from the header"
+    assert sorted(_lib.SIGNATURES) == declared
+    for name in declared:
+        assert hasattr(lib, name), f"{name} not exported"
+
+
+def test_version_and_error_paths_without_gpu(lib):
+    import ctypes as C
+    assert lib.gs_version() == 1
+    h = C.c_void_p()
+    # argument validation happens before any HIP call
+    assert lib.gs_ipca_create(0, 1, 0, 0, 0, C.byref(h)) == -1
+    assert b"feature dim" in lib.gs_last_error()
+    assert lib.gs_ipca_create(16, 32, 0, 0, 0, C.byref(h)) == -1       # k > d
+    assert lib.gs_ipca_create(16, 4, 7, 0, 0, C.byref(h)) == -1        # bad mode
+    assert lib.gs_ipca_create(16, 4, 0, 3, 0, C.byref(h)) == -5        # precision not implemented
+    assert lib.gs_ipca_create(100000, 4, 0, 0, 0, C.byref(h)) == -5    # d beyond the Gram-side solver
+    assert lib.gs_ipca_update(None, None, 1, 1, None) == -1
+    assert lib.gs_ipca_destroy(None) == 0
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from ganspace_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setenv("GANSPACE_HIP_LIB", str(tmp_path / "nope.so"))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        _lib.load()
+
+
+def test_estimator_factory_names():
+    from ganspace_amd.estimators import get_estimator
+    assert get_estimator("ipca", 80, 1.0).get_param_str() == "ipca_c80"
+    assert get_estimator("ipca-exact", 20, 1.0).get_param_str() == "ipca-exact_c20"
+    assert get_estimator("ipca", 80, 1.0).batch_support is True
+    with pytest.raises(RuntimeError, match="Unknown estimator"):
+        get_estimator("bogus", 3, 1.0)
+    with pytest.raises(NotImplementedError):
+        get_estimator("pca", 3, 1.0)
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "ganspace_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), f
+                assert not re.search(r"^\s*(from|import)\s+(sklearn|scipy)\b", txt, flags=re.M), f

@@ -1,0 +1,284 @@
+"""GPU parity tests (run on a real MI355X with ``-m gpu``): the HIP path, called through
+the C-ABI, against the oracle and the reference-generated golden fixtures."""
+import os
+
+import numpy as np
+import pytest
+
+import inputs as gin
+from oracle import ipca as O
+from oracle import synth
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a HIP device; the product path has no CPU fallback")
+    from ganspace_amd import _lib
+    _lib.load()          # fail loudly if the extension is missing
+    return torch.device("cuda", 0)
+
+
+def _golden(golden_dir, name):
+    return np.load(os.path.join(golden_dir, f"ipca_ref_{name}.npz"), allow_pickle=False)
+
+
+# ---- Gram / column-sum kernel --------------------------------------------------------------
+
+@pytest.mark.parametrize("rows,d,ld_extra,use_shift", [
+    (1000, 64, 0, False), (777, 200, 8, True), (2000, 512, 0, True), (333, 37, 3, True),
+    (10000, 512, 0, False), (4097, 384, 0, True), (5, 128, 0, False), (30000, 96, 0, True),
+])
+def test_gram_accumulate_matches_float64(dev, rows, d, ld_extra, use_shift):
+    from ganspace_amd import ops
+    rs = np.random.RandomState(rows + d)
+    Xh = (rs.standard_normal((rows, d + ld_extra)) * rs.uniform(0.2, 3.0, d + ld_extra) + 0.7).astype(np.float32)
+    X = torch.from_numpy(Xh).to(dev)[:, :d]
+    sh = (Xh[:, :d].mean(0) + 0.01).astype(np.float32) if use_shift else None
+    G, cs = ops.gram_accumulate(X, shift=torch.from_numpy(sh).to(dev) if use_shift else None)
+    Xc = Xh[:, :d].astype(np.float64) - (sh.astype(np.float64) if use_shift else 0.0)
+    Gref = Xc.T @ Xc
+    scale = np.sqrt(np.outer(np.diag(Gref), np.diag(Gref)))
+    # float32 fma chains of <= 512 rows, float64 across chunks: ~1e-6 of the Cauchy-Schwarz scale
+    assert np.abs(G.cpu().numpy() - Gref).max() <= 2e-6 * scale.max()
+    assert np.abs((G.cpu().numpy() - Gref) / scale).max() <= 5e-6
+    np.testing.assert_allclose(cs.cpu().numpy(), Xc.sum(0), atol=2e-6 * np.abs(Xc).sum(0).max())
+    Gh = G.cpu().numpy()
+    np.testing.assert_array_equal(Gh, Gh.T)      # exactly symmetric by construction
+
+
+def test_gram_accumulates_and_is_linear(dev):
+    from ganspace_amd import ops
+    rs = np.random.RandomState(5)
+    X = torch.from_numpy(rs.standard_normal((3000, 256)).astype(np.float32)).to(dev)
+    G1, c1 = ops.gram_accumulate(X)
+    G2, c2 = ops.gram_accumulate(X, G1.clone(), c1.clone())
+    torch.testing.assert_close(G2, 2 * G1, rtol=1e-12, atol=0)
+    torch.testing.assert_close(c2, 2 * c1, rtol=1e-12, atol=0)
+    # splitting the rows changes only float32 chunk boundaries
+    Ga, ca = ops.gram_accumulate(X[:1234])
+    Gb, cb = ops.gram_accumulate(X[1234:], Ga, ca)
+    assert (Gb - G1).abs().max().item() <= 2e-6 * G1.abs().max().item()
+
+
+# ---- eigensolver -----------------------------------------------------------------------------
+
+@pytest.mark.parametrize("n,rank", [(8, 8), (64, 64), (129, 129), (200, 50), (512, 512)])
+def test_eigh_matches_lapack(dev, n, rank):
+    from ganspace_amd import ops
+    rs = np.random.RandomState(n)
+    B = rs.standard_normal((rank, n)) * (1.15 ** -np.arange(rank))[:, None]
+    A = B.T @ B
+    w, V, sweeps = ops.eigh_sym(torch.from_numpy(A).to(dev))
+    w, V = w.cpu().numpy(), V.cpu().numpy()
+    wr, Ur = np.linalg.eigh(A)
+    wr, Ur = wr[::-1], Ur[:, ::-1].T
+    assert sweeps < 40
+    np.testing.assert_allclose(w, np.maximum(wr, 0), atol=1e-12 * wr[0])
+    r = min(rank, 40)
+    cos = np.abs(np.sum(V[:r] * Ur[:r], axis=1))
+    assert cos.min() > 1 - 1e-10
+    # orthonormal rows on the numerically non-null part, residual A v = w v
+    Vr = V[:r]
+    assert np.abs(Vr @ Vr.T - np.eye(r)).max() < 1e-11
+    assert np.abs(A @ Vr.T - Vr.T * w[:r]).max() < 1e-11 * wr[0]
+
+
+# ---- incremental PCA, sklearn-faithful mode vs the reference fixtures ----------------------------
+
+def _fit_device(name_or_case, mode, dev, device_input=True):
+    from ganspace_amd.estimators import get_estimator
+    case = gin.IPCA_CASES[name_or_case] if isinstance(name_or_case, str) else name_or_case
+    est = get_estimator("ipca" if mode == "faithful" else "ipca-exact", case["k"], 1.0)
+    for X in gin.ipca_blocks(case):
+        arg = torch.from_numpy(X).to(dev) if device_input else X
+        assert est.fit_partial(arg) is True
+    return est
+
+
+@pytest.mark.parametrize("name", list(gin.IPCA_CASES))
+def test_faithful_mode_matches_reference_fixture(dev, golden_dir, name):
+    case = gin.IPCA_CASES[name]
+    g = _golden(golden_dir, name)
+    est = _fit_device(name, "faithful", dev, device_input=(name != "d64_k8"))
+    comp, stdev, ratio = est.get_components()
+    t = est.transformer
+    r = case["ncheck"]
+    assert comp.shape == (case["k"], case["d"]) and comp.dtype == np.float32
+    cos = O.signed_cosines(comp[:r], g["components"][:r])
+    # tolerance: the reference's block 1 runs a float32 SVD; ours is f32-Gram + f64 eigh
+    assert cos.min() > 1 - 5e-6, (name, cos.min())
+    scale = g["singular_values"][0]
+    np.testing.assert_allclose(t.singular_values_[:r], g["singular_values"][:r], rtol=1e-4)
+    np.testing.assert_allclose(t.singular_values_, g["singular_values"], atol=5e-5 * scale)
+    np.testing.assert_allclose(t.mean_, g["mean"], atol=2e-6 * max(1.0, np.abs(g["mean"]).max()))
+    np.testing.assert_allclose(t.var_, g["var"], rtol=1e-4)
+    np.testing.assert_allclose(stdev[:r], g["stdev"][:r], rtol=1e-4)
+    np.testing.assert_allclose(ratio[:r], g["var_ratio"][:r], rtol=2e-4)
+    assert int(t.n_samples_seen_) == int(g["n_samples_seen"])
+    assert est.get_param_str() == str(g["param_str"])
+
+
+@pytest.mark.parametrize("name", ["d64_k8", "d512_k20", "d96_k12_bigmean", "d200_k200_ragged"])
+def test_faithful_mode_matches_gram_oracle_tightly(dev, name):
+    case = gin.IPCA_CASES[name]
+    est = _fit_device(name, "faithful", dev)
+    orc = O.IPCAEstimatorOracle(case["k"], "gram")
+    for X in gin.ipca_blocks(case):
+        orc.fit_partial(X)
+    r = case["ncheck"]
+    cos = O.signed_cosines(est.transformer.components_[:r], orc.transformer.components_[:r])
+    assert cos.min() > 1 - 1e-6
+    np.testing.assert_allclose(est.transformer.singular_values_[:r], orc.transformer.singular_values_[:r], rtol=2e-5)
+    np.testing.assert_allclose(est.transformer.mean_, orc.transformer.mean_,
+                               atol=1e-6 * max(1.0, np.abs(orc.transformer.mean_).max()))
+
+
+@pytest.mark.parametrize("name", ["d64_k8", "d512_k20", "d512_k80_nb10000", "d96_k12_bigmean"])
+def test_exact_mode_matches_exact_oracle(dev, golden_dir, name):
+    case = gin.IPCA_CASES[name]
+    est = _fit_device(name, "exact", dev)
+    ex = O.exact_pca(gin.ipca_blocks(case), case["k"])
+    t = est.transformer
+    r = case["ncheck"]
+    cos = O.signed_cosines(t.components_[:r], ex["components_"][:r])
+    assert cos.min() > 1 - 1e-6, cos.min()
+    np.testing.assert_allclose(t.singular_values_[:r], ex["singular_values_"][:r], rtol=2e-5)
+    np.testing.assert_allclose(t.explained_variance_ratio_[:r], ex["explained_variance_ratio_"][:r], rtol=1e-4)
+    np.testing.assert_allclose(t.mean_, ex["mean_"], atol=2e-6 * max(1.0, np.abs(ex["mean_"]).max()))
+    np.testing.assert_allclose(t.var_, ex["var_"], rtol=1e-4)
+    # BASELINE target: top-20 |cos| >= 0.999 against the reference CPU IPCA
+    g = _golden(golden_dir, name)
+    top = min(20, r)
+    assert np.abs(O.signed_cosines(t.components_[:top], g["components"][:top])).min() > 0.999
+    assert est.get_param_str() == f"ipca-exact_c{case['k']}"
+
+
+def test_first_block_smaller_than_k_returns_false(dev, capsys):
+    from ganspace_amd.estimators import get_estimator
+    est = get_estimator("ipca", 20, 1.0)
+    assert est.fit_partial(np.zeros((10, 32), dtype=np.float32)) is False
+    assert "IPCA error" in capsys.readouterr().out
+
+
+def test_unknown_estimator_raises():
+    from ganspace_amd.estimators import get_estimator
+    with pytest.raises(RuntimeError):
+        get_estimator("nope", 3, 1.0)
+
+
+def test_caller_buffer_is_left_untouched_and_reusable(dev):
+    # decomposition.py:243,261,290-291: the caller overwrites X for the next block and centres
+    # the last block in place afterwards -> the estimator must not alias or modify it
+    case = gin.IPCA_CASES["d64_k8"]
+    from ganspace_amd.estimators import get_estimator
+    est = get_estimator("ipca", case["k"], 1.0)
+    buf = np.ones((300, 64), dtype=np.float32)
+    for X in gin.ipca_blocks(case):
+        buf[:] = X
+        keep = buf.copy()
+        assert est.fit_partial(buf)
+        np.testing.assert_array_equal(buf, keep)
+        buf[:] = -1e9          # clobber immediately, like the reference loop does
+    ref = _fit_device("d64_k8", "faithful", dev)
+    np.testing.assert_array_equal(est.transformer.components_, ref.transformer.components_)
+
+
+def test_state_merge_equals_single_fit(dev):
+    from ganspace_amd.estimators import IPCAEstimator
+    from ganspace_amd import distributed as D
+    case = gin.IPCA_CASES["d512_k20"]
+    blocks = list(gin.ipca_blocks(case))
+    full = IPCAEstimator(case["k"], "exact")
+    a, b = IPCAEstimator(case["k"], "exact"), IPCAEstimator(case["k"], "exact")
+    for i, X in enumerate(blocks):
+        Xd = torch.from_numpy(X).to(dev)
+        full.fit_partial(Xd)
+        (a if i < 2 else b).fit_partial(Xd)
+    merged = D.merge_states([a.transformer.export_state(), b.transformer.export_state()], case["d"])
+    c = IPCAEstimator(case["k"], "exact")
+    c.transformer.import_state(merged, case["d"])
+    cos = O.signed_cosines(c.transformer.components_, full.transformer.components_)
+    assert cos.min() > 1 - 1e-9
+    np.testing.assert_allclose(c.transformer.singular_values_, full.transformer.singular_values_, rtol=1e-9)
+    np.testing.assert_allclose(c.transformer.mean_, full.transformer.mean_, atol=1e-9)
+    assert int(c.transformer.n_samples_seen_) == sum(case["blocks"])
+
+
+def test_transform_projects_onto_components(dev):
+    case = gin.IPCA_CASES["d512_k20"]
+    est = _fit_device("d512_k20", "faithful", dev)
+    X = next(gin.ipca_blocks(case))[:100]
+    t = est.transformer
+    Y = t.transform(X)
+    Yref = (X.astype(np.float64) - t.mean_) @ t.components_.astype(np.float64).T
+    np.testing.assert_allclose(Y, Yref, atol=2e-4 * np.abs(Yref).max())
+
+
+# ---- z -> activation layers --------------------------------------------------------------------
+
+def test_mapping_network_matches_oracle_and_reference_gmapping(dev, golden_dir):
+    from ganspace_amd import ops
+    W, b = gin.mapping_weights()
+    z = gin.mapping_z()
+    out = ops.mapping_forward(torch.from_numpy(z).to(dev), torch.from_numpy(W).to(dev), torch.from_numpy(b).to(dev),
+                              lr_mul=gin.MAPPING_CASE["lr_mul"]).cpu().numpy()
+    ref64 = synth.mapping_network(z, W, b, lr_mul=gin.MAPPING_CASE["lr_mul"])
+    g = np.load(os.path.join(golden_dir, "mapping_gmapping_ref.npz"))
+    scale = np.abs(ref64).max()
+    # exact-f32 MFMA fma chains over K=512, 8 layers deep: float32 roundoff class
+    assert np.abs(out - ref64).max() < 2e-5 * scale
+    assert np.abs(out - g["w_f64"]).max() < 2e-5 * scale
+    # at least as close to float64 truth as the reference's own float32 CPU run (x4 slack)
+    assert np.abs(out - ref64).max() <= 4 * np.abs(g["w_f32"] - g["w_f64"]).max() + 1e-7 * scale
+
+
+@pytest.mark.parametrize("rows,in_f,out_f", [(64, 256, 32768), (1000, 512, 512), (130, 128, 200), (7, 64, 64)])
+def test_linear_forward_matches_float64(dev, rows, in_f, out_f):
+    from ganspace_amd import ops
+    rs = np.random.RandomState(rows)
+    x = rs.standard_normal((rows, in_f)).astype(np.float32)
+    W = (rs.standard_normal((out_f, in_f)) / np.sqrt(in_f)).astype(np.float32)
+    b = rs.standard_normal(out_f).astype(np.float32)
+    y = ops.linear_forward(torch.from_numpy(x).to(dev), torch.from_numpy(W).to(dev), torch.from_numpy(b).to(dev))
+    ref = synth.linear(x, W, b)
+    assert np.abs(y.cpu().numpy() - ref).max() < 1e-5 * np.abs(ref).max()
+
+
+# ---- BASELINE-size properties (no oracle at this size: size-independent invariants) --------------
+
+def test_full_size_block_properties(dev):
+    """cfg2 block shape [10 000, 512]: Gram symmetry/linearity, trace identity, and the eigen
+    residual of the exact-mode result, checked with float64 torch matmuls on the device."""
+    from ganspace_amd import ops
+    from ganspace_amd.estimators import IPCAEstimator
+    gen = torch.Generator(device="cpu").manual_seed(0)
+    A = torch.randn(160, 512, generator=gen, dtype=torch.float64) * (1.04 ** -torch.arange(160.0, dtype=torch.float64))[:, None]
+    est = IPCAEstimator(80, "exact")
+    C = torch.zeros(512, 512, dtype=torch.float64, device=dev)
+    s1 = torch.zeros(512, dtype=torch.float64, device=dev)
+    n = 0
+    for i in range(4):
+        Z = torch.randn(10000, 160, generator=gen, dtype=torch.float64)
+        X = (Z @ A + 0.05 * torch.randn(10000, 512, generator=gen, dtype=torch.float64) + 0.1).float().to(dev)
+        assert est.fit_partial(X)
+        Xd = X.double()
+        C += Xd.T @ Xd
+        s1 += Xd.sum(0)
+        n += X.shape[0]
+    mean = s1 / n
+    Cc = C - n * torch.outer(mean, mean)
+    t = est.transformer
+    V = torch.from_numpy(t.components_).to(dev).double()
+    lam = torch.from_numpy(t.singular_values_).to(dev) ** 2
+    assert (V @ V.T - torch.eye(80, dtype=torch.float64, device=dev)).abs().max().item() < 1e-6
+    resid = (Cc @ V.T - V.T * lam).abs().max().item()
+    assert resid < 2e-5 * lam[0].item()
+    np.testing.assert_allclose(t.mean_, mean.cpu().numpy(), atol=1e-6)
+    np.testing.assert_allclose(t.var_ * n, torch.diag(Cc).cpu().numpy(), rtol=1e-5)
+    assert abs(float(np.sum(t.explained_variance_ratio_)) - (lam.sum() / torch.trace(Cc)).item()) < 1e-6
+    assert int(t.n_samples_seen_) == n
