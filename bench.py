@@ -1,0 +1,217 @@
+#!/usr/bin/env python3
+"""Headline benchmark: latent samples/s into the PCA (BASELINE.json metric).
+
+Workload = BASELINE config 2: StyleGAN2-ffhq W-space, -n=1_000_000 -b=10_000 -c=80 on one
+MI355X with a random-init mapping network.  A *step* is one IPCA block (NB = 10 000 rows x
+512 features, float32, already resident in HBM) pushed through ``fit_partial``; after the K
+timed steps the job is completed inside the timed region (multi-GPU: the RCCL all-reduce of
+the sufficient statistics; then the eigensolve and the device->host copy of the components),
+so ``value`` is whole-job throughput.  Default K = 100 is exactly n = 1e6 samples per GPU.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--mode exact|faithful]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line (plus human-readable notes on stderr).
+"""
+import argparse
+import ctypes as C
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+D, NB, K_COMP = 512, 10_000, 80
+PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_HBM_GBS = 8000.0             # HBM3E spec
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def make_mapping_weights(dev):
+    """Random-init StyleGAN2 mapping network: weight = randn(out,in)/lr_mul, bias 0."""
+    g = torch.Generator(device="cpu").manual_seed(0)
+    W = torch.randn(8, D, D, generator=g) / 0.01
+    return W.to(dev), torch.zeros(8, D, device=dev)
+
+
+def make_latents(n_blocks, dev, rank):
+    """W-space latents [n_blocks*NB, 512] float32 in HBM: z ~ N(0,1) -> style(z) (HIP kernel)."""
+    from ganspace_amd import ops
+    W, b = make_mapping_weights(dev)
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+    out = torch.empty((n_blocks * NB, D), dtype=torch.float32, device=dev)
+    for i in range(n_blocks):
+        z = torch.randn((NB, D), generator=g, device=dev, dtype=torch.float32)
+        out[i * NB:(i + 1) * NB] = ops.mapping_forward(z, W, b)
+    torch.cuda.synchronize()
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--mode", default="exact", choices=["exact", "faithful"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-blocks", type=int, default=16)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    from ganspace_amd import _lib, distributed as gdist
+    from ganspace_amd.estimators import IPCAEstimator
+    lib = _lib.load()
+
+    K, Wm = args.steps, args.warmup
+    n_blocks = max(K, Wm, 1)
+    t0 = time.perf_counter()
+    lat = make_latents(n_blocks, dev, rank)
+    t_sample = time.perf_counter() - t0
+    blocks = [lat[i * NB:(i + 1) * NB] for i in range(n_blocks)]
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def run(est, nsteps, finish=True):
+        for i in range(nsteps):
+            ok = est.fit_partial(blocks[i % n_blocks])
+            assert ok
+        if finish:
+            if dist is not None and args.mode == "exact":
+                gdist.allreduce_estimator(est)
+            est.get_components()           # eigensolve (exact mode) + D2H of the results
+
+    # ---- warm-up (untimed) ------------------------------------------------------------------
+    warm = IPCAEstimator(K_COMP, args.mode)
+    run(warm, Wm, finish=Wm > 0)
+    del warm
+
+    # ---- timed region ------------------------------------------------------------------------
+    est = IPCAEstimator(K_COMP, args.mode)
+    est.transformer._ensure(D)             # allocate the handle outside the timed region
+    barrier()
+    t0 = time.perf_counter()
+    run(est, K)
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    samples = K * NB * world
+    value = samples / dt
+
+    # ---- split of the job: update loop vs finalize ----------------------------------------------
+    est2 = IPCAEstimator(K_COMP, args.mode)
+    est2.transformer._ensure(D)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(est2, K, finish=False)
+    torch.cuda.synchronize()
+    t_updates = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    est2.get_components()
+    torch.cuda.synchronize()
+    t_final = time.perf_counter() - t0
+
+    # ---- roofline of the dominant kernel (partial X^T X MFMA kernel), HIP events on its stream ---
+    avg_ms = C.c_float(0)
+    rows_timed = C.c_int64(0)
+    _lib.check(lib.gs_gram_kernel_time(est2.transformer._h, C.c_void_p(blocks[0].data_ptr()), NB, D, 50,
+                                       C.cast(C.byref(avg_ms), C.c_void_p),
+                                       C.cast(C.byref(rows_timed), C.c_void_p), _lib.current_stream_ptr()))
+    rows_l = rows_timed.value
+    flops = rows_l * D * (D + 1)           # algorithmic: upper triangle incl. diagonal, 2 flop/MAC
+    bytes_ = rows_l * D * 4                # algorithmic: one read of the [rows, d] f32 block
+    ach_tf = flops / (avg_ms.value * 1e-3) / 1e12
+    ach_gbs = bytes_ / (avg_ms.value * 1e-3) / 1e9
+    roofline = {"bound": "mfma", "kernel": "gram_partial_kernel<true>", "achieved": round(ach_tf, 2),
+                "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach_tf / PEAK_F32_MFMA_TFLOPS, 4),
+                "traffic": None, "avg_launch_us": round(avg_ms.value * 1e3, 2), "rows_per_launch": rows_l,
+                "algorithmic_flops_per_launch": flops, "algorithmic_bytes_per_launch": bytes_,
+                "hbm_achieved_GBs": round(ach_gbs, 1), "hbm_frac_of_8TBs": round(ach_gbs / PEAK_HBM_GBS, 4)}
+
+    out = {
+        "metric": "latent samples/sec into PCA (n=1e6) + top-20 component cos-sim vs reference",
+        "value": round(value, 1), "unit": "samples/s", "n_gpus": world, "steps": K, "warmup": Wm,
+        "ms_per_step": round(dt / K * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "cfg2: StyleGAN2-ffhq W-space PCA, -n=%d -b=10_000 -c=80 per GPU, "
+                               "random-init mapping network, activations resident in HBM" % (K * NB),
+                   "mode": args.mode, "feat_dim": D, "block_rows": NB, "components": K_COMP,
+                   "parallelism": f"dp{world} (rows sharded, one RCCL all-reduce of n/mean/scatter)"},
+        "roofline": roofline,
+        "breakdown": {"update_loop_s": round(t_updates, 5), "finalize_eigensolve_s": round(t_final, 5),
+                      "sampling_zgen_plus_mapping_s": round(t_sample, 4),
+                      "eigh_sweeps": int(getattr(est2.transformer, "_last_sweeps", 0) or 0)},
+    }
+
+    # ---- CPU baseline + cos-sim on a bounded sample (rank 0, N=1 only) -----------------------------
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import reference_cpu
+        from oracle.ipca import signed_cosines
+        nb = min(args.cpu_blocks, n_blocks)
+        host_blocks = [b.cpu().numpy() for b in blocks[:nb]]
+        ref, t_cpu, n_cpu = reference_cpu.time_reference_fit(host_blocks, K_COMP)
+        cores = reference_cpu.host_threads()
+        out["cpu_baseline"] = {"value": round(n_cpu / t_cpu, 1), "unit": "samples/s", "cores": cores,
+                               "kind": "reference",
+                               "sample": f"first {nb} of the {K} blocks ({n_cpu} samples, {t_cpu:.1f} s): "
+                                         "sklearn IncrementalPCA.partial_fit configured as "
+                                         "estimators.py:59 (the arithmetic the reference executes), "
+                                         f"host cpu_count={os.cpu_count()}"}
+        cos = {}
+        for mode in ("exact", "faithful"):
+            e = IPCAEstimator(K_COMP, mode)
+            for b in blocks[:nb]:
+                e.fit_partial(b)
+            c = signed_cosines(e.get_components()[0], ref.components_)
+            cos[mode] = {"top20_min_signed_cos": round(float(c[:20].min()), 7),
+                         "all80_min_abs_cos": round(float(np.abs(c).min()), 5)}
+            if mode == "faithful":
+                # throughput of the sklearn-faithful mode on the same sample (one eigensolve per block)
+                torch.cuda.synchronize()
+                e2 = IPCAEstimator(K_COMP, mode)
+                t0 = time.perf_counter()
+                for b in blocks[:nb]:
+                    e2.fit_partial(b)
+                e2.get_components()
+                torch.cuda.synchronize()
+                cos[mode]["samples_per_s"] = round(nb * NB / (time.perf_counter() - t0), 1)
+        out["cos_sim_vs_reference"] = cos
+        out["vs_cpu_baseline"] = round(value / out["cpu_baseline"]["value"], 1)
+
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -53,6 +53,10 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch must be imported first: its wheel bundles the HIP runtime under the same SONAME
+    # (libamdhip64.so.7) as /opt/rocm, and streams / device pointers are only interchangeable
+    # when both sides resolve to ONE runtime instance - the one torch already loaded.
+    import torch  # noqa: F401
     path = os.environ.get("GANSPACE_HIP_LIB", _build.lib_path())
     if not os.path.exists(path):
         raise RuntimeError(
