@@ -24,6 +24,8 @@
 //     re-read from that XCD's L2.
 //   * the shift s (running mean, float32) is subtracted while staging, which keeps the
 //     accumulated scatter centred (no catastrophic cancellation for |mean| >> stdev).
+#include <cstdlib>
+
 #include "gs_common.h"
 
 namespace gs {
@@ -45,28 +47,162 @@ __device__ __forceinline__ void decode_upper(int idx, int T, int &I, int &J) {
     J = i + idx;
 }
 
+// Raw (un-shifted) float4 of X at a CLAMPED address: never out of bounds, never branches, and
+// nothing depends on the loaded value until `finish` runs - so all loads of a stage stay in
+// flight behind the MFMAs instead of being waited for one by one.
 template <bool VEC>
-__device__ __forceinline__ float4 load_shifted(const float *__restrict__ X, int64_t row, int64_t r1,
-                                               int64_t ld, int col, int d, float4 sh) {
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (row < r1) {
-        const float *p = X + row * ld + col;
-        if (VEC) {
-            if (col < d) {
-                v = *reinterpret_cast<const float4 *>(p);
-                v.x -= sh.x;
-                v.y -= sh.y;
-                v.z -= sh.z;
-                v.w -= sh.w;
+__device__ __forceinline__ float4 load_raw(const float *__restrict__ X, int64_t row, int64_t last_row,
+                                           int64_t ld, int col, int d) {
+    const int64_t rc = row < last_row ? row : last_row;
+    if (VEC) {
+        const int cc = col < d ? col : 0;
+        return *reinterpret_cast<const float4 *>(X + rc * ld + cc);
+    } else {
+        const float *p = X + rc * ld;
+        const int dm = d - 1;
+        float4 v;
+        v.x = p[col + 0 < dm ? col + 0 : dm];
+        v.y = p[col + 1 < dm ? col + 1 : dm];
+        v.z = p[col + 2 < dm ? col + 2 : dm];
+        v.w = p[col + 3 < dm ? col + 3 : dm];
+        return v;
+    }
+}
+
+__device__ __forceinline__ float4 finish(float4 v, float4 sh, bool row_ok, int col, int d) {
+    v.x = (row_ok && col + 0 < d) ? v.x - sh.x : 0.f;
+    v.y = (row_ok && col + 1 < d) ? v.y - sh.y : 0.f;
+    v.z = (row_ok && col + 2 < d) ? v.z - sh.z : 0.f;
+    v.w = (row_ok && col + 3 < d) ? v.w - sh.w : 0.f;
+    return v;
+}
+
+struct GramTileCtx {
+    const float *X;
+    int64_t ld, r0, r1;
+    int d, dp, chunk, I, J;
+    float *P, *CS;
+    const float *shift;
+};
+
+// Main loop of one (macro tile, row chunk) workgroup.  DIAG is wave-uniform per workgroup and
+// is a template parameter so that the pipelined loop contains no control flow at all.
+template <bool VEC, bool DIAG>
+__device__ __forceinline__ void gram_tile(const GramTileCtx &c, float (*lds)[2][kKB][kMacroTile]) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wi = wave >> 1, wj = wave & 1;
+    const bool active = !(DIAG && wi == 1 && wj == 0);
+    const int c4 = tid & 31, rr = tid >> 5;
+    const int colA = c.I * kMacroTile + c4 * 4, colB = c.J * kMacroTile + c4 * 4;
+    const float4 shA = *reinterpret_cast<const float4 *>(c.shift + colA);
+    const float4 shB = *reinterpret_cast<const float4 *>(c.shift + colB);
+    const int d = c.d;
+    const int64_t r1 = c.r1, ld = c.ld;
+
+    float4 ra[4], rb[4];
+    float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    auto fetch = [&](int64_t rbase) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            ra[i] = load_raw<VEC>(c.X, rbase + rr + 8 * i, r1 - 1, ld, colA, d);
+            if (!DIAG) rb[i] = load_raw<VEC>(c.X, rbase + rr + 8 * i, r1 - 1, ld, colB, d);
+        }
+    };
+    auto stash = [&](int buf, int64_t rbase) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bool ok = rbase + rr + 8 * i < r1;
+            const float4 va = finish(ra[i], shA, ok, colA, d);
+            *reinterpret_cast<float4 *>(&lds[buf][0][rr + 8 * i][c4 * 4]) = va;
+            if (!DIAG) {
+                const float4 vb = finish(rb[i], shB, ok, colB, d);
+                *reinterpret_cast<float4 *>(&lds[buf][1][rr + 8 * i][c4 * 4]) = vb;
+            } else {
+                cs.x += va.x;
+                cs.y += va.y;
+                cs.z += va.z;
+                cs.w += va.w;
             }
-        } else {
-            if (col + 0 < d) v.x = p[0] - sh.x;
-            if (col + 1 < d) v.y = p[1] - sh.y;
-            if (col + 2 < d) v.z = p[2] - sh.z;
-            if (col + 3 < d) v.w = p[3] - sh.w;
+        }
+    };
+
+    f32x16 acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};
+    const int nst = (int)((r1 - c.r0 + kKB - 1) / kKB);
+    const int arow = lane >> 5;
+    const int acol = wi * kWaveTile + (lane & 31);
+    const int bcol = wj * kWaveTile + (lane & 31);
+
+    if (nst > 0) {
+        fetch(c.r0);
+        stash(0, c.r0);
+    }
+    __syncthreads();
+    for (int s = 0; s < nst; ++s) {
+        const int buf = s & 1;
+        const int64_t rnext = c.r0 + (int64_t)(s + 1) * kKB;
+        if (s + 1 < nst) fetch(rnext);
+        if (active) {
+            const float *A = &lds[buf][0][arow][acol];
+            const float *B = &lds[buf][DIAG ? 0 : 1][arow][bcol];
+            // fragments of k-step k+2 are read while the MFMAs of k-step k run
+            float a0 = A[0], a1 = A[32], b0 = B[0], b1 = B[32];
+#pragma unroll
+            for (int k = 0; k < kKB; k += 2) {
+                float na0 = 0.f, na1 = 0.f, nb0 = 0.f, nb1 = 0.f;
+                if (k + 2 < kKB) {
+                    na0 = A[(k + 2) * kMacroTile];
+                    na1 = A[(k + 2) * kMacroTile + 32];
+                    nb0 = B[(k + 2) * kMacroTile];
+                    nb1 = B[(k + 2) * kMacroTile + 32];
+                }
+                acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc00, 0, 0, 0);
+                acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc01, 0, 0, 0);
+                acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc10, 0, 0, 0);
+                acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc11, 0, 0, 0);
+                // pin the order: the two LDS reads of the NEXT k-step issue ahead of this step's MFMAs
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                a0 = na0;
+                a1 = na1;
+                b0 = nb0;
+                b1 = nb1;
+            }
+        }
+        if (s + 1 < nst) stash(buf ^ 1, rnext);
+        __syncthreads();
+    }
+
+    // ---- epilogue: 64x64 wave tile -> this chunk's float32 slab --------------------------
+    if (active) {
+        float *Pc = c.P + (int64_t)c.chunk * c.dp * c.dp;
+        const int row_base = c.I * kMacroTile + wi * kWaveTile + 4 * (lane >> 5);
+        const int col_base = c.J * kMacroTile + wj * kWaveTile + (lane & 31);
+        const int64_t dp = c.dp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = row_base + (r & 3) + 8 * (r >> 2);
+            Pc[(int64_t)row * dp + col_base] = acc00[r];
+            Pc[(int64_t)row * dp + col_base + 32] = acc01[r];
+            Pc[(int64_t)(row + 32) * dp + col_base] = acc10[r];
+            Pc[(int64_t)(row + 32) * dp + col_base + 32] = acc11[r];
         }
     }
-    return v;
+    // ---- column sums of panel I (diagonal macro tiles only; each panel is diagonal once) --
+    if (DIAG) {
+        float *scr = &lds[0][0][0][0];
+        scr[rr * kMacroTile + c4 * 4 + 0] = cs.x;
+        scr[rr * kMacroTile + c4 * 4 + 1] = cs.y;
+        scr[rr * kMacroTile + c4 * 4 + 2] = cs.z;
+        scr[rr * kMacroTile + c4 * 4 + 3] = cs.w;
+        __syncthreads();
+        if (tid < kMacroTile) {
+            float t = 0.f;
+#pragma unroll
+            for (int g = 0; g < 8; ++g) t += scr[g * kMacroTile + tid];
+            c.CS[(int64_t)c.chunk * c.dp + c.I * kMacroTile + tid] = t;
+        }
+    }
 }
 
 template <bool VEC>
@@ -78,111 +214,23 @@ __global__ __launch_bounds__(kThreads, 2) void gram_partial_kernel(
 
     const int b = blockIdx.x;
     const int xcd = b & 7, local = b >> 3;
-    const int chunk = (local / nmt) * 8 + xcd;
-    const int mt = local % nmt;
-    if (chunk >= nchunks) return;
-
-    int I, J;
-    decode_upper(mt, T, I, J);
-    const bool diag = (I == J);
-    const int64_t r0 = (int64_t)chunk * chunk_rows;
-    const int64_t r1 = (r0 + chunk_rows < rows) ? r0 + chunk_rows : rows;
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wi = wave >> 1, wj = wave & 1;
-    const bool active = !(diag && wi == 1 && wj == 0);
-
-    const int c4 = tid & 31, rr = tid >> 5;
-    const int colA = I * kMacroTile + c4 * 4, colB = J * kMacroTile + c4 * 4;
-    const float4 shA = *reinterpret_cast<const float4 *>(shift + colA);
-    const float4 shB = *reinterpret_cast<const float4 *>(shift + colB);
-
-    float4 ra[4], rb[4];
-    float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
-
-    auto fetch = [&](int64_t rbase) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            ra[i] = load_shifted<VEC>(X, rbase + rr + 8 * i, r1, ld, colA, d, shA);
-            if (!diag) rb[i] = load_shifted<VEC>(X, rbase + rr + 8 * i, r1, ld, colB, d, shB);
-        }
-    };
-    auto stash = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            *reinterpret_cast<float4 *>(&lds[buf][0][rr + 8 * i][c4 * 4]) = ra[i];
-            if (!diag) *reinterpret_cast<float4 *>(&lds[buf][1][rr + 8 * i][c4 * 4]) = rb[i];
-            if (diag) {
-                cs.x += ra[i].x;
-                cs.y += ra[i].y;
-                cs.z += ra[i].z;
-                cs.w += ra[i].w;
-            }
-        }
-    };
-
-    f32x16 acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};
-    const int nst = (int)((r1 - r0 + kKB - 1) / kKB);
-    const int arow = lane >> 5;
-    const int acol = wi * kWaveTile + (lane & 31);
-    const int bcol = wj * kWaveTile + (lane & 31);
-
-    if (nst > 0) {
-        fetch(r0);
-        stash(0);
-    }
-    __syncthreads();
-    for (int s = 0; s < nst; ++s) {
-        const int buf = s & 1;
-        if (s + 1 < nst) fetch(r0 + (int64_t)(s + 1) * kKB);
-        if (active) {
-            const float *A = &lds[buf][0][0][0];
-            const float *B = diag ? A : &lds[buf][1][0][0];
-#pragma unroll
-            for (int k = 0; k < kKB; k += 2) {
-                const float a0 = A[(k + arow) * kMacroTile + acol];
-                const float a1 = A[(k + arow) * kMacroTile + acol + 32];
-                const float b0 = B[(k + arow) * kMacroTile + bcol];
-                const float b1 = B[(k + arow) * kMacroTile + bcol + 32];
-                acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc00, 0, 0, 0);
-                acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc01, 0, 0, 0);
-                acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc10, 0, 0, 0);
-                acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc11, 0, 0, 0);
-            }
-        }
-        if (s + 1 < nst) stash(buf ^ 1);
-        __syncthreads();
-    }
-
-    // ---- epilogue: 64x64 wave tile -> this chunk's float32 slab --------------------------
-    if (active) {
-        float *Pc = P + (int64_t)chunk * dp * dp;
-        const int row_base = I * kMacroTile + wi * kWaveTile + 4 * (lane >> 5);
-        const int col_base = J * kMacroTile + wj * kWaveTile + (lane & 31);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = row_base + (r & 3) + 8 * (r >> 2);
-            Pc[(int64_t)row * dp + col_base] = acc00[r];
-            Pc[(int64_t)row * dp + col_base + 32] = acc01[r];
-            Pc[(int64_t)(row + 32) * dp + col_base] = acc10[r];
-            Pc[(int64_t)(row + 32) * dp + col_base + 32] = acc11[r];
-        }
-    }
-    // ---- column sums of panel I (diagonal macro tiles only; each panel is diagonal once) --
-    if (diag) {
-        float *scr = &lds[0][0][0][0];
-        scr[rr * kMacroTile + c4 * 4 + 0] = cs.x;
-        scr[rr * kMacroTile + c4 * 4 + 1] = cs.y;
-        scr[rr * kMacroTile + c4 * 4 + 2] = cs.z;
-        scr[rr * kMacroTile + c4 * 4 + 3] = cs.w;
-        __syncthreads();
-        if (tid < kMacroTile) {
-            float t = 0.f;
-#pragma unroll
-            for (int g = 0; g < 8; ++g) t += scr[g * kMacroTile + tid];
-            CS[(int64_t)chunk * dp + I * kMacroTile + tid] = t;
-        }
-    }
+    GramTileCtx c;
+    c.chunk = (local / nmt) * 8 + xcd;
+    if (c.chunk >= nchunks) return;
+    decode_upper(local % nmt, T, c.I, c.J);
+    c.X = X;
+    c.ld = ld;
+    c.d = d;
+    c.dp = dp;
+    c.P = P;
+    c.CS = CS;
+    c.shift = shift;
+    c.r0 = (int64_t)c.chunk * chunk_rows;
+    c.r1 = (c.r0 + chunk_rows < rows) ? c.r0 + chunk_rows : rows;
+    if (c.I == c.J)
+        gram_tile<VEC, true>(c, lds);
+    else
+        gram_tile<VEC, false>(c, lds);
 }
 
 // Fold the per-chunk float32 slabs into the float64 accumulators (upper 64x64 wave tiles).
@@ -263,7 +311,12 @@ static GramGeom gram_geometry(const GramWorkspace &ws, int64_t n) {
     g.T = dp / kMacroTile;
     g.nmt = g.T * (g.T + 1) / 2;
     // target ~2 workgroups per CU; chunks are multiples of 8 (one group of chunks per XCD)
-    g.want = (int)round_up(ceil_div(512, g.nmt), 8);
+    static const int target_wgs = []() {
+        const char *e = getenv("GS_GRAM_TARGET_WGS");
+        const int v = e ? atoi(e) : 0;
+        return v > 0 ? v : 512;
+    }();
+    g.want = (int)round_up(ceil_div(target_wgs, g.nmt), 8);
     if (g.want > ws.max_chunks) g.want = ws.max_chunks;
     g.rows_per_launch = (int64_t)g.want * kMaxChunkRows;
     if (n > g.rows_per_launch) n = g.rows_per_launch;
