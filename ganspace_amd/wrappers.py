@@ -1,0 +1,605 @@
+"""Model wrappers: the ``BaseModel`` surface of the reference (``models/wrappers.py:27-94``)
+and the two generator families the BASELINE configs name.
+
+No pretrained weights exist in this environment (no network; the StyleGAN2 generator source
+itself - submodule ``models/stylegan2/stylegan2-pytorch`` - is absent from the reference
+tree), so both generators are *synthetic*: random-init (``torch.manual_seed(0)``) networks
+with the layer names, shapes and call order the reference wrappers rely on:
+
+``StyleGAN2``  ``model.style`` (PixelNorm + 8 x EqualLinear(512, 512, lr_mul=0.01,
+               fused_lrelu)) runs on the hand-written f32-MFMA kernels
+               (``gs_mapping_forward``); ``strided_style``, ``input``, ``conv1``, ``to_rgb1``,
+               ``convs.N``, ``to_rgbs.N`` are ordinary PyTorch-ROCm modules (outside the
+               hand-written-kernel scope).
+``BigGAN``     ``embeddings`` and ``generator.gen_z`` (Linear 256 -> 32768, HIP
+               ``gs_linear_forward``) plus a small stand-in for ``generator.layers``.
+
+``sample_latent`` reproduces the reference's seeding protocol exactly
+(wrappers.py:167-179, 562-569): one ``np.random.randint(int32.max)`` from the
+GLOBAL legacy NumPy stream per call, then a private ``RandomState(seed)``.
+"""
+from __future__ import annotations
+
+import math
+import random
+import re
+from abc import ABC as AbstractBaseClass
+from abc import abstractmethod
+from functools import singledispatch
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+from .config import Config
+from .nethook import InstrumentedModel
+
+
+class BaseModel(AbstractBaseClass, nn.Module):
+    """Abstract wrapper; method-for-method the reference ``BaseModel`` (wrappers.py:27-94)."""
+
+    def __init__(self, model_name, class_name):
+        super().__init__()
+        self.model_name = model_name
+        self.outclass = class_name
+
+    @abstractmethod
+    def partial_forward(self, x, layer_name):
+        """Evaluate only up to ``layer_name``; the activation is read from the hook."""
+
+    @abstractmethod
+    def sample_latent(self, n_samples=1, seed=None, truncation=None):
+        """Batch of latent vectors."""
+
+    def get_max_latents(self):
+        return 1
+
+    def latent_space_name(self):
+        return "Z"
+
+    def get_latent_shape(self):
+        return tuple(self.sample_latent(1).shape)
+
+    def get_latent_dims(self):
+        return np.prod(self.get_latent_shape())
+
+    def set_output_class(self, new_class):
+        self.outclass = new_class
+
+    def forward(self, x):
+        out = self.model.forward(x)
+        return 0.5 * (out + 1)
+
+    def sample_np(self, z=None, n_samples=1, seed=None):
+        if z is None:
+            z = self.sample_latent(n_samples, seed=seed)
+        elif isinstance(z, list):
+            z = [torch.tensor(l).to(self.device) if not torch.is_tensor(l) else l for l in z]
+        elif not torch.is_tensor(z):
+            z = torch.tensor(z).to(self.device)
+        img = self.forward(z)
+        img_np = img.permute(0, 2, 3, 1).cpu().detach().numpy()
+        return np.clip(img_np, 0.0, 1.0).squeeze()
+
+    def get_conditional_state(self, z):
+        return None
+
+    def set_conditional_state(self, z, c):
+        return z
+
+    def named_modules(self, *args, **kwargs):
+        return self.model.named_modules(*args, **kwargs)
+
+
+# =================================================================================================
+# synthetic StyleGAN2 generator
+# =================================================================================================
+
+class MappingNetwork(nn.Module):
+    """``Generator.style``: PixelNorm + L x EqualLinear(dim, dim, lr_mul, 'fused_lrelu').
+
+    Parameters are stored as in the published definition (``weight = randn(out, in) / lr_mul``,
+    ``bias = zeros``); the forward pass is ONE call into the HIP library for device tensors.
+    """
+
+    def __init__(self, dim=512, n_layers=8, lr_mul=0.01):
+        super().__init__()
+        self.dim, self.n_layers, self.lr_mul = dim, n_layers, lr_mul
+        self.weight = nn.Parameter(torch.randn(n_layers, dim, dim) / lr_mul)
+        self.bias = nn.Parameter(torch.zeros(n_layers, dim))
+
+    def forward(self, z):
+        return ops.mapping_forward(z, self.weight.detach(), self.bias.detach(), lr_mul=self.lr_mul)
+
+
+class Identity(nn.Module):
+    """``strided_style``: per-layer pass-through so that nethook can name/edit W+ (A.5)."""
+
+    def forward(self, x):
+        return x
+
+
+class ConstantInput(nn.Module):
+    def __init__(self, channel, size=4):
+        super().__init__()
+        self.input = nn.Parameter(torch.randn(1, channel, size, size))
+
+    def forward(self, latent):
+        return self.input.repeat(latent.shape[0], 1, 1, 1)
+
+
+class ModulatedConv2d(nn.Module):
+    def __init__(self, in_ch, out_ch, k, style_dim, demodulate=True, upsample=False):
+        super().__init__()
+        self.in_ch, self.out_ch, self.k = in_ch, out_ch, k
+        self.demodulate, self.upsample = demodulate, upsample
+        self.scale = 1 / math.sqrt(in_ch * k * k)
+        self.weight = nn.Parameter(torch.randn(1, out_ch, in_ch, k, k))
+        self.mod_weight = nn.Parameter(torch.randn(in_ch, style_dim))
+        self.mod_bias = nn.Parameter(torch.ones(in_ch))
+        self.mod_scale = 1 / math.sqrt(style_dim)
+
+    def forward(self, x, style):
+        b, c, h, w = x.shape
+        s = F.linear(style, self.mod_weight * self.mod_scale, self.mod_bias).view(b, 1, c, 1, 1)
+        wgt = self.scale * self.weight * s
+        if self.demodulate:
+            wgt = wgt * torch.rsqrt(wgt.pow(2).sum([2, 3, 4]) + 1e-8).view(b, self.out_ch, 1, 1, 1)
+        wgt = wgt.view(b * self.out_ch, c, self.k, self.k)
+        if self.upsample:
+            x = F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=False)
+            h, w = h * 2, w * 2
+        out = F.conv2d(x.reshape(1, b * c, h, w), wgt, padding=self.k // 2, groups=b)
+        return out.view(b, self.out_ch, h, w)
+
+
+class StyledConv(nn.Module):
+    def __init__(self, in_ch, out_ch, k, style_dim, upsample=False):
+        super().__init__()
+        self.conv = ModulatedConv2d(in_ch, out_ch, k, style_dim, upsample=upsample)
+        self.noise_weight = nn.Parameter(torch.zeros(1))
+        self.bias = nn.Parameter(torch.zeros(1, out_ch, 1, 1))
+
+    def forward(self, x, style, noise=None):
+        out = self.conv(x, style)
+        if noise is not None:
+            out = out + self.noise_weight * noise
+        return math.sqrt(2.0) * F.leaky_relu(out + self.bias, 0.2)
+
+
+class ToRGB(nn.Module):
+    def __init__(self, in_ch, style_dim, upsample=True):
+        super().__init__()
+        self.upsample = upsample
+        self.conv = ModulatedConv2d(in_ch, 3, 1, style_dim, demodulate=False)
+        self.bias = nn.Parameter(torch.zeros(1, 3, 1, 1))
+
+    def forward(self, x, style, skip=None):
+        out = self.conv(x, style) + self.bias
+        if skip is not None:
+            if self.upsample:
+                skip = F.interpolate(skip, scale_factor=2, mode="bilinear", align_corners=False)
+            out = out + skip
+        return out
+
+
+class SyntheticStyleGAN2Generator(nn.Module):
+    """``Generator(size, 512, 8)`` with the attribute set the reference wrapper touches
+    (wrappers.py:157,177,200-255,263-267): style, strided_style, input, conv1, to_rgb1, convs,
+    to_rgbs, n_latent, log_size."""
+
+    def __init__(self, size, style_dim=512, n_mlp=8, channel_multiplier=2):
+        super().__init__()
+        self.size, self.style_dim = size, style_dim
+        self.style = MappingNetwork(style_dim, n_mlp)
+        self.strided_style = Identity()
+        ch = {4: 512, 8: 512, 16: 512, 32: 512, 64: 256 * channel_multiplier, 128: 128 * channel_multiplier,
+              256: 64 * channel_multiplier, 512: 32 * channel_multiplier, 1024: 16 * channel_multiplier}
+        self.input = ConstantInput(ch[4])
+        self.conv1 = StyledConv(ch[4], ch[4], 3, style_dim)
+        self.to_rgb1 = ToRGB(ch[4], style_dim, upsample=False)
+        self.log_size = int(math.log2(size))
+        self.n_latent = self.log_size * 2 - 2
+        self.convs, self.to_rgbs = nn.ModuleList(), nn.ModuleList()
+        in_ch = ch[4]
+        for i in range(3, self.log_size + 1):
+            out_ch = ch[2 ** i]
+            self.convs.append(StyledConv(in_ch, out_ch, 3, style_dim, upsample=True))
+            self.convs.append(StyledConv(out_ch, out_ch, 3, style_dim))
+            self.to_rgbs.append(ToRGB(out_ch, style_dim))
+            in_ch = out_ch
+
+    def forward(self, styles, noise=None, truncation=1, truncation_latent=None, input_is_w=False):
+        if not input_is_w:
+            styles = [self.style(s) for s in styles]
+        if truncation < 1:
+            styles = [truncation_latent + truncation * (s - truncation_latent) for s in styles]
+        if len(styles) == 1:
+            latent = styles[0].unsqueeze(1).repeat(1, self.n_latent, 1)
+        else:
+            latent = torch.stack(styles, dim=1) if len(styles) == self.n_latent else \
+                torch.cat([styles[0].unsqueeze(1).repeat(1, self.n_latent // 2, 1),
+                           styles[1].unsqueeze(1).repeat(1, self.n_latent - self.n_latent // 2, 1)], 1)
+        latent = self.strided_style(latent)
+        noise = noise or [None] * (self.n_latent - 1)
+        out = self.input(latent)
+        out = self.conv1(out, latent[:, 0], noise=noise[0])
+        skip = self.to_rgb1(out, latent[:, 1])
+        i = 1
+        for conv1, conv2, to_rgb in zip(self.convs[::2], self.convs[1::2], self.to_rgbs):
+            out = conv1(out, latent[:, i], noise=noise[i])
+            out = conv2(out, latent[:, i + 1], noise=noise[i + 1])
+            skip = to_rgb(out, latent[:, i + 2], skip)
+            i += 2
+        return skip, None
+
+
+class StyleGAN2(BaseModel):
+    """Mirror of the reference ``StyleGAN2`` wrapper (wrappers.py:97-267) on a synthetic generator."""
+
+    CONFIGS = {"ffhq": 1024, "car": 512, "cat": 256, "church": 256, "horse": 256,
+               "bedrooms": 256, "kitchen": 256, "places": 256}
+
+    def __init__(self, device, class_name, truncation=1.0, use_w=False):
+        super().__init__("StyleGAN2", class_name or "ffhq")
+        self.device = device
+        self.truncation = truncation
+        self.latent_avg = None
+        self.w_primary = use_w
+        assert self.outclass in self.CONFIGS, \
+            f'Invalid StyleGAN2 class {self.outclass}, should be one of [{", ".join(self.CONFIGS.keys())}]'
+        self.resolution = self.CONFIGS[self.outclass]
+        self.name = f"StyleGAN2-{self.outclass}"
+        self.has_latent_residual = True
+        self.load_model()
+        self.set_noise_seed(0)
+
+    def latent_space_name(self):
+        return "W" if self.w_primary else "Z"
+
+    def use_w(self):
+        self.w_primary = True
+
+    def use_z(self):
+        self.w_primary = False
+
+    def load_model(self):
+        # random-init weights, reproducible: the BASELINE configs say "random-init generator weights"
+        rng_state = torch.random.get_rng_state()
+        torch.manual_seed(0)
+        self.model = SyntheticStyleGAN2Generator(self.resolution, 512, 8).to(self.device)
+        torch.random.set_rng_state(rng_state)
+        self.latent_avg = torch.zeros(512, device=self.device)
+
+    def sample_latent(self, n_samples=1, seed=None, truncation=None):
+        if seed is None:
+            seed = np.random.randint(np.iinfo(np.int32).max)  # use (reproducible) global rand state
+        rng = np.random.RandomState(seed)
+        z = torch.from_numpy(rng.standard_normal(512 * n_samples).reshape(n_samples, 512)).float().to(self.device)
+        if self.w_primary:
+            z = self.model.style(z)
+        return z
+
+    def get_max_latents(self):
+        return self.model.n_latent
+
+    def set_output_class(self, new_class):
+        if self.outclass != new_class:
+            raise RuntimeError("StyleGAN2: cannot change output class without reloading")
+
+    def forward(self, x):
+        x = x if isinstance(x, list) else [x]
+        out, _ = self.model(x, noise=self.noise, truncation=self.truncation,
+                            truncation_latent=self.latent_avg, input_is_w=self.w_primary)
+        return 0.5 * (out + 1)
+
+    def partial_forward(self, x, layer_name):
+        styles = x if isinstance(x, list) else [x]
+        inject_index = None
+        noise = self.noise
+        if not self.w_primary:
+            styles = [self.model.style(s) for s in styles]
+        if len(styles) == 1:
+            inject_index = self.model.n_latent
+            latent = self.model.strided_style(styles[0].unsqueeze(1).repeat(1, inject_index, 1))
+        elif len(styles) == 2:
+            if inject_index is None:
+                inject_index = random.randint(1, self.model.n_latent - 1)
+            latent = styles[0].unsqueeze(1).repeat(1, inject_index, 1)
+            latent2 = styles[1].unsqueeze(1).repeat(1, self.model.n_latent - inject_index, 1)
+            latent = self.model.strided_style(torch.cat([latent, latent2], 1))
+        else:
+            assert len(styles) == self.model.n_latent, \
+                f"Expected {self.model.n_latent} latents, got {len(styles)}"
+            latent = self.model.strided_style(torch.stack(styles, dim=1))
+
+        if "style" in layer_name:
+            return
+        out = self.model.input(latent)
+        if "input" == layer_name:
+            return
+        out = self.model.conv1(out, latent[:, 0], noise=noise[0])
+        if "conv1" in layer_name:
+            return
+        skip = self.model.to_rgb1(out, latent[:, 1])
+        if "to_rgb1" in layer_name:
+            return
+        i = 1
+        noise_i = 1
+        for conv1, conv2, to_rgb in zip(self.model.convs[::2], self.model.convs[1::2], self.model.to_rgbs):
+            out = conv1(out, latent[:, i], noise=noise[noise_i])
+            if f"convs.{i-1}" in layer_name:
+                return
+            out = conv2(out, latent[:, i + 1], noise=noise[noise_i + 1])
+            if f"convs.{i}" in layer_name:
+                return
+            skip = to_rgb(out, latent[:, i + 2], skip)
+            if f"to_rgbs.{i//2}" in layer_name:
+                return
+            i += 2
+            noise_i += 2
+        raise RuntimeError(f"Layer {layer_name} not encountered in partial_forward")
+
+    def set_noise_seed(self, seed):
+        rng_state = torch.random.get_rng_state()
+        torch.manual_seed(seed)
+        self.noise = [torch.randn(1, 1, 2 ** 2, 2 ** 2).to(self.device)]
+        for i in range(3, self.model.log_size + 1):
+            for _ in range(2):
+                self.noise.append(torch.randn(1, 1, 2 ** i, 2 ** i).to(self.device))
+        torch.random.set_rng_state(rng_state)
+
+
+# =================================================================================================
+# synthetic BigGAN (deep-512 geometry for the path: z 128, class embedding 128, gen_z 256 -> 32768)
+# =================================================================================================
+
+class HipLinear(nn.Module):
+    """``nn.Linear`` whose forward is the f32-MFMA ``gs_linear_forward`` kernel."""
+
+    def __init__(self, in_features, out_features, bias=True):
+        super().__init__()
+        self.in_features, self.out_features = in_features, out_features
+        self.weight = nn.Parameter(torch.randn(out_features, in_features) / math.sqrt(in_features))
+        self.bias = nn.Parameter(torch.randn(out_features) * 0.1) if bias else None
+
+    def forward(self, x):
+        return ops.linear_forward(x, self.weight.detach(), None if self.bias is None else self.bias.detach())
+
+
+class _BigGANBlock(nn.Module):
+    def __init__(self, cin, cout, cond_dim, up):
+        super().__init__()
+        self.up = up
+        self.gain = nn.Linear(cond_dim, cin)
+        self.conv = nn.Conv2d(cin, cout, 3, padding=1)
+
+    def forward(self, x, cond, truncation=1.0):
+        x = x * (1 + 0.1 * self.gain(cond)).unsqueeze(-1).unsqueeze(-1)
+        if self.up:
+            x = F.interpolate(x, scale_factor=2, mode="nearest")
+        return self.conv(F.relu(x))
+
+
+GenBlock = _BigGANBlock
+
+
+class _BigGANGenerator(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.config = cfg
+        ch = cfg.channel_width
+        self.gen_z = HipLinear(2 * cfg.z_dim, 4 * 4 * 16 * ch)
+        widths = [16 * ch] + [max(ch, 16 * ch // (2 ** (i // 2 + 1))) for i in range(len(cfg.layers))]
+        self.layers = nn.ModuleList([
+            GenBlock(widths[i], widths[i + 1], 2 * cfg.z_dim, up) for i, (up, _, _) in enumerate(cfg.layers)])
+        self.to_rgb = nn.Conv2d(widths[-1], 3, 3, padding=1)
+
+    def forward(self, cond_vectors, truncation):
+        z = self.gen_z(cond_vectors[0])
+        z = z.view(-1, 4, 4, 16 * self.config.channel_width).permute(0, 3, 1, 2).contiguous()
+        for i, layer in enumerate(self.layers):
+            z = layer(z, cond_vectors[i + 1], truncation)
+        return torch.tanh(self.to_rgb(F.relu(z)))
+
+
+class SyntheticBigGAN(nn.Module):
+    """``biggan.BigGAN`` surface used by the wrapper: ``embeddings``, ``generator``, ``config``,
+    ``n_latents`` (biggan/.../model.py:255-311 with per-layer latents)."""
+
+    def __init__(self, resolution=512):
+        super().__init__()
+        n_up = int(math.log2(resolution)) - 2
+        layers = [(i % 2 == 1, 0, 0) for i in range(2 * n_up)]      # (upsample, in, out) placeholders
+        self.config = SimpleNamespace(output_dim=resolution, z_dim=128, class_embed_dim=128, channel_width=128,
+                                      num_classes=1000, layers=layers)
+        self.embeddings = nn.Linear(1000, 128, bias=False)
+        self.generator = _BigGANGenerator(self.config)
+        self.n_latents = len(layers) + 1
+
+    def forward(self, z, class_label, truncation):
+        if not isinstance(z, list):
+            z = self.n_latents * [z]
+        if not isinstance(class_label, list):
+            class_label = self.n_latents * [class_label]
+        cond = [torch.cat((zz, self.embeddings(c)), dim=1) for zz, c in zip(z, class_label)]
+        return self.generator(cond, truncation)
+
+
+def truncated_noise_sample(batch_size=1, dim_z=128, truncation=1.0, seed=None):
+    """``biggan/.../utils.py:21-33``: truncnorm[-2, 2] draws from ``RandomState(seed)``."""
+    from scipy.stats import truncnorm
+    state = None if seed is None else np.random.RandomState(seed)
+    values = truncnorm.rvs(-2, 2, size=(batch_size, dim_z), random_state=state).astype(np.float32)
+    return truncation * values
+
+
+class BigGAN(BaseModel):
+    """Mirror of the reference ``BigGAN`` wrapper (wrappers.py:525-648); classes are given as
+    integers (the name lookup of the reference needs nltk, absent here)."""
+
+    def __init__(self, device, resolution, class_name, truncation=1.0):
+        super().__init__(f"BigGAN-{resolution}", class_name)
+        self.device = device
+        self.truncation = truncation
+        self.load_model(f"biggan-deep-{resolution}")
+        self.set_output_class(class_name if class_name is not None else 250)
+        self.name = f"BigGAN-{resolution}-{self.outclass}-t{self.truncation}"
+        self.has_latent_residual = True
+
+    def load_model(self, name):
+        m = re.match(r"^biggan-deep-(128|256|512)$", name)
+        if not m:
+            raise RuntimeError("Unknown BigGAN model name", name)
+        rng_state = torch.random.get_rng_state()
+        torch.manual_seed(0)
+        self.model = SyntheticBigGAN(int(m.group(1))).to(self.device)
+        torch.random.set_rng_state(rng_state)
+
+    def sample_latent(self, n_samples=1, truncation=None, seed=None):
+        if seed is None:
+            seed = np.random.randint(np.iinfo(np.int32).max)
+        noise_vector = truncated_noise_sample(truncation=truncation or self.truncation, batch_size=n_samples,
+                                              seed=seed)
+        return torch.from_numpy(noise_vector).to(self.device)
+
+    def get_max_latents(self):
+        return len(self.model.config.layers) + 1
+
+    def get_conditional_state(self, z):
+        return self.v_class
+
+    def set_conditional_state(self, z, c):
+        self.v_class = c
+
+    def is_valid_class(self, class_id):
+        if isinstance(class_id, int):
+            return class_id < 1000
+        raise RuntimeError(f"Unknown class identifier {class_id}")
+
+    def set_output_class(self, class_id):
+        if isinstance(class_id, str) and class_id.isdigit():
+            class_id = int(class_id)
+        if isinstance(class_id, int):
+            onehot = np.zeros((1, 1000), dtype=np.float32)
+            onehot[0, class_id] = 1.0
+            self.v_class = torch.from_numpy(onehot).to(self.device)
+            self.outclass = f"class{class_id}"
+        else:
+            raise RuntimeError(f"Unknown class identifier {class_id}")
+
+    def forward(self, x):
+        if isinstance(x, list):
+            c = self.v_class.repeat(x[0].shape[0], 1)
+            class_vector = len(x) * [c]
+        else:
+            class_vector = self.v_class.repeat(x.shape[0], 1)
+        out = self.model.forward(x, class_vector, self.truncation)
+        return 0.5 * (out + 1)
+
+    def partial_forward(self, x, layer_name):
+        if layer_name in ["embeddings", "generator.gen_z"]:
+            n_layers = 0
+        elif "generator.layers" in layer_name:
+            layer_base = re.match(r"^generator\.layers\.[0-9]+", layer_name)[0]
+            n_layers = int(layer_base.split(".")[-1]) + 1
+        else:
+            n_layers = len(self.model.config.layers)
+        if not isinstance(x, list):
+            x = self.model.n_latents * [x]
+        class_label = self.v_class.repeat(x[0].shape[0], 1)
+        embed = len(x) * [self.model.embeddings(class_label)]
+        assert len(x) == self.model.n_latents, f"Expected {self.model.n_latents} latents, got {len(x)}"
+        cond_vectors = [torch.cat((z, e), dim=1) for (z, e) in zip(x, embed)]
+        z = self.model.generator.gen_z(cond_vectors[0])
+        z = z.view(-1, 4, 4, 16 * self.model.generator.config.channel_width)
+        z = z.permute(0, 3, 1, 2).contiguous()
+        cond_idx = 1
+        for layer in self.model.generator.layers[:n_layers]:
+            z = layer(z, cond_vectors[cond_idx], self.truncation)
+            cond_idx += 1
+        return None
+
+
+# =================================================================================================
+# factories (wrappers.py:651-735)
+# =================================================================================================
+
+@singledispatch
+def get_model(name, output_class, device, **kwargs):
+    inst = kwargs.get("inst", None)
+    model = kwargs.get("model", None)
+    if inst or model:
+        cached = model or inst.model
+        network_same = (cached.model_name == name)
+        outclass_same = (cached.outclass == output_class)
+        can_change_class = ("BigGAN" in name)
+        if network_same and (outclass_same or can_change_class):
+            cached.set_output_class(output_class)
+            return cached
+    if "BigGAN" in name:
+        assert "-" in name, "Please specify BigGAN resolution, e.g. BigGAN-512"
+        model = BigGAN(device, name.split("-")[-1], class_name=output_class)
+    elif name == "StyleGAN2":
+        model = StyleGAN2(device, class_name=output_class)
+    elif name in ("StyleGAN", "ProGAN", "DCGAN"):
+        raise RuntimeError(f"Model {name} is outside the MI355X hot-path scope (BASELINE configs use "
+                           "StyleGAN2 and BigGAN)")
+    else:
+        raise RuntimeError(f"Unknown model {name}")
+    return model
+
+
+@get_model.register(Config)
+def _(cfg, device, **kwargs):
+    kwargs["use_w"] = kwargs.get("use_w", cfg.use_w)
+    return get_model(cfg.model, cfg.output_class, device, **kwargs)
+
+
+def annotate_model_shapes(inst, latent_shape):
+    """Dry run with a zero latent: records input/feature/output shapes on the instrumented model
+    (netdissect/modelconfig.py:110-144)."""
+    device = next(inst.parameters()).device
+    with torch.no_grad():
+        output = inst(torch.zeros(latent_shape).to(device))
+    inst.input_shape = latent_shape
+    inst.feature_shape = {layer: feature.shape for layer, feature in inst.retained_features().items()}
+    inst.output_shape = output.shape
+    return inst
+
+
+@singledispatch
+def get_instrumented_model(name, output_class, layers, device, **kwargs):
+    model = get_model(name, output_class, device, **kwargs)
+    model.eval()
+    inst = kwargs.get("inst", None)
+    if inst:
+        inst.close()
+    if not isinstance(layers, list):
+        layers = [layers]
+    module_names = [n for (n, _) in model.named_modules()]
+    for layer_name in layers:
+        if layer_name not in module_names:
+            print(f"Layer '{layer_name}' not found in model!")
+            print("Available layers:", "\n".join(module_names))
+            raise RuntimeError(f"Unknown layer '{layer_name}''")
+    if hasattr(model, "use_z"):
+        model.use_z()       # shape annotation happens in Z mode (wrappers.py:713-715)
+    inst = InstrumentedModel(model)
+    inst.retain_layers(layers)
+    inst.eval()
+    if device.type == "cuda":
+        inst.cuda()
+    annotate_model_shapes(inst, model.get_latent_shape())
+    if kwargs.get("use_w", False):
+        model.use_w()
+    return inst
+
+
+@get_instrumented_model.register(Config)
+def _(cfg, device, **kwargs):
+    kwargs["use_w"] = kwargs.get("use_w", cfg.use_w)
+    return get_instrumented_model(cfg.model, cfg.output_class, cfg.layer, device, **kwargs)
