@@ -234,6 +234,8 @@ __global__ __launch_bounds__(kThreads, 2) void gram_partial_kernel(
 }
 
 // Fold the per-chunk float32 slabs into the float64 accumulators (upper 64x64 wave tiles).
+// One thread per output element (147 k threads at d = 512) so that the ~15 MB of slab reads are
+// spread over every CU with many independent loads in flight; lanes walk a tile row (coalesced).
 __global__ __launch_bounds__(256) void gram_fold_kernel(const float *__restrict__ P,
                                                         const float *__restrict__ CS,
                                                         double *__restrict__ G64,
@@ -241,34 +243,31 @@ __global__ __launch_bounds__(256) void gram_fold_kernel(const float *__restrict_
                                                         int T64, int ntiles, int accumulate) {
     const int bid = blockIdx.x;
     const int tid = threadIdx.x;
-    if (bid < ntiles * 4) {
+    if (bid < ntiles * 16) {
         int ti, tj;
-        decode_upper(bid >> 2, T64, ti, tj);
-        const int e = (bid & 3) * 1024 + tid * 4;
+        decode_upper(bid >> 4, T64, ti, tj);
+        const int e = (bid & 15) * 256 + tid;
         const int row = ti * kWaveTile + (e >> 6), col = tj * kWaveTile + (e & 63);
         const int64_t off = (int64_t)row * dp + col;
+        const int64_t stride = (int64_t)dp * dp;
         double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-        for (int c = 0; c < nchunks; ++c) {
-            const float4 v = *reinterpret_cast<const float4 *>(P + (int64_t)c * dp * dp + off);
-            s0 += v.x;
-            s1 += v.y;
-            s2 += v.z;
-            s3 += v.w;
+        int c = 0;
+        for (; c + 4 <= nchunks; c += 4) {
+            const float v0 = P[(c + 0) * stride + off], v1 = P[(c + 1) * stride + off];
+            const float v2 = P[(c + 2) * stride + off], v3 = P[(c + 3) * stride + off];
+            s0 += v0;
+            s1 += v1;
+            s2 += v2;
+            s3 += v3;
         }
-        double *g = G64 + off;
-        if (accumulate) {
-            g[0] += s0;
-            g[1] += s1;
-            g[2] += s2;
-            g[3] += s3;
-        } else {
-            g[0] = s0;
-            g[1] = s1;
-            g[2] = s2;
-            g[3] = s3;
-        }
+        for (; c < nchunks; ++c) s0 += P[c * stride + off];
+        const double s = (s0 + s1) + (s2 + s3);
+        if (accumulate)
+            G64[off] += s;
+        else
+            G64[off] = s;
     } else {
-        const int col = (bid - ntiles * 4) * 256 + tid;
+        const int col = (bid - ntiles * 16) * 256 + tid;
         if (col < dp) {
             double s = 0;
             for (int c = 0; c < nchunks; ++c) s += CS[(int64_t)c * dp + col];
@@ -310,13 +309,15 @@ static GramGeom gram_geometry(const GramWorkspace &ws, int64_t n) {
     const int dp = (int)ws.dp;
     g.T = dp / kMacroTile;
     g.nmt = g.T * (g.T + 1) / 2;
-    // target ~2 workgroups per CU; chunks are multiples of 8 (one group of chunks per XCD)
     static const int target_wgs = []() {
         const char *e = getenv("GS_GRAM_TARGET_WGS");
         const int v = e ? atoi(e) : 0;
-        return v > 0 ? v : 512;
+        return v > 0 ? v : 256;
     }();
-    g.want = (int)round_up(ceil_div(target_wgs, g.nmt), 8);
+    // one workgroup per CU (one wave per SIMD already saturates the f32 matrix pipe) keeps the
+    // float32 slab traffic at one 64 KiB tile per CU; chunks come in multiples of 8 (one group per XCD)
+    g.want = (target_wgs / g.nmt) / 8 * 8;
+    if (g.want < 8) g.want = 8;
     if (g.want > ws.max_chunks) g.want = ws.max_chunks;
     g.rows_per_launch = (int64_t)g.want * kMaxChunkRows;
     if (n > g.rows_per_launch) n = g.rows_per_launch;
@@ -352,7 +353,7 @@ int gram_update(const GramWorkspace &ws, const float *X, int64_t rows, int64_t l
         const GramGeom g = gram_geometry(ws, n);
         const int nchunks = g.nchunks;
         launch_partial(ws, g, X + base * ld, n, ld, d, shift, stream);
-        const int fold_grid = ntiles * 4 + (int)ceil_div(dp, 256);
+        const int fold_grid = ntiles * 16 + (int)ceil_div(dp, 256);
         hipLaunchKernelGGL(gram_fold_kernel, dim3(fold_grid), dim3(256), 0, stream, ws.partial,
                            ws.colsum_partial, G64, S1, dp, nchunks, T64, ntiles, acc ? 1 : 0);
         acc = true;

@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""Condense rocprofv3 outputs under <dir> into a markdown summary (kernel stats + per-launch PMC
+averages for our kernels).  FETCH_SIZE is doubled as MI355X_MICROARCH.md (HBM section) prescribes
+for wide coalesced streaming reads on gfx950 (the counter tallies 128-B requests as 64 B)."""
+import collections
+import csv
+import os
+import sys
+
+root = sys.argv[1]
+print(f"# rocprofv3 summary ({root})\n")
+ks = os.path.join(root, "bench_trace", "b_kernel_stats.csv")
+if os.path.exists(ks):
+    print("## kernel-trace --stats of `python bench.py --no-cpu-baseline`\n")
+    print("| kernel | calls | total us | avg us | % |\n|---|---|---|---|---|")
+    for r in list(csv.DictReader(open(ks)))[:12]:
+        name = r["Name"].split("(")[0].replace("void ", "")[-60:]
+        print(f"| `{name}` | {r['Calls']} | {int(r['TotalDurationNs'])/1e3:.1f} | {float(r['AverageNs'])/1e3:.2f} | {float(r['Percentage']):.2f} |")
+    print()
+print("## PMC passes on `tools/gram_probe.py` (10 000 x 512 float32 block), averages per launch\n")
+print("| kernel | counter | avg per launch | launches |\n|---|---|---|---|")
+for sub in ("pmc_FETCH_SIZE", "pmc_WRITE_SIZE", "pmc_sq", "pmc_lds"):
+    p = os.path.join(root, sub, "p_counter_collection.csv")
+    if not os.path.exists(p):
+        continue
+    d = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(p)):
+        k = r["Kernel_Name"]
+        if "gs::" not in k:
+            continue
+        short = k.split("(")[0].replace("void ", "")[-48:]
+        d[short][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        d[short]["duration_ns"].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    for k, v in d.items():
+        for c, x in v.items():
+            avg = sum(x) / len(x)
+            note = ""
+            if c == "FETCH_SIZE":
+                note = f" KiB -> x2 correction = {avg*2*1024/1e6:.2f} MB HBM read"
+            if c == "WRITE_SIZE":
+                note = f" KiB = {avg*1024/1e6:.2f} MB written"
+            print(f"| `{k}` | {c} | {avg:.1f}{note} | {len(x)} |")
