@@ -151,9 +151,20 @@ def main():
     bytes_ = rows_l * D * 4                # algorithmic: one read of the [rows, d] f32 block
     ach_tf = flops / (avg_ms.value * 1e-3) / 1e12
     ach_gbs = bytes_ / (avg_ms.value * 1e-3) / 1e9
+    # HBM traffic of that kernel from the committed rocprofv3 PMC passes (bench.py cannot run the
+    # profiler on itself): FETCH_SIZE, x2-corrected as MI355X_MICROARCH.md prescribes, per launch
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "gram_pmc_latest.json")) as f:
+            pmc = json.load(f)
+        if pmc.get("rows_per_launch") == rows_l:
+            traffic = pmc["hbm_read_bytes_per_launch_corrected_x2"]
+    except Exception:
+        pass
     roofline = {"bound": "mfma", "kernel": "gram_partial_kernel<true>", "achieved": round(ach_tf, 2),
                 "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach_tf / PEAK_F32_MFMA_TFLOPS, 4),
-                "traffic": None, "avg_launch_us": round(avg_ms.value * 1e3, 2), "rows_per_launch": rows_l,
+                "traffic": traffic, "traffic_source": "profiles/gram_pmc_latest.json (rocprofv3 --pmc FETCH_SIZE, x2)",
+                "avg_launch_us": round(avg_ms.value * 1e3, 2), "rows_per_launch": rows_l,
                 "algorithmic_flops_per_launch": flops, "algorithmic_bytes_per_launch": bytes_,
                 "hbm_achieved_GBs": round(ach_gbs, 1), "hbm_frac_of_8TBs": round(ach_gbs / PEAK_HBM_GBS, 4)}
 
@@ -169,7 +180,7 @@ def main():
         "roofline": roofline,
         "breakdown": {"update_loop_s": round(t_updates, 5), "finalize_eigensolve_s": round(t_final, 5),
                       "sampling_zgen_plus_mapping_s": round(t_sample, 4),
-                      "eigh_sweeps": int(getattr(est2.transformer, "_last_sweeps", 0) or 0)},
+                      "eigh_sweeps": int(lib.gs_ipca_last_sweeps(est2.transformer._h))},
     }
 
     # ---- CPU baseline + cos-sim on a bounded sample (rank 0, N=1 only) -----------------------------

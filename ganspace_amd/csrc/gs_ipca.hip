@@ -527,6 +527,8 @@ int gs_ipca_finalize(gs_ipca_t *h, float *components_host, double *singular_valu
     return GS_OK;
 }
 
+int gs_ipca_last_sweeps(const gs_ipca_t *h) { return h ? h->last_sweeps : GS_EINVAL; }
+
 int gs_ipca_components_device(gs_ipca_t *h, const float **components, const float **mean) {
     GS_REQUIRE(h != nullptr, GS_EINVAL, "gs_ipca_components_device: NULL handle");
     GS_REQUIRE(h->finalized, GS_ESTATE, "gs_ipca_components_device: call finalize first");

@@ -99,6 +99,9 @@ int gs_ipca_finalize(gs_ipca_t *h, float *components_host, double *singular_valu
                      double *mean_host, double *var_host, double *explained_variance_host,
                      double *explained_variance_ratio_host, int64_t *n_seen_host, void *stream);
 
+/* Jacobi sweeps used by the most recent eigensolve of this handle (diagnostic). */
+int gs_ipca_last_sweeps(const gs_ipca_t *h);
+
 /* Device-resident results of the last finalize/block close (float32 [k*d] components,
  * float32 [d] mean) for projection without a host round trip.                            */
 int gs_ipca_components_device(gs_ipca_t *h, const float **components, const float **mean);
