@@ -33,9 +33,10 @@ inline int64_t ceil_div(int64_t x, int64_t m) { return (x + m - 1) / m; }
 // ---- Gram (X^T X) accumulation: gs_gram.hip -------------------------------------------
 constexpr int kMacroTile = 128;   // output tile of one workgroup (2x2 waves of 64x64)
 constexpr int kWaveTile = 64;
+constexpr int kSubTile = 32;     // granularity of the valid (upper-triangle) region of slabs / G64
 
 struct GramWorkspace {
-    float *partial = nullptr;      // [chunks][dp][dp] f32 per-chunk partial Grams (upper wave tiles)
+    float *partial = nullptr;      // [chunks][dp][dp] f32 per-chunk partial Grams (upper 32x32 sub-tiles)
     float *colsum_partial = nullptr;  // [chunks][dp]
     int64_t dp = 0;                // d rounded up to kMacroTile
     int max_chunks = 0;
@@ -45,7 +46,7 @@ int gram_workspace_alloc(GramWorkspace &ws, int64_t d);
 void gram_workspace_free(GramWorkspace &ws);
 
 // Launch colsum+Gram partials for X[rows, ld] and fold them in float64 into
-// G64 (upper 64x64 wave tiles of a [dp][dp] row-major array) and S1[dp].
+// G64 (upper 32x32 sub-tiles of a [dp][dp] row-major array) and S1[dp].
 // accumulate=false overwrites G64/S1 instead of adding.
 int gram_update(const GramWorkspace &ws, const float *X, int64_t rows, int64_t ld, int64_t d,
                 const float *shift, double *G64, double *S1, bool accumulate, hipStream_t stream);

@@ -32,8 +32,9 @@ namespace gs {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
-constexpr int kKB = 32;        // rows per LDS stage
-constexpr int kThreads = 256;
+constexpr int kKB = 64;        // rows per LDS stage (2 x 2 x 64 x 128 f32 = 128 KiB of LDS per workgroup)
+constexpr int kLoadIters = kKB / 16;
+constexpr int kThreads = 512;   // 8 waves: two per SIMD
 constexpr int kMaxChunkRows = 512;
 
 __device__ __forceinline__ void decode_upper(int idx, int T, int &I, int &J) {
@@ -83,41 +84,83 @@ struct GramTileCtx {
     int d, dp, chunk, I, J;
     float *P, *CS;
     const float *shift;
+    int ablate;  // profiling only: 1 = no MFMA, 2 = no global loads after the first stage, 3 = no epilogue
 };
 
-// Main loop of one (macro tile, row chunk) workgroup.  DIAG is wave-uniform per workgroup and
-// is a template parameter so that the pipelined loop contains no control flow at all.
+// MFMA k-loop over `ksteps` row pairs of one LDS stage for a wave that owns the 64 x 32 strip
+// (sub-tiles a = 0, 1 stacked in M).  M0 / M1 say which of the two sub-tiles this wave computes
+// (diagonal macro tiles skip sub-tiles that lie strictly below the diagonal).
+template <bool M0, bool M1>
+__device__ __forceinline__ void mfma_stage(const float *__restrict__ A, const float *__restrict__ B,
+                                           int ksteps, f32x16 &acc0, f32x16 &acc1) {
+    if (ksteps == kKB / 2) {
+#pragma unroll
+        for (int k = 0; k < kKB; k += 2) {
+            const float b0 = B[k * kMacroTile];
+            if (M0) acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(A[k * kMacroTile], b0, acc0, 0, 0, 0);
+            if (M1) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(A[k * kMacroTile + 32], b0, acc1, 0, 0, 0);
+        }
+    } else {
+        // ragged last stage of a chunk: only the rows that exist (no MFMA time spent on zero padding)
+        for (int k = 0; k < 2 * ksteps; k += 2) {
+            const float b0 = B[k * kMacroTile];
+            if (M0) acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(A[k * kMacroTile], b0, acc0, 0, 0, 0);
+            if (M1) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(A[k * kMacroTile + 32], b0, acc1, 0, 0, 0);
+        }
+    }
+}
+
+// Main loop of one (macro tile, row chunk) workgroup: 8 waves = 2 per SIMD, so that one wave's
+// LDS waits / barrier arrivals are covered by its SIMD partner's MFMAs.  Wave (i, j) owns the
+// 64 x 32 strip at rows i*64, cols j*32 of the 128 x 128 macro tile.  DIAG is uniform per
+// workgroup and a template parameter so that the pipelined loop contains no control flow.
 template <bool VEC, bool DIAG>
 __device__ __forceinline__ void gram_tile(const GramTileCtx &c, float (*lds)[2][kKB][kMacroTile]) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wi = wave >> 1, wj = wave & 1;
-    const bool active = !(DIAG && wi == 1 && wj == 0);
-    const int c4 = tid & 31, rr = tid >> 5;
+    // strip assignment.  Off-diagonal tiles: wave w -> (w >> 2, w & 3), both sub-tiles.
+    // Diagonal tiles: only the 10 sub-tiles on/above the diagonal are computed, dealt to the waves
+    // so that the two waves sharing a SIMD (w and w + 4) issue 3,3,2,2 MFMAs per k-step.
+    int wi, wj;
+    bool m0, m1;
+    if (!DIAG) {
+        wi = wave >> 2;
+        wj = wave & 3;
+        m0 = m1 = true;
+    } else {
+        const int tab_i[8] = {0, 1, 0, 1, 0, 0, 0, 0};
+        const int tab_j[8] = {0, 2, 3, 3, 1, 2, 0, 0};
+        const int tab_m[8] = {1, 1, 3, 3, 3, 3, 0, 0};  // bit0: sub-tile a=0, bit1: a=1
+        wi = tab_i[wave];
+        wj = tab_j[wave];
+        m0 = tab_m[wave] & 1;
+        m1 = tab_m[wave] & 2;
+    }
+    const int c4 = tid & 31, rr = tid >> 5;  // 16 row groups x 32 float4 columns
     const int colA = c.I * kMacroTile + c4 * 4, colB = c.J * kMacroTile + c4 * 4;
     const float4 shA = *reinterpret_cast<const float4 *>(c.shift + colA);
     const float4 shB = *reinterpret_cast<const float4 *>(c.shift + colB);
     const int d = c.d;
     const int64_t r1 = c.r1, ld = c.ld;
 
-    float4 ra[4], rb[4];
+    float4 ra[kLoadIters], rb[kLoadIters];
     float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
 
     auto fetch = [&](int64_t rbase) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            ra[i] = load_raw<VEC>(c.X, rbase + rr + 8 * i, r1 - 1, ld, colA, d);
-            if (!DIAG) rb[i] = load_raw<VEC>(c.X, rbase + rr + 8 * i, r1 - 1, ld, colB, d);
+        for (int i = 0; i < kLoadIters; ++i) {
+            ra[i] = load_raw<VEC>(c.X, rbase + rr + 16 * i, r1 - 1, ld, colA, d);
+            if (!DIAG) rb[i] = load_raw<VEC>(c.X, rbase + rr + 16 * i, r1 - 1, ld, colB, d);
         }
     };
     auto stash = [&](int buf, int64_t rbase) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const bool ok = rbase + rr + 8 * i < r1;
+        for (int i = 0; i < kLoadIters; ++i) {
+            const bool ok = rbase + rr + 16 * i < r1;
             const float4 va = finish(ra[i], shA, ok, colA, d);
-            *reinterpret_cast<float4 *>(&lds[buf][0][rr + 8 * i][c4 * 4]) = va;
+            *reinterpret_cast<float4 *>(&lds[buf][0][rr + 16 * i][c4 * 4]) = va;
             if (!DIAG) {
                 const float4 vb = finish(rb[i], shB, ok, colB, d);
-                *reinterpret_cast<float4 *>(&lds[buf][1][rr + 8 * i][c4 * 4]) = vb;
+                *reinterpret_cast<float4 *>(&lds[buf][1][rr + 16 * i][c4 * 4]) = vb;
             } else {
                 cs.x += va.x;
                 cs.y += va.y;
@@ -127,11 +170,12 @@ __device__ __forceinline__ void gram_tile(const GramTileCtx &c, float (*lds)[2][
         }
     };
 
-    f32x16 acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};
-    const int nst = (int)((r1 - c.r0 + kKB - 1) / kKB);
+    f32x16 acc0 = {0}, acc1 = {0};
+    const int64_t nrows = r1 - c.r0;
+    const int nst = (int)((nrows + kKB - 1) / kKB);
     const int arow = lane >> 5;
-    const int acol = wi * kWaveTile + (lane & 31);
-    const int bcol = wj * kWaveTile + (lane & 31);
+    const int acol = wi * 64 + (lane & 31);
+    const int bcol = wj * 32 + (lane & 31);
 
     if (nst > 0) {
         fetch(c.r0);
@@ -141,54 +185,40 @@ __device__ __forceinline__ void gram_tile(const GramTileCtx &c, float (*lds)[2][
     for (int s = 0; s < nst; ++s) {
         const int buf = s & 1;
         const int64_t rnext = c.r0 + (int64_t)(s + 1) * kKB;
-        if (s + 1 < nst) fetch(rnext);
-        if (active) {
-            const float *A = &lds[buf][0][arow][acol];
-            const float *B = &lds[buf][DIAG ? 0 : 1][arow][bcol];
-            // fragments of k-step k+2 are read while the MFMAs of k-step k run
-            float a0 = A[0], a1 = A[32], b0 = B[0], b1 = B[32];
-#pragma unroll
-            for (int k = 0; k < kKB; k += 2) {
-                float na0 = 0.f, na1 = 0.f, nb0 = 0.f, nb1 = 0.f;
-                if (k + 2 < kKB) {
-                    na0 = A[(k + 2) * kMacroTile];
-                    na1 = A[(k + 2) * kMacroTile + 32];
-                    nb0 = B[(k + 2) * kMacroTile];
-                    nb1 = B[(k + 2) * kMacroTile + 32];
-                }
-                acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc00, 0, 0, 0);
-                acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc01, 0, 0, 0);
-                acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc10, 0, 0, 0);
-                acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc11, 0, 0, 0);
-                // pin the order: the two LDS reads of the NEXT k-step issue ahead of this step's MFMAs
-                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-                a0 = na0;
-                a1 = na1;
-                b0 = nb0;
-                b1 = nb1;
-            }
+        if (s + 1 < nst && c.ablate != 2) fetch(rnext);
+        int rows_here = (int)(nrows - (int64_t)s * kKB);
+        if (rows_here > kKB) rows_here = kKB;
+        const int ksteps = (rows_here + 1) / 2;
+        const float *A = &lds[buf][0][arow][acol];
+        const float *B = &lds[buf][DIAG ? 0 : 1][arow][bcol];
+        if (c.ablate != 1) {
+            if (m0 && m1)
+                mfma_stage<true, true>(A, B, ksteps, acc0, acc1);
+            else if (m0)
+                mfma_stage<true, false>(A, B, ksteps, acc0, acc1);
         }
         if (s + 1 < nst) stash(buf ^ 1, rnext);
         __syncthreads();
     }
 
-    // ---- epilogue: 64x64 wave tile -> this chunk's float32 slab --------------------------
-    if (active) {
+    // ---- epilogue: 32x32 sub-tiles -> this chunk's float32 slab --------------------------------
+    if (c.ablate != 3 || c.r0 < 0) {
         float *Pc = c.P + (int64_t)c.chunk * c.dp * c.dp;
-        const int row_base = c.I * kMacroTile + wi * kWaveTile + 4 * (lane >> 5);
-        const int col_base = c.J * kMacroTile + wj * kWaveTile + (lane & 31);
+        const int row_base = c.I * kMacroTile + wi * 64 + 4 * (lane >> 5);
+        const int col = c.J * kMacroTile + wj * 32 + (lane & 31);
         const int64_t dp = c.dp;
+        if (m0) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = row_base + (r & 3) + 8 * (r >> 2);
-            Pc[(int64_t)row * dp + col_base] = acc00[r];
-            Pc[(int64_t)row * dp + col_base + 32] = acc01[r];
-            Pc[(int64_t)(row + 32) * dp + col_base] = acc10[r];
-            Pc[(int64_t)(row + 32) * dp + col_base + 32] = acc11[r];
+            for (int r = 0; r < 16; ++r)
+                Pc[(int64_t)(row_base + (r & 3) + 8 * (r >> 2)) * dp + col] = acc0[r];
+        }
+        if (m1) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                Pc[(int64_t)(row_base + 32 + (r & 3) + 8 * (r >> 2)) * dp + col] = acc1[r];
         }
     }
-    // ---- column sums of panel I (diagonal macro tiles only; each panel is diagonal once) --
+    // ---- column sums of panel I (diagonal macro tiles only; each panel is diagonal once) --------
     if (DIAG) {
         float *scr = &lds[0][0][0][0];
         scr[rr * kMacroTile + c4 * 4 + 0] = cs.x;
@@ -199,18 +229,18 @@ __device__ __forceinline__ void gram_tile(const GramTileCtx &c, float (*lds)[2][
         if (tid < kMacroTile) {
             float t = 0.f;
 #pragma unroll
-            for (int g = 0; g < 8; ++g) t += scr[g * kMacroTile + tid];
+            for (int g = 0; g < 16; ++g) t += scr[g * kMacroTile + tid];
             c.CS[(int64_t)c.chunk * c.dp + c.I * kMacroTile + tid] = t;
         }
     }
 }
 
 template <bool VEC>
-__global__ __launch_bounds__(kThreads, 2) void gram_partial_kernel(
+__global__ __launch_bounds__(kThreads, 1) void gram_partial_kernel(
     const float *__restrict__ X, int64_t rows, int64_t ld, int d, const float *__restrict__ shift,
     float *__restrict__ P, float *__restrict__ CS, int dp, int nchunks, int64_t chunk_rows, int nmt,
-    int T) {
-    __shared__ __attribute__((aligned(16))) float lds[2][2][kKB][kMacroTile];  // 64 KiB
+    int T, int ablate) {
+    __shared__ __attribute__((aligned(16))) float lds[2][2][kKB][kMacroTile];  // 128 KiB
 
     const int b = blockIdx.x;
     const int xcd = b & 7, local = b >> 3;
@@ -225,6 +255,7 @@ __global__ __launch_bounds__(kThreads, 2) void gram_partial_kernel(
     c.P = P;
     c.CS = CS;
     c.shift = shift;
+    c.ablate = ablate;
     c.r0 = (int64_t)c.chunk * chunk_rows;
     c.r1 = (c.r0 + chunk_rows < rows) ? c.r0 + chunk_rows : rows;
     if (c.I == c.J)
@@ -233,7 +264,8 @@ __global__ __launch_bounds__(kThreads, 2) void gram_partial_kernel(
         gram_tile<VEC, false>(c, lds);
 }
 
-// Fold the per-chunk float32 slabs into the float64 accumulators (upper 64x64 wave tiles).
+// Fold the per-chunk float32 slabs into the float64 accumulators (upper 32x32 sub-tiles; T64 here
+// is the number of 32-wide sub-tiles per side).
 // One thread per output element (147 k threads at d = 512) so that the ~15 MB of slab reads are
 // spread over every CU with many independent loads in flight; lanes walk a tile row (coalesced).
 __global__ __launch_bounds__(256) void gram_fold_kernel(const float *__restrict__ P,
@@ -243,11 +275,11 @@ __global__ __launch_bounds__(256) void gram_fold_kernel(const float *__restrict_
                                                         int T64, int ntiles, int accumulate) {
     const int bid = blockIdx.x;
     const int tid = threadIdx.x;
-    if (bid < ntiles * 16) {
+    if (bid < ntiles * 4) {
         int ti, tj;
-        decode_upper(bid >> 4, T64, ti, tj);
-        const int e = (bid & 15) * 256 + tid;
-        const int row = ti * kWaveTile + (e >> 6), col = tj * kWaveTile + (e & 63);
+        decode_upper(bid >> 2, T64, ti, tj);
+        const int e = (bid & 3) * 256 + tid;
+        const int row = ti * kSubTile + (e >> 5), col = tj * kSubTile + (e & 31);
         const int64_t off = (int64_t)row * dp + col;
         const int64_t stride = (int64_t)dp * dp;
         double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
@@ -267,7 +299,7 @@ __global__ __launch_bounds__(256) void gram_fold_kernel(const float *__restrict_
         else
             G64[off] = s;
     } else {
-        const int col = (bid - ntiles * 16) * 256 + tid;
+        const int col = (bid - ntiles * 4) * 256 + tid;
         if (col < dp) {
             double s = 0;
             for (int c = 0; c < nchunks; ++c) s += CS[(int64_t)c * dp + col];
@@ -332,19 +364,23 @@ static void launch_partial(const GramWorkspace &ws, const GramGeom &g, const flo
                            int64_t d, const float *shift, hipStream_t stream) {
     const bool vec = (ld % 4 == 0) && (d % 4 == 0) && ((reinterpret_cast<uintptr_t>(Xb) & 15) == 0);
     const int dp = (int)ws.dp;
+    static const int ablate = []() {
+        const char *e = getenv("GS_GRAM_ABLATE");
+        return e ? atoi(e) : 0;
+    }();
     if (vec)
         hipLaunchKernelGGL(gram_partial_kernel<true>, dim3(g.grid), dim3(kThreads), 0, stream, Xb, n, ld, (int)d,
-                           shift, ws.partial, ws.colsum_partial, dp, g.nchunks, g.chunk_rows, g.nmt, g.T);
+                           shift, ws.partial, ws.colsum_partial, dp, g.nchunks, g.chunk_rows, g.nmt, g.T, ablate);
     else
         hipLaunchKernelGGL(gram_partial_kernel<false>, dim3(g.grid), dim3(kThreads), 0, stream, Xb, n, ld, (int)d,
-                           shift, ws.partial, ws.colsum_partial, dp, g.nchunks, g.chunk_rows, g.nmt, g.T);
+                           shift, ws.partial, ws.colsum_partial, dp, g.nchunks, g.chunk_rows, g.nmt, g.T, ablate);
 }
 
 int gram_update(const GramWorkspace &ws, const float *X, int64_t rows, int64_t ld, int64_t d,
                 const float *shift, double *G64, double *S1, bool accumulate, hipStream_t stream) {
     if (rows <= 0) return GS_OK;
     const int dp = (int)ws.dp;
-    const int T64 = dp / kWaveTile, ntiles = T64 * (T64 + 1) / 2;
+    const int T64 = dp / kSubTile, ntiles = T64 * (T64 + 1) / 2;
     const int64_t rows_per_launch = gram_geometry(ws, rows).rows_per_launch;
 
     bool acc = accumulate;
@@ -353,7 +389,7 @@ int gram_update(const GramWorkspace &ws, const float *X, int64_t rows, int64_t l
         const GramGeom g = gram_geometry(ws, n);
         const int nchunks = g.nchunks;
         launch_partial(ws, g, X + base * ld, n, ld, d, shift, stream);
-        const int fold_grid = ntiles * 16 + (int)ceil_div(dp, 256);
+        const int fold_grid = ntiles * 4 + (int)ceil_div(dp, 256);
         hipLaunchKernelGGL(gram_fold_kernel, dim3(fold_grid), dim3(256), 0, stream, ws.partial,
                            ws.colsum_partial, G64, S1, dp, nchunks, T64, ntiles, acc ? 1 : 0);
         acc = true;

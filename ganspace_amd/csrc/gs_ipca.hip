@@ -37,7 +37,7 @@ struct gs_ipca {
     EighWorkspace ews;
     float *shift = nullptr;      // [dp]
     double *S1 = nullptr;        // [dp]    sum (x - shift)
-    double *G64 = nullptr;       // [dp*dp] upper 64x64 tiles: sum (x-shift)(x-shift)^T
+    double *G64 = nullptr;       // [dp*dp] upper 32x32 tiles: sum (x-shift)(x-shift)^T
     double *W = nullptr;         // [dp*dp] eigensolver workspace, leading dim dp
     double *mean = nullptr;      // [dp]
     double *m2 = nullptr;        // [dp]    per-feature sum of squared deviations
@@ -53,8 +53,8 @@ struct gs_ipca {
 namespace {
 
 __device__ __forceinline__ double upper_get(const double *G, int dp, int i, int j) {
-    // G holds the upper 64x64 wave tiles (tile(i) <= tile(j)); inside a tile everything is valid
-    return ((i >> 6) <= (j >> 6)) ? G[(int64_t)i * dp + j] : G[(int64_t)j * dp + i];
+    // G holds the upper 32x32 sub-tiles (tile(i) <= tile(j)); inside a tile everything is valid
+    return ((i >> 5) <= (j >> 5)) ? G[(int64_t)i * dp + j] : G[(int64_t)j * dp + i];
 }
 
 // ---- EXACT: C = S2 - S1 S1^T / n  (full symmetric), mean, var, trace -------------------
@@ -263,7 +263,7 @@ __global__ void state_setmean_kernel(double *__restrict__ state, const double *_
     if (j < d) state[1 + j] = new_mean[j];
 }
 
-// expand the upper 64x64 wave tiles to a full symmetric row-major [d*d] matrix
+// expand the upper 32x32 sub-tiles to a full symmetric row-major [d*d] matrix
 __global__ void symmetrize_out_kernel(const double *__restrict__ G, double *__restrict__ out, int d, int dp,
                                       int accumulate) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
