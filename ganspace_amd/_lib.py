@@ -12,7 +12,7 @@ import os
 from . import _build
 
 GS_OK, GS_EINVAL, GS_EHIP, GS_ENOMEM, GS_ESTATE, GS_ENOTIMPL = 0, -1, -2, -3, -4, -5
-GS_MODE_EXACT, GS_MODE_FAITHFUL = 0, 1
+GS_MODE_EXACT, GS_MODE_FAITHFUL, GS_MODE_SMALLSIDE = 0, 1, 2
 GS_PREC_F32 = 0
 
 _vp, _i64, _int, _f32 = C.c_void_p, C.c_int64, C.c_int, C.c_float

@@ -72,4 +72,27 @@ void eigh_workspace_free(EighWorkspace &ws);
 // holds lambda_j * v_j (unsorted).  norms[j] = lambda_j^2.
 int eigh_jacobi(const EighWorkspace &ws, double *W, int n, int64_t ldw, int *sweeps_out, hipStream_t stream);
 
+// rank[j] = position of column j when sorted by decreasing squared norm (ews.norms)
+int rank_columns(const EighWorkspace &ws, int n, hipStream_t stream);
+
+// column sums of X[rows, ld] accumulated (atomically) into out[d] (float64, caller zeroes it)
+int column_sums_f64(const float *X, int64_t rows, int64_t ld, int64_t d, double *out, hipStream_t stream);
+
+// ---- small-side recurrence for d >> m: gs_smallside.hip -------------------------------------------
+struct SmallSide {
+    int64_t d = 0;
+    int k = 0, m_cap = 0, r_cap = 0, rp = 0, kp = 0, nsplit = 0;
+    float *M = nullptr;      // [rp][d]  stacked matrix
+    double *T = nullptr;     // [rp][rp] M M^T, then its Jacobi-rotated columns
+    double *slab = nullptr;  // [nsplit][rp][rp]
+    float *Ct = nullptr;     // [rp][kp] coefficients (t-major)
+    float *Vtmp = nullptr;   // [kp][d]
+    double *colsq = nullptr; // [d]
+    EighWorkspace ews;
+};
+int smallside_alloc(SmallSide &ss, int64_t d, int k, int m);
+void smallside_free(SmallSide &ss);
+int smallside_update(SmallSide &ss, const float *X, int64_t rows, int64_t ldx, double n0, float *V, double *lam,
+                     double *mean, double *m2, double *vec, double *bs, int *sweeps_out, hipStream_t stream);
+
 }  // namespace gs

@@ -151,15 +151,21 @@ __global__ __launch_bounds__(256) void jacobi_round_kernel(double *__restrict__ 
 template <int NPL>
 __device__ __forceinline__ void rotate_pair_lds(double *__restrict__ ca, double *__restrict__ cb, int lane,
                                                 double floor2, int &rotated) {
-    double x[NPL], y[NPL];
+    // long columns (NPL > 16) are streamed twice from LDS instead of being held in registers
+    constexpr bool kInRegs = (NPL <= 16);
+    constexpr int NR = kInRegs ? NPL : 1;
+    double x[NR], y[NR];
     double alpha = 0, beta = 0, gamma = 0;
-#pragma unroll
+#pragma unroll 8
     for (int t = 0; t < NPL; ++t) {
-        x[t] = ca[t * 64 + lane];
-        y[t] = cb[t * 64 + lane];
-        alpha += x[t] * x[t];
-        beta += y[t] * y[t];
-        gamma += x[t] * y[t];
+        const double xv = ca[t * 64 + lane], yv = cb[t * 64 + lane];
+        if (kInRegs) {
+            x[t % NR] = xv;
+            y[t % NR] = yv;
+        }
+        alpha += xv * xv;
+        beta += yv * yv;
+        gamma += xv * yv;
     }
     alpha = wave_sum_fast(alpha);
     beta = wave_sum_fast(beta);
@@ -177,10 +183,12 @@ __device__ __forceinline__ void rotate_pair_lds(double *__restrict__ ca, double 
     const double c = c2 * ic;
     double s = 0.5 * fabs(b) * ir * ic;
     s = ((a < 0.0) != (b < 0.0)) ? -s : s;
-#pragma unroll
+#pragma unroll 8
     for (int u = 0; u < NPL; ++u) {
-        ca[u * 64 + lane] = c * x[u] - s * y[u];
-        cb[u * 64 + lane] = s * x[u] + c * y[u];
+        const double xv = kInRegs ? x[u % NR] : ca[u * 64 + lane];
+        const double yv = kInRegs ? y[u % NR] : cb[u * 64 + lane];
+        ca[u * 64 + lane] = c * xv - s * yv;
+        cb[u * 64 + lane] = s * xv + c * yv;
     }
 }
 
@@ -294,6 +302,25 @@ static int launch_block_sweeps(const EighWorkspace &ws, double *W, int n, int64_
     return GS_OK;
 }
 
+// rank of every column by decreasing squared norm (ties: lower index first)
+__global__ void rank_kernel(const double *__restrict__ norms, int *__restrict__ rank, int n) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const double v = norms[j];
+    int r = 0;
+    for (int i = 0; i < n; ++i) {
+        const double u = norms[i];
+        r += (u > v) || (u == v && i < j);
+    }
+    rank[j] = r;
+}
+
+int rank_columns(const EighWorkspace &ws, int n, hipStream_t stream) {
+    hipLaunchKernelGGL(rank_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, stream, ws.norms, ws.rank, n);
+    GS_HIP_CHECK(hipGetLastError());
+    return GS_OK;
+}
+
 int eigh_workspace_alloc(EighWorkspace &ws, int n) {
     GS_HIP_CHECK(hipMalloc(&ws.norms, sizeof(double) * (n + 8)));
     GS_HIP_CHECK(hipMalloc(&ws.rank, sizeof(int) * (n + 8)));
@@ -324,7 +351,7 @@ int eigh_jacobi(const EighWorkspace &ws, double *W, int n, int64_t ldw, int *swe
 
     int sweeps = 0;
     static const bool force_flat = getenv("GS_EIGH_FLAT") != nullptr;
-    if (n > 1 && n <= 2048 && !force_flat) {
+    if (n > 1 && n <= 4096 && !force_flat) {
         // LDS-resident block Jacobi: NPL = ceil(n / 64) rounded to a power of two, BS sized so that
         // the 2*BS-column panel fits the 160 KiB LDS
         int rc;
@@ -348,8 +375,10 @@ int eigh_jacobi(const EighWorkspace &ws, double *W, int n, int64_t ldw, int *swe
         }
         else if (n <= 1024)
             rc = launch_block_sweeps<16, 8>(ws, W, n, ldw, &sweeps, stream);
-        else
+        else if (n <= 2048)
             rc = launch_block_sweeps<32, 4>(ws, W, n, ldw, &sweeps, stream);
+        else
+            rc = launch_block_sweeps<64, 2>(ws, W, n, ldw, &sweeps, stream);
         if (rc != GS_OK) return rc;
     } else if (n > 1) {
         for (; sweeps < kMaxSweeps;) {

@@ -440,6 +440,14 @@ __global__ __launch_bounds__(256) void colsum_f64_kernel(const float *__restrict
     }
 }
 
+int column_sums_f64(const float *X, int64_t rows, int64_t ld, int64_t d, double *out, hipStream_t stream) {
+    const int64_t rpb = 256;
+    dim3 grid((unsigned)ceil_div(d, 32), (unsigned)ceil_div(rows, rpb));
+    hipLaunchKernelGGL(colsum_f64_kernel, grid, dim3(256), 0, stream, X, rows, ld, (int)d, out, rpb);
+    GS_HIP_CHECK(hipGetLastError());
+    return GS_OK;
+}
+
 __global__ void mean_from_sum_kernel(const double *__restrict__ sum, float *__restrict__ out, int d,
                                      int dp, double inv_n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -48,6 +48,9 @@ struct gs_ipca {
     double *outs = nullptr;      // [3*k]   sv, ev, evr
     float *comp32 = nullptr;     // [k*d]
     float *mean32 = nullptr;     // [d]
+    // GS_MODE_SMALLSIDE only (d >> block rows): comp32 doubles as the float32 state V
+    SmallSide ss;
+    double *bs = nullptr;        // [d] column sums scratch
 };
 
 namespace {
@@ -123,19 +126,6 @@ __global__ void faithful_assemble_kernel(const double *__restrict__ G, const dou
     }
 }
 
-// rank of every column by decreasing squared norm (ties: lower index first)
-__global__ void rank_kernel(const double *__restrict__ norms, int *__restrict__ rank, int n) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n) return;
-    const double v = norms[j];
-    int r = 0;
-    for (int i = 0; i < n; ++i) {
-        const double u = norms[i];
-        r += (u > v) || (u == v && i < j);
-    }
-    rank[j] = r;
-}
-
 // Column j of W (= lambda_j v_j) with rank r < k  ->  row r of Vk, unit norm, sign fixed so the
 // entry of largest magnitude is positive (sklearn svd_flip(u_based_decision=False),
 // extmath.py:943-951; first index wins ties like np.argmax).
@@ -181,10 +171,15 @@ __global__ __launch_bounds__(256) void select_topk_kernel(const double *__restri
 // sv = sqrt(lambda), ev = lambda/(n-1), evr = lambda/total
 __global__ void derive_outputs_kernel(const double *__restrict__ lam, const double *__restrict__ total_src,
                                       int total_len, double *__restrict__ outs, int k, double n) {
+    __shared__ double part[256];
     __shared__ double tot;
+    double acc = 0;
+    for (int i = threadIdx.x; i < total_len; i += blockDim.x) acc += total_src[i];
+    part[threadIdx.x] = acc;
+    __syncthreads();
     if (threadIdx.x == 0) {
         double t = 0;
-        for (int i = 0; i < total_len; ++i) t += total_src[i];
+        for (int i = 0; i < (int)blockDim.x; ++i) t += part[i];
         tot = t;
     }
     __syncthreads();
@@ -283,8 +278,8 @@ __global__ void add_vec_kernel(const double *__restrict__ src, double *__restric
 
 int select_and_derive(gs_ipca *h, const double *total_src, int total_len, hipStream_t stream) {
     const int n = h->n2, dp = (int)h->dp, k = h->k;
-    hipLaunchKernelGGL(rank_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, stream, h->ews.norms,
-                       h->ews.rank, n);
+    int rc0 = rank_columns(h->ews, n, stream);
+    if (rc0 != GS_OK) return rc0;
     hipLaunchKernelGGL(select_topk_kernel, dim3((unsigned)ceil_div(n, 4)), dim3(256), 0, stream, h->W,
                        h->ews.norms, h->ews.rank, h->Vk, h->lam, n, (int64_t)dp, dp, k);
     hipLaunchKernelGGL(derive_outputs_kernel, dim3(1), dim3(256), 0, stream, h->lam, total_src, total_len,
@@ -324,12 +319,19 @@ int gs_device_count(void) {
 int gs_ipca_create(int64_t d, int k, int mode, int precision, int device, gs_ipca_t **out) {
     GS_REQUIRE(out != nullptr, GS_EINVAL, "gs_ipca_create: out is NULL");
     *out = nullptr;
-    GS_REQUIRE(d >= 1 && d <= 8192, d > 8192 ? GS_ENOTIMPL : GS_EINVAL,
-               "gs_ipca_create: feature dim must be in [1, 8192] for the Gram-side solver");
+    GS_REQUIRE(mode == GS_MODE_EXACT || mode == GS_MODE_FAITHFUL || mode == GS_MODE_SMALLSIDE, GS_EINVAL,
+               "gs_ipca_create: bad mode");
+    GS_REQUIRE(precision == GS_PREC_F32, GS_ENOTIMPL, "gs_ipca_create: only GS_PREC_F32 is implemented");
+    if (mode == GS_MODE_SMALLSIDE) {
+        GS_REQUIRE(d >= 4 && d <= ((int64_t)1 << 21), GS_EINVAL, "gs_ipca_create: feature dim out of range");
+        GS_REQUIRE(d % 4 == 0, GS_ENOTIMPL, "gs_ipca_create: small-side mode needs feat_dim % 4 == 0");
+    } else {
+        GS_REQUIRE(d >= 1 && d <= 8192, d > 8192 ? GS_ENOTIMPL : GS_EINVAL,
+                   "gs_ipca_create: feature dim must be in [1, 8192] for the Gram-side solver "
+                   "(use GS_MODE_SMALLSIDE beyond)");
+    }
     // sklearn: n_components must be <= n_features (_incremental_pca.py:300-305)
     GS_REQUIRE(k >= 1 && k <= d, GS_EINVAL, "gs_ipca_create: n_components invalid for n_features");
-    GS_REQUIRE(mode == GS_MODE_EXACT || mode == GS_MODE_FAITHFUL, GS_EINVAL, "gs_ipca_create: bad mode");
-    GS_REQUIRE(precision == GS_PREC_F32, GS_ENOTIMPL, "gs_ipca_create: only GS_PREC_F32 is implemented");
     GS_HIP_CHECK(hipSetDevice(device));
     gs_ipca *h = new (std::nothrow) gs_ipca();
     GS_REQUIRE(h != nullptr, GS_ENOMEM, "gs_ipca_create: out of host memory");
@@ -339,10 +341,7 @@ int gs_ipca_create(int64_t d, int k, int mode, int precision, int device, gs_ipc
     h->prec = precision;
     h->device = device;
     h->n2 = (int)d;
-    int rc = gram_workspace_alloc(h->gws, d);
-    if (rc == GS_OK) rc = eigh_workspace_alloc(h->ews, (int)d + 2);
-    h->dp = h->gws.dp;
-    const int64_t dp = h->dp;
+    int rc = GS_OK;
     auto alloc = [&](void **p, size_t bytes) {
         if (rc != GS_OK) return;
         if (hipMalloc(p, bytes) != hipSuccess) {
@@ -352,6 +351,28 @@ int gs_ipca_create(int64_t d, int k, int mode, int precision, int device, gs_ipc
             rc = GS_EHIP;
         }
     };
+    if (mode == GS_MODE_SMALLSIDE) {
+        // state: V = comp32 (k x d f32), lam, mean, m2; per-block scratch is sized at the first update
+        h->dp = d;
+        alloc((void **)&h->mean, sizeof(double) * d);
+        alloc((void **)&h->m2, sizeof(double) * d);
+        alloc((void **)&h->vec, sizeof(double) * d * 3);
+        alloc((void **)&h->bs, sizeof(double) * d);
+        alloc((void **)&h->lam, sizeof(double) * k);
+        alloc((void **)&h->outs, sizeof(double) * 3 * k);
+        alloc((void **)&h->comp32, sizeof(float) * k * d);
+        alloc((void **)&h->mean32, sizeof(float) * d);
+        if (rc != GS_OK) {
+            gs_ipca_destroy(h);
+            return rc;
+        }
+        *out = h;
+        return GS_OK;
+    }
+    rc = gram_workspace_alloc(h->gws, d);
+    if (rc == GS_OK) rc = eigh_workspace_alloc(h->ews, (int)d + 2);
+    h->dp = h->gws.dp;
+    const int64_t dp = h->dp;
     alloc((void **)&h->shift, sizeof(float) * dp);
     alloc((void **)&h->S1, sizeof(double) * dp);
     alloc((void **)&h->G64, sizeof(double) * dp * dp);
@@ -378,7 +399,8 @@ int gs_ipca_destroy(gs_ipca_t *h) {
     (void)hipSetDevice(h->device);
     gram_workspace_free(h->gws);
     eigh_workspace_free(h->ews);
-    void *ptrs[] = {h->shift, h->S1, h->G64, h->W,   h->mean,   h->m2,    h->vec,
+    smallside_free(h->ss);
+    void *ptrs[] = {h->shift, h->S1, h->G64, h->W,   h->mean,   h->m2,    h->vec, h->bs,
                     h->Vk,    h->lam, h->scal, h->outs, h->comp32, h->mean32};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -404,6 +426,29 @@ int gs_ipca_update(gs_ipca_t *h, const float *X, int64_t rows, int64_t ld, void 
         GS_REQUIRE(h->k <= rows, GS_EINVAL,
                    "n_components must be less or equal to the batch number of samples for the first "
                    "partial_fit call");
+    }
+    if (h->mode == GS_MODE_SMALLSIDE) {
+        GS_REQUIRE(h->k + rows + 1 <= 4096, GS_ENOTIMPL,
+                   "small-side mode supports n_components + rows + 1 <= 4096 per block");
+        if (h->ss.M == nullptr || rows > h->ss.m_cap) {
+            GS_HIP_CHECK(hipStreamSynchronize(stream));
+            int rc = smallside_alloc(h->ss, h->d, h->k, (int)rows);
+            if (rc != GS_OK) return rc;
+        }
+        int rc = smallside_update(h->ss, X, rows, ld, (double)h->n_seen, h->comp32, h->lam, h->mean, h->m2, h->vec,
+                                  h->bs, &h->last_sweeps, stream);
+        if (rc != GS_OK) return rc;
+        h->n_seen += rows;
+        h->blocks += 1;
+        hipLaunchKernelGGL(derive_outputs_kernel, dim3(1), dim3(256), 0, stream, h->lam, h->m2, (int)h->d, h->outs,
+                           h->k, (double)h->n_seen);
+        hipLaunchKernelGGL(to_f32_kernel, dim3((unsigned)ceil_div(h->d, 256), 1), dim3(256), 0, stream,
+                           (const double *)nullptr, h->mean, (float *)nullptr, h->mean32, d, d, 0);
+        GS_HIP_CHECK(hipGetLastError());
+        h->finalized = true;
+        return GS_OK;
+    }
+    if (h->n_seen == 0) {
         int rc = column_means_f32(X, rows, ld, d, dp, h->shift, h->vec, stream);
         if (rc != GS_OK) return rc;
     }
@@ -603,8 +648,7 @@ int gs_eigh_sym(double *A, double *w, int n, int *sweeps_out_host, void *stream_
     }
     rc = eigh_jacobi(ws, A, n, n, sweeps_out_host, stream);
     if (rc == GS_OK) {
-        hipLaunchKernelGGL(rank_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, stream, ws.norms, ws.rank,
-                           n);
+        rc = rank_columns(ws, n, stream);
         hipLaunchKernelGGL(select_topk_kernel, dim3((unsigned)ceil_div(n, 4)), dim3(256), 0, stream, A, ws.norms,
                            ws.rank, tmp, lam, n, (int64_t)n, n, n);
         (void)hipMemcpyAsync(A, tmp, sizeof(double) * (size_t)n * n, hipMemcpyDeviceToDevice, stream);

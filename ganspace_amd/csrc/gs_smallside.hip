@@ -1,0 +1,448 @@
+// Small-side incremental PCA for feat_dim d >> block rows m (gfx950).
+//
+// Same recurrence as IncrementalPCA.partial_fit (sklearn/decomposition/_incremental_pca.py:335-378,
+// reached through reference estimators.py:68-76), for the BASELINE configs whose activation is
+// far wider than a block is tall (BigGAN generator.gen_z d = 32 768, StyleGAN2 conv features
+// d = 131 072, NB = 2 000): the d x d Gram is 4-64 GiB there and its eigensolve hopeless, so
+// the stacked matrix  M = [ diag(S) V ; X - bm ; mc ]  (r = k + m + 1 rows) is
+// handled from its SMALL side:
+//
+//     T = M M^T            (r x r, f32 MFMA over d with float64 carry every 1024 columns)
+//     T = U diag(w) U^T    (block one-sided Jacobi, gs_eigh.hip)
+//     V' = diag(w^-1/2) U_k^T M      (k x d, f32 MFMA over r)
+//     S' = sqrt(w_k),  rows sign-fixed (svd_flip, extmath.py:943-951)
+//
+// M is materialised once per block in HBM (1.09 GB at r = 2081, d = 131 072: 288 GB of HBM make
+// that the simple choice) and streamed: once for T (row panels re-read through L2/MALL), once
+// for V'.
+#include "gs_common.h"
+
+namespace gs {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+constexpr int kRT = 128;  // output tile
+constexpr int kRK = 32;   // K step (columns of M)
+constexpr int kRP = kRT + 1;
+constexpr int kFlushStages = 32;  // float64 carry every 32 * 32 = 1024 columns
+
+__device__ __forceinline__ void decode_upper2(int idx, int T, int &I, int &J) {
+    int i = 0, len = T;
+    while (idx >= len) {
+        idx -= len;
+        ++i;
+        --len;
+    }
+    I = i;
+    J = i + idx;
+}
+
+// ---- T partials: slab[s][rp][rp] (float64, upper macro tiles) = M[:, Ks] M[:, Ks]^T ----------------
+__global__ __launch_bounds__(256, 1) void rowgram_kernel(const float *__restrict__ M, int64_t d, int64_t ldm,
+                                                         double *__restrict__ slab, int rp, int nmt, int T,
+                                                         int64_t kchunk) {
+    __shared__ float lds[2][2][kRK][kRP];
+    const int split = blockIdx.x / nmt;
+    int I, J;
+    decode_upper2(blockIdx.x % nmt, T, I, J);
+    const bool diag = (I == J);
+    const int64_t k_begin = (int64_t)split * kchunk;
+    const int64_t k_end = (k_begin + kchunk < d) ? k_begin + kchunk : d;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wi = wave >> 1, wj = wave & 1;
+    const int k4 = tid & 7, r8 = tid >> 3;
+    const float *Ma = M + (int64_t)I * kRT * ldm;
+    const float *Mb = M + (int64_t)J * kRT * ldm;
+
+    float4 ra[4], rb[4];
+    auto fetch = [&](int64_t k0) {
+        const int64_t kk = k0 + k4 * 4;
+        const bool ok = kk < k_end;  // d % 4 == 0 is required by the caller
+        const int64_t kc = ok ? kk : k_begin;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            ra[i] = *reinterpret_cast<const float4 *>(Ma + (int64_t)(r8 + 32 * i) * ldm + kc);
+            if (!diag) rb[i] = *reinterpret_cast<const float4 *>(Mb + (int64_t)(r8 + 32 * i) * ldm + kc);
+            if (!ok) {
+                ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                rb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+    };
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = r8 + 32 * i;
+            lds[buf][0][k4 * 4 + 0][r] = ra[i].x;
+            lds[buf][0][k4 * 4 + 1][r] = ra[i].y;
+            lds[buf][0][k4 * 4 + 2][r] = ra[i].z;
+            lds[buf][0][k4 * 4 + 3][r] = ra[i].w;
+            if (!diag) {
+                lds[buf][1][k4 * 4 + 0][r] = rb[i].x;
+                lds[buf][1][k4 * 4 + 1][r] = rb[i].y;
+                lds[buf][1][k4 * 4 + 2][r] = rb[i].z;
+                lds[buf][1][k4 * 4 + 3][r] = rb[i].w;
+            }
+        }
+    };
+
+    f32x16 acc[4] = {{0}, {0}, {0}, {0}};
+    double acc64[4][16];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc64[a][r] = 0.0;
+
+    const int nst = (int)((k_end - k_begin + kRK - 1) / kRK);
+    const int arow = lane >> 5;
+    const int acol = wi * 64 + (lane & 31), bcol = wj * 64 + (lane & 31);
+    if (nst > 0) {
+        fetch(k_begin);
+        stash(0);
+    }
+    __syncthreads();
+    for (int s = 0; s < nst; ++s) {
+        const int buf = s & 1;
+        if (s + 1 < nst) fetch(k_begin + (int64_t)(s + 1) * kRK);
+        const float *A = &lds[buf][0][arow][acol];
+        const float *B = &lds[buf][diag ? 0 : 1][arow][bcol];
+#pragma unroll
+        for (int k = 0; k < kRK; k += 2) {
+            const float a0 = A[k * kRP], a1 = A[k * kRP + 32];
+            const float b0 = B[k * kRP], b1 = B[k * kRP + 32];
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[1], 0, 0, 0);
+            acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[2], 0, 0, 0);
+            acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[3], 0, 0, 0);
+        }
+        if ((s + 1) % kFlushStages == 0 || s + 1 == nst) {
+            // float64 carry: bounds every float32 fma chain to 1024 products
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    acc64[a][r] += (double)acc[a][r];
+                    acc[a][r] = 0.f;
+                }
+            }
+        }
+        if (s + 1 < nst) stash(buf ^ 1);
+        __syncthreads();
+    }
+    double *out = slab + (int64_t)split * rp * rp;
+    const int row_base = I * kRT + wi * 64 + 4 * (lane >> 5);
+    const int col_base = J * kRT + wj * 64 + (lane & 31);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = row_base + (r & 3) + 8 * (r >> 2);
+        out[(int64_t)row * rp + col_base] = acc64[0][r];
+        out[(int64_t)row * rp + col_base + 32] = acc64[1][r];
+        out[(int64_t)(row + 32) * rp + col_base] = acc64[2][r];
+        out[(int64_t)(row + 32) * rp + col_base + 32] = acc64[3][r];
+    }
+}
+
+// T (full symmetric, leading dim rp) = sum over splits of the upper macro tiles
+__global__ void rowgram_fold_kernel(const double *__restrict__ slab, double *__restrict__ Tm, int rp,
+                                    int nsplit) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = blockIdx.y;
+    if (j >= rp) return;
+    if ((i / kRT) > (j / kRT)) return;  // lower macro tiles are filled by mirroring
+    double s = 0.0;
+    for (int c = 0; c < nsplit; ++c) s += slab[(int64_t)c * rp * rp + (int64_t)i * rp + j];
+    Tm[(int64_t)i * rp + j] = s;
+    if ((i / kRT) < (j / kRT)) Tm[(int64_t)j * rp + i] = s;
+}
+
+// ---- out[kp x d] = Ct^T M   (Ct: [rp x kp] t-major coefficients, M: [rp x d]) -----------------------
+// Same operand pattern as the Gram kernel: contraction over ROWS of two row-major matrices, so both
+// MFMA operands are "row t, 32 consecutive columns" (coalesced reads, conflict-free ds_read_b32).
+__global__ __launch_bounds__(256, 2) void tn_gemm_kernel(const float *__restrict__ Ct, int kp,
+                                                         const float *__restrict__ M, int64_t d, int64_t ldm,
+                                                         int r, float *__restrict__ out, int64_t ldo) {
+    __shared__ __attribute__((aligned(16))) float lds[2][2][32][kRT];
+    const int64_t ntn = (d + kRT - 1) / kRT;
+    const int ti = (int)(blockIdx.x / ntn);
+    const int64_t tj = blockIdx.x % ntn;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wi = wave >> 1, wj = wave & 1;
+    const int c4 = tid & 31, rr = tid >> 5;
+    const int colA = ti * kRT + c4 * 4;
+    const int64_t colB = tj * kRT + c4 * 4;
+    const bool okB = colB < d;
+
+    float4 ra[4], rb[4];
+    auto fetch = [&](int t0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int t = t0 + rr + 8 * i;
+            const int tc = t < r ? t : r - 1;
+            ra[i] = *reinterpret_cast<const float4 *>(Ct + (int64_t)tc * kp + colA);
+            rb[i] = *reinterpret_cast<const float4 *>(M + (int64_t)tc * ldm + (okB ? colB : 0));
+            if (t >= r) {
+                ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                rb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+    };
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<float4 *>(&lds[buf][0][rr + 8 * i][c4 * 4]) = ra[i];
+            *reinterpret_cast<float4 *>(&lds[buf][1][rr + 8 * i][c4 * 4]) = rb[i];
+        }
+    };
+    f32x16 acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};
+    const int nst = (r + 31) / 32;
+    const int arow = lane >> 5;
+    const int acol = wi * 64 + (lane & 31), bcol = wj * 64 + (lane & 31);
+    fetch(0);
+    stash(0);
+    __syncthreads();
+    for (int s = 0; s < nst; ++s) {
+        const int buf = s & 1;
+        if (s + 1 < nst) fetch((s + 1) * 32);
+        const float *A = &lds[buf][0][arow][acol];
+        const float *B = &lds[buf][1][arow][bcol];
+#pragma unroll
+        for (int k = 0; k < 32; k += 2) {
+            const float a0 = A[k * kRT], a1 = A[k * kRT + 32];
+            const float b0 = B[k * kRT], b1 = B[k * kRT + 32];
+            acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc00, 0, 0, 0);
+            acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc01, 0, 0, 0);
+            acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc10, 0, 0, 0);
+            acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc11, 0, 0, 0);
+        }
+        if (s + 1 < nst) stash(buf ^ 1);
+        __syncthreads();
+    }
+    const int row_base = ti * kRT + wi * 64 + 4 * (lane >> 5);
+    const int64_t col0 = tj * kRT + wj * 64 + (lane & 31), col1 = col0 + 32;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int row = row_base + (q & 3) + 8 * (q >> 2);
+        if (col0 < d) {
+            out[(int64_t)row * ldo + col0] = acc00[q];
+            out[(int64_t)(row + 32) * ldo + col0] = acc10[q];
+        }
+        if (col1 < d) {
+            out[(int64_t)row * ldo + col1] = acc01[q];
+            out[(int64_t)(row + 32) * ldo + col1] = acc11[q];
+        }
+    }
+}
+
+// ---- assembling M and the per-column statistics ------------------------------------------------------
+// rows [0,k): S_t V_t ; [k, k+m): X - bm ; k+m: mc ; beyond: zero.   vec = [bm | mc | delta] (float64)
+__global__ void ss_build_kernel(const float *__restrict__ X, int64_t ldx, int m, const float *__restrict__ V,
+                                const double *__restrict__ lam, const double *__restrict__ vec, int64_t d,
+                                int k, int rp, double n0, float *__restrict__ M) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int t = blockIdx.y;
+    if (j >= d) return;
+    float v = 0.f;
+    if (t < k) {
+        if (n0 > 0) v = (float)(sqrt(lam[t]) * (double)V[(int64_t)t * d + j]);
+    } else if (t < k + m) {
+        v = (float)((double)X[(int64_t)(t - k) * ldx + j] - vec[j]);
+    } else if (t == k + m) {
+        v = (n0 > 0) ? (float)vec[d + j] : 0.f;
+    }
+    M[(int64_t)t * d + j] = v;
+}
+
+// colsq[j] += sum over the m data rows of M[k + t][j]^2   (float64)
+__global__ __launch_bounds__(256) void ss_colsq_kernel(const float *__restrict__ M, int64_t d, int k, int m,
+                                                       double *__restrict__ colsq, int rows_per_block) {
+    __shared__ double scr[8][32];
+    const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
+    const int64_t col = (int64_t)blockIdx.x * 32 + cx;
+    const int r0 = blockIdx.y * rows_per_block;
+    const int r1 = (r0 + rows_per_block < m) ? r0 + rows_per_block : m;
+    double s = 0;
+    if (col < d)
+        for (int r = r0 + ry; r < r1; r += 8) {
+            const double v = M[(int64_t)(k + r) * d + col];
+            s += v * v;
+        }
+    scr[ry][cx] = s;
+    __syncthreads();
+    if (ry == 0 && col < d) {
+        double t = 0;
+        for (int g = 0; g < 8; ++g) t += scr[g][cx];
+        atomicAdd(colsq + col, t);
+    }
+}
+
+__global__ void ss_stats_kernel(const double *__restrict__ bs, double *__restrict__ mean,
+                                double *__restrict__ vec, int64_t d, double n0, double m) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= d) return;
+    const double n1 = n0 + m;
+    const double bm = bs[i] / m;
+    vec[i] = bm;
+    if (n0 > 0) {
+        const double mu = mean[i];
+        const double delta = bm - mu;
+        vec[d + i] = sqrt(n0 / n1 * m) * (mu - bm);
+        vec[2 * d + i] = delta;
+        mean[i] = mu + delta * (m / n1);
+    } else {
+        vec[d + i] = 0;
+        vec[2 * d + i] = 0;
+        mean[i] = bm;
+    }
+}
+
+__global__ void ss_m2_kernel(const double *__restrict__ colsq, const double *__restrict__ vec,
+                             double *__restrict__ m2, int64_t d, double n0, double m) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= d) return;
+    const double dl = vec[2 * d + i];
+    m2[i] = (n0 > 0 ? m2[i] : 0.0) + colsq[i] + dl * dl * (n0 * m / (n0 + m));
+}
+
+// Coefficients: column j of W (= w_j u_j, norms[j] = w_j^2) with rank i < k  ->  Ct[t][i] = u_j[t] / sqrt(w_j)
+__global__ void ss_coef_kernel(const double *__restrict__ W, int64_t ldw, const double *__restrict__ norms,
+                               const double *__restrict__ maxnorm, const int *__restrict__ rank, int r, int rp,
+                               int k, int kp, float *__restrict__ Ct, double *__restrict__ lam) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = blockIdx.y;
+    if (j >= r) return;
+    const int i = rank[j];
+    if (i >= k) return;
+    const double nrm2 = norms[j];
+    const double w = sqrt(nrm2);  // eigenvalue of T = sigma^2
+    // numerically zero direction (rank-deficient data): no component can be formed from it
+    const bool dead = nrm2 <= maxnorm[0] * 1e-26;
+    if (t < rp) {
+        const double c = (dead || t >= r) ? 0.0 : W[(int64_t)j * ldw + t] / (w * sqrt(w));
+        Ct[(int64_t)t * kp + i] = (float)c;
+    }
+    if (t == 0) lam[i] = dead ? 0.0 : w;
+}
+
+// per row: sign of the largest-magnitude entry (first index wins ties), V[i] = sign * Vtmp[i]
+__global__ __launch_bounds__(1024) void ss_sign_kernel(const float *__restrict__ Vtmp, int64_t ldv,
+                                                       float *__restrict__ V, int64_t d) {
+    __shared__ float sbest[1024];
+    __shared__ long long sidx[1024];
+    __shared__ float ssgn;
+    const int i = blockIdx.x;
+    const float *src = Vtmp + (int64_t)i * ldv;
+    float best = -1.f;
+    long long bi = 0x7fffffffffffffffLL;
+    for (int64_t e = threadIdx.x; e < d; e += 1024) {
+        const float a = fabsf(src[e]);
+        if (a > best) {
+            best = a;
+            bi = e;
+        }
+    }
+    sbest[threadIdx.x] = best;
+    sidx[threadIdx.x] = bi;
+    __syncthreads();
+    for (int s = 512; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) {
+            const float ob = sbest[threadIdx.x + s];
+            const long long oi = sidx[threadIdx.x + s];
+            if (ob > sbest[threadIdx.x] || (ob == sbest[threadIdx.x] && oi < sidx[threadIdx.x])) {
+                sbest[threadIdx.x] = ob;
+                sidx[threadIdx.x] = oi;
+            }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) ssgn = (sbest[0] > 0.f && src[sidx[0]] < 0.f) ? -1.f : 1.f;
+    __syncthreads();
+    const float sg = ssgn;
+    float *dst = V + (int64_t)i * d;
+    for (int64_t e = threadIdx.x; e < d; e += 1024) dst[e] = sg * src[e];
+}
+
+// ---- host orchestration ---------------------------------------------------------------------------------
+int smallside_alloc(SmallSide &ss, int64_t d, int k, int m) {
+    smallside_free(ss);
+    ss.d = d;
+    ss.k = k;
+    ss.m_cap = m;
+    ss.r_cap = k + m + 1;
+    ss.rp = (int)round_up(ss.r_cap, kRT);
+    ss.kp = (int)round_up(k, kRT);
+    ss.nsplit = 4;
+    auto alloc = [&](void **p, size_t bytes) -> int {
+        if (hipMalloc(p, bytes) != hipSuccess) {
+            set_error("smallside: hipMalloc failed");
+            return GS_ENOMEM;
+        }
+        return hipMemset(*p, 0, bytes) == hipSuccess ? GS_OK : GS_EHIP;
+    };
+    int rc = GS_OK;
+    if (rc == GS_OK) rc = alloc((void **)&ss.M, sizeof(float) * (size_t)ss.rp * d);
+    if (rc == GS_OK) rc = alloc((void **)&ss.T, sizeof(double) * (size_t)ss.rp * ss.rp);
+    if (rc == GS_OK) rc = alloc((void **)&ss.slab, sizeof(double) * (size_t)ss.nsplit * ss.rp * ss.rp);
+    if (rc == GS_OK) rc = alloc((void **)&ss.Ct, sizeof(float) * (size_t)ss.rp * ss.kp);
+    if (rc == GS_OK) rc = alloc((void **)&ss.Vtmp, sizeof(float) * (size_t)ss.kp * d);
+    if (rc == GS_OK) rc = alloc((void **)&ss.colsq, sizeof(double) * d);
+    if (rc == GS_OK) rc = eigh_workspace_alloc(ss.ews, ss.rp + 2);
+    return rc;
+}
+
+void smallside_free(SmallSide &ss) {
+    void *ptrs[] = {ss.M, ss.T, ss.slab, ss.Ct, ss.Vtmp, ss.colsq};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    eigh_workspace_free(ss.ews);
+    ss = SmallSide();
+}
+
+// One partial_fit block.  V (k x d f32), lam (k), mean/m2 (d), vec (3d scratch), bs (d scratch) belong to the caller.
+int smallside_update(SmallSide &ss, const float *X, int64_t rows, int64_t ldx, double n0, float *V, double *lam,
+                     double *mean, double *m2, double *vec, double *bs, int *sweeps_out, hipStream_t stream) {
+    const int64_t d = ss.d;
+    const int k = ss.k, m = (int)rows;
+    const int r = k + m + 1, rp = ss.rp, kp = ss.kp;
+    GS_REQUIRE(r <= ss.r_cap, GS_ESTATE, "smallside_update: block larger than the allocated capacity");
+    // 1. column sums -> block mean, Chan update of the running mean, mean-correction row
+    GS_HIP_CHECK(hipMemsetAsync(bs, 0, sizeof(double) * d, stream));
+    GS_HIP_CHECK(hipMemsetAsync(ss.colsq, 0, sizeof(double) * d, stream));
+    int rc = column_sums_f64(X, rows, ldx, d, bs, stream);
+    if (rc != GS_OK) return rc;
+    const unsigned gd = (unsigned)ceil_div(d, 256);
+    hipLaunchKernelGGL(ss_stats_kernel, dim3(gd), dim3(256), 0, stream, bs, mean, vec, d, n0, (double)m);
+    // 2. M = [S V ; X - bm ; mc ; 0]
+    hipLaunchKernelGGL(ss_build_kernel, dim3(gd, (unsigned)rp), dim3(256), 0, stream, X, ldx, m, V, lam, vec, d, k,
+                       rp, n0, ss.M);
+    // 3. per-feature sum of squared deviations of this block -> variance update
+    hipLaunchKernelGGL(ss_colsq_kernel, dim3((unsigned)ceil_div(d, 32), (unsigned)ceil_div(m, 256)), dim3(256), 0,
+                       stream, ss.M, d, k, m, ss.colsq, 256);
+    hipLaunchKernelGGL(ss_m2_kernel, dim3(gd), dim3(256), 0, stream, ss.colsq, vec, m2, d, n0, (double)m);
+    // 4. T = M M^T
+    const int Tt = (int)ceil_div(r, kRT), nmt = Tt * (Tt + 1) / 2;
+    const int64_t kchunk = round_up(ceil_div(d, ss.nsplit), kRK);
+    hipLaunchKernelGGL(rowgram_kernel, dim3((unsigned)(nmt * ss.nsplit)), dim3(256), 0, stream, ss.M, d, d, ss.slab,
+                       rp, nmt, Tt, kchunk);
+    const int rused = Tt * kRT;
+    hipLaunchKernelGGL(rowgram_fold_kernel, dim3((unsigned)ceil_div(rused, 256), (unsigned)rused), dim3(256), 0,
+                       stream, ss.slab, ss.T, rp, ss.nsplit);
+    GS_HIP_CHECK(hipGetLastError());
+    // 5. eigen-decomposition of T
+    rc = eigh_jacobi(ss.ews, ss.T, r, rp, sweeps_out, stream);
+    if (rc != GS_OK) return rc;
+    // 6. top-k coefficients, V' = Ct^T M, sign convention
+    rc = rank_columns(ss.ews, r, stream);
+    if (rc != GS_OK) return rc;
+    GS_HIP_CHECK(hipMemsetAsync(ss.Ct, 0, sizeof(float) * (size_t)rp * kp, stream));
+    hipLaunchKernelGGL(ss_coef_kernel, dim3((unsigned)ceil_div(rp, 256), (unsigned)r), dim3(256), 0, stream, ss.T,
+                       (int64_t)rp, ss.ews.norms, ss.ews.offmax + 1, ss.ews.rank, r, rp, k, kp, ss.Ct, lam);
+    const int64_t ntn = ceil_div(d, kRT);
+    hipLaunchKernelGGL(tn_gemm_kernel, dim3((unsigned)((kp / kRT) * ntn)), dim3(256), 0, stream, ss.Ct, kp, ss.M, d,
+                       d, r, ss.Vtmp, d);
+    hipLaunchKernelGGL(ss_sign_kernel, dim3((unsigned)k), dim3(1024), 0, stream, ss.Vtmp, d, V, d);
+    GS_HIP_CHECK(hipGetLastError());
+    return GS_OK;
+}
+
+}  // namespace gs

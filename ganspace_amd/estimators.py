@@ -8,6 +8,8 @@ attribute names (``mean_``, ``components_``, ``explained_variance_`` ...), which
 
 ``'ipca'``        sklearn-faithful recurrence on the device (all k components and signs
                   match ``IncrementalPCA``); cache key ``ipca_c{k}`` as in the reference.
+                  Gram-side (d x d) for feat_dim <= 8192, small-side (r x r, r = k+rows+1)
+                  beyond, chosen automatically.
 ``'ipca-exact'``  one global Gram + one eigensolve (the multi-GPU all-reduce design);
                   leading components match to ~1e-6 cosine, trailing ones are the *exact*
                   PCA instead of IPCA's truncated approximation; cache key ``ipca-exact_c{k}``.
@@ -37,6 +39,8 @@ class _DeviceIncrementalPCA:
     update and cached until the next one.
     """
 
+    GRAM_SIDE_MAX_FEATURES = 8192
+
     def __init__(self, n_components: int, mode: int, device=None):
         self.n_components = int(n_components)
         self.whiten = False
@@ -59,6 +63,10 @@ class _DeviceIncrementalPCA:
             raise RuntimeError("ganspace_amd needs a HIP device (torch.cuda.is_available() is False)")
         if self._device is None:
             self._device = torch.device("cuda", torch.cuda.current_device())
+        if self._mode == _lib.GS_MODE_FAITHFUL and d > self.GRAM_SIDE_MAX_FEATURES:
+            # feat_dim >> block rows (gen_z d = 32 768, conv features d = 131 072): same recurrence,
+            # handled from the small side of the stacked matrix
+            self._mode = _lib.GS_MODE_SMALLSIDE
         h = C.c_void_p()
         _lib.check(self._lib.gs_ipca_create(d, self.n_components, self._mode, _lib.GS_PREC_F32,
                                             self._device.index or 0, C.byref(h)))
@@ -205,12 +213,13 @@ class IPCAEstimator:
         self.n_components = n_components
         self.whiten = False
         self.mode = mode
-        m = {"faithful": _lib.GS_MODE_FAITHFUL, "exact": _lib.GS_MODE_EXACT}[mode]
+        m = {"faithful": _lib.GS_MODE_FAITHFUL, "exact": _lib.GS_MODE_EXACT,
+             "smallside": _lib.GS_MODE_SMALLSIDE}[mode]
         self.transformer = _DeviceIncrementalPCA(n_components, m, device)
         self.batch_support = True
 
     def get_param_str(self):
-        tag = "ipca" if self.mode == "faithful" else "ipca-exact"
+        tag = "ipca-exact" if self.mode == "exact" else "ipca"
         return "{}_c{}{}".format(tag, self.n_components, "_w" if self.whiten else "")
 
     def fit(self, X):

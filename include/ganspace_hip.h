@@ -46,8 +46,12 @@ enum {
  *                  IPCA's to ~1e-6 cosine, trailing ones differ by IPCA's own truncation.
  * GS_MODE_FAITHFUL sklearn's IncrementalPCA recurrence restated on the d x d Gram of its
  *                  stacked matrix (one eigensolve per block) - reproduces ALL k components
- *                  of the reference, signs included.                                       */
-enum { GS_MODE_EXACT = 0, GS_MODE_FAITHFUL = 1 };
+ *                  of the reference, signs included.
+ * GS_MODE_SMALLSIDE the same recurrence as FAITHFUL handled from the small side of the stacked
+ *                  matrix (r = k + rows + 1 <= 4096) for feat_dim >> block rows (BigGAN gen_z
+ *                  d = 32 768, conv features d = 131 072): T = M M^T, eigh(T), V' = S^-1 U^T M.
+ *                  Needs feat_dim % 4 == 0.                                                    */
+enum { GS_MODE_EXACT = 0, GS_MODE_FAITHFUL = 1, GS_MODE_SMALLSIDE = 2 };
 
 /* Arithmetic of the X^T X contraction.  GS_PREC_F32 = exact-f32 MFMA
  * (v_mfma_f32_32x32x2_f32), f32 accumulate per row-chunk, f64 across chunks/blocks. */

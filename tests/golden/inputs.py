@@ -19,6 +19,9 @@ IPCA_CASES = {
     "d200_k200_ragged": dict(seed=14, d=200, k=200, rank=200, decay=1.06, ncheck=100, blocks=[700, 333, 1024], mean_scale=0.5, noise=0.1),
     # |mean| >> stdev: the catastrophic-cancellation trap of raw moments (BigGAN gen_z-like bias)
     "d96_k12_bigmean": dict(seed=15, d=96, k=12, rank=32, decay=1.25, ncheck=12, blocks=[500, 500, 500], mean_scale=40.0, noise=0.05),
+    # feat_dim >> block rows: the small-side path (cfg3 / cfg5 shape in miniature)
+    "d3000_k12_highd": dict(seed=17, d=3000, k=12, rank=40, decay=1.12, ncheck=12, blocks=[300, 300, 300],
+                            mean_scale=1.0, noise=0.05),
     # affine in a 16-d latent: covariance rank 16 < k (BigGAN gen_z is affine in z)
     "d128_k24_lowrank": dict(seed=16, d=128, k=24, rank=16, decay=1.15, ncheck=16, blocks=[400, 400, 400], mean_scale=1.0, noise=0.0),
 }

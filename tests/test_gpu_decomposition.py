@@ -125,3 +125,66 @@ def test_biggan_gen_z_matches_oracle(dev):
     ref = synth.biggan_gen_z(z.cpu().numpy(), emb, g.weight.detach().cpu().numpy(), g.bias.detach().cpu().numpy())
     assert np.abs(act - ref).max() < 1e-5 * np.abs(ref).max()
     inst.close()
+
+
+def test_cfg3_biggan_gen_z_small_side(dev, tmp_path):
+    """BASELINE config 3 shape (reduced n): BigGAN-512 --layer=generator.gen_z, d = 32 768 >> NB = 2000
+    -> small-side recurrence; z from truncnorm with the reference's seeding; lat_comp by regression."""
+    from types import SimpleNamespace
+    from ganspace_amd.config import Config
+    from ganspace_amd.decomposition import get_or_compute
+    from ganspace_amd.wrappers import get_instrumented_model
+    from ganspace_amd import _lib
+    cfg = Config(model="BigGAN-512", layer="generator.gen_z", output_class=250, n=4000, batch_size=500,
+                 components=10, estimator="ipca")
+    inst = get_instrumented_model(cfg.model, cfg.output_class, cfg.layer, dev)
+    model = inst.model
+    sub = SimpleNamespace(run_dir_root=str(tmp_path), run_dir=str(tmp_path))
+    path = get_or_compute(cfg, inst, submit_config=sub)
+    assert path.name == "biggan-512-250_generator.gen_z_ipca_c10_n4000.npz"
+    data = np.load(path, allow_pickle=False)
+    assert data["act_comp"].shape == (10, 1, 32768) and data["lat_comp"].shape == (10, 1, 128)
+
+    emb = model.model.embeddings.weight.detach().cpu().numpy()[:, 250]
+    g = model.model.generator.gen_z
+    Wg, bg = g.weight.detach().cpu().numpy(), g.bias.detach().cpu().numpy()
+    feats = lambda z: synth.biggan_gen_z(z, emb, Wg, bg).astype(np.float32)
+    ref = pipeline.run(4000, 500, 10, features=feats, latent_kind="biggan")
+    cos = O.signed_cosines(data["act_comp"].reshape(10, -1), ref["act_comp"])
+    assert cos.min() > 1 - 1e-4, cos
+    np.testing.assert_allclose(data["act_stdev"], ref["act_stdev"], rtol=1e-3)
+    np.testing.assert_allclose(data["var_ratio"], ref["var_ratio"], rtol=2e-3)
+    np.testing.assert_allclose(data["act_mean"].ravel(), ref["act_mean"].ravel(), atol=1e-4)
+    lcos = O.signed_cosines(data["lat_comp"].reshape(10, -1), ref["lat_comp"])
+    assert lcos.min() > 0.999, lcos
+    inst.close()
+
+
+def test_cfg5_conv_features_small_side(dev):
+    """BASELINE config 5 shape: StyleGAN2 conv activations (convs.0: 512 x 8 x 8 = 32 768 features here;
+    convs.2 is 131 072).  The generator prefix is PyTorch-ROCm (out of kernel scope), so parity is of the PCA
+    path: the same hooked activations go to the device estimator and to the CPU oracle."""
+    from ganspace_amd.estimators import get_estimator
+    from ganspace_amd.wrappers import get_instrumented_model
+    inst = get_instrumented_model("StyleGAN2", "cat", "convs.0", dev)
+    model = inst.model
+    est = get_estimator("ipca", 8, 1.0)
+    orc = O.IPCAEstimatorOracle(8, "svd")
+    np.random.seed(5)
+    with torch.no_grad():
+        for _ in range(2):
+            rows = []
+            for _ in range(4):
+                z = model.sample_latent(64)
+                model.partial_forward(z, "convs.0")
+                rows.append(inst.retained_features()["convs.0"].reshape(64, -1))
+            X = torch.cat(rows)                      # [256, 32768] float32, on the device
+            assert X.shape[1] == 32768
+            assert est.fit_partial(X)
+            orc.fit_partial(X.cpu().numpy())
+    cos = O.signed_cosines(est.transformer.components_, orc.transformer.components_)
+    assert cos.min() > 1 - 1e-5, cos
+    np.testing.assert_allclose(est.transformer.singular_values_, orc.transformer.singular_values_, rtol=1e-4)
+    np.testing.assert_allclose(est.transformer.explained_variance_ratio_,
+                               orc.transformer.explained_variance_ratio_, rtol=1e-3)
+    inst.close()

@@ -162,6 +162,47 @@ def test_exact_mode_matches_exact_oracle(dev, golden_dir, name):
     assert est.get_param_str() == f"ipca-exact_c{case['k']}"
 
 
+@pytest.mark.parametrize("name", ["d3000_k12_highd", "d512_k20", "d128_k24_lowrank", "d64_k8"])
+def test_smallside_mode_matches_reference_fixture(dev, golden_dir, name):
+    """d >> m formulation (T = M M^T): same recurrence, same answers as the reference fixture."""
+    from ganspace_amd.estimators import IPCAEstimator
+    case = gin.IPCA_CASES[name]
+    g = _golden(golden_dir, name)
+    est = IPCAEstimator(case["k"], "smallside")
+    for X in gin.ipca_blocks(case):
+        assert est.fit_partial(torch.from_numpy(X).to(dev)) is True
+    comp, stdev, ratio = est.get_components()
+    t = est.transformer
+    r = case["ncheck"]
+    cos = O.signed_cosines(comp[:r], g["components"][:r])
+    assert cos.min() > 1 - 5e-6, (name, cos.min())
+    scale = g["singular_values"][0]
+    np.testing.assert_allclose(t.singular_values_[:r], g["singular_values"][:r], rtol=1e-4)
+    np.testing.assert_allclose(t.singular_values_, g["singular_values"], atol=5e-4 * scale)
+    np.testing.assert_allclose(t.mean_, g["mean"], atol=2e-6 * max(1.0, np.abs(g["mean"]).max()))
+    np.testing.assert_allclose(t.var_, g["var"], rtol=1e-4)
+    np.testing.assert_allclose(ratio[:r], g["var_ratio"][:r], rtol=2e-4)
+    assert int(t.n_samples_seen_) == int(g["n_samples_seen"])
+    assert est.get_param_str() == str(g["param_str"])
+
+
+def test_smallside_is_selected_automatically_for_wide_features(dev):
+    from ganspace_amd import _lib
+    from ganspace_amd.estimators import get_estimator
+    rs = np.random.RandomState(0)
+    A = rs.standard_normal((24, 16384)) * (1.2 ** -np.arange(24))[:, None]
+    est = get_estimator("ipca", 6, 1.0)
+    orc = O.IPCAEstimatorOracle(6, "svd")
+    for _ in range(2):
+        X = (rs.standard_normal((64, 24)) @ A + 0.01 * rs.standard_normal((64, 16384))).astype(np.float32)
+        assert est.fit_partial(torch.from_numpy(X).to(dev))
+        orc.fit_partial(X)
+    assert est.transformer._mode == _lib.GS_MODE_SMALLSIDE
+    cos = O.signed_cosines(est.transformer.components_, orc.transformer.components_)
+    assert cos.min() > 1 - 1e-5, cos
+    np.testing.assert_allclose(est.transformer.singular_values_, orc.transformer.singular_values_, rtol=1e-4)
+
+
 def test_first_block_smaller_than_k_returns_false(dev, capsys):
     from ganspace_amd.estimators import get_estimator
     est = get_estimator("ipca", 20, 1.0)
