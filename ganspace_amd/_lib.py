@@ -32,6 +32,7 @@ SIGNATURES = {
     "gs_state_recenter": (_int, [_vp, _i64, _vp, _vp]),
     "gs_ipca_finalize": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gs_ipca_last_sweeps": (_int, [_vp]),
+    "gs_ipca_last_mults": (_int, [_vp]),
     "gs_ipca_components_device": (_int, [_vp, C.POINTER(_vp), C.POINTER(_vp)]),
     "gs_gram_accumulate": (_int, [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp]),
     "gs_gram_kernel_time": (_int, [_vp, _vp, _i64, _i64, _int, _vp, _vp, _vp]),

@@ -78,6 +78,24 @@ int rank_columns(const EighWorkspace &ws, int n, hipStream_t stream);
 // column sums of X[rows, ld] accumulated (atomically) into out[d] (float64, caller zeroes it)
 int column_sums_f64(const float *X, int64_t rows, int64_t ld, int64_t d, double *out, hipStream_t stream);
 
+// ---- top-k subspace eigensolver: gs_subspace.hip ---------------------------------------------------
+struct SubspaceWorkspace {
+    int n_cap = 0, p_cap = 0, pp = 0;
+    double *Q = nullptr, *Y = nullptr, *Z = nullptr, *R = nullptr;  // [n][pp]
+    double *H = nullptr, *B = nullptr, *U = nullptr;                // [pp][pp]
+    double *theta = nullptr;                                        // [2*pp + 8]: Ritz values | residuals | pivot floor
+    double *Rm = nullptr;                                           // [pp][pp] Cholesky factor
+    double *Dinv = nullptr;                                         // inverses of its 32 x 32 diagonal blocks
+    EighWorkspace ews;
+};
+int subspace_workspace_alloc(SubspaceWorkspace &ws, int n, int p);
+void subspace_workspace_free(SubspaceWorkspace &ws);
+// subspace dimension used for (n, k), or 0 when the full Jacobi solver should be used instead
+int subspace_dim(int n, int k);
+int eigh_topk_subspace(SubspaceWorkspace &ws, const double *A, int n, int64_t lda, int k, const double *V0, int k0,
+                       int64_t ldv0, double *Vk, int64_t ldv, double *lam, int *iters_out, int *converged,
+                       hipStream_t stream);
+
 // ---- small-side recurrence for d >> m: gs_smallside.hip -------------------------------------------
 struct SmallSide {
     int64_t d = 0;
@@ -89,6 +107,10 @@ struct SmallSide {
     float *Vtmp = nullptr;   // [kp][d]
     double *colsq = nullptr; // [d]
     EighWorkspace ews;
+    SubspaceWorkspace sws;   // top-k solver on T
+    double *Uk = nullptr;    // [k][rp] leading eigenvectors of T (rows)
+    double *wk = nullptr;    // [k]     leading eigenvalues of T
+    int last_mults = 0;
 };
 int smallside_alloc(SmallSide &ss, int64_t d, int k, int m);
 void smallside_free(SmallSide &ss);

@@ -286,7 +286,8 @@ static int launch_block_sweeps(const EighWorkspace &ws, double *W, int n, int64_
     int host_done[2] = {0, 0};
     while (sweeps < kMaxSweeps) {
         // enqueue a few sweeps without touching the host, then look at the device flag
-        const int batch = (sweeps == 0) ? 6 : 2;
+        // small problems (the p x p Rayleigh-Ritz matrices) are often nearly diagonal already: look early
+        const int batch = (sweeps == 0) ? (n <= 256 ? 3 : 6) : 2;
         for (int s = 0; s < batch; ++s) {
             for (int r = 0; r < rounds; ++r)
                 hipLaunchKernelGGL(kern, dim3(nblk / 2), dim3(BS * 64), lds_bytes, stream, W, n, ldw, nblk, r,

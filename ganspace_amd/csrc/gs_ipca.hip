@@ -12,6 +12,7 @@
 //             eigh(Gc) -> S' = sqrt(w_top), V' = sign-fixed rows; Chan update of mean/var.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -51,6 +52,8 @@ struct gs_ipca {
     // GS_MODE_SMALLSIDE only (d >> block rows): comp32 doubles as the float32 state V
     SmallSide ss;
     double *bs = nullptr;        // [d] column sums scratch
+    SubspaceWorkspace sws;       // top-k subspace eigensolver (Gram-side modes, when k << d)
+    int last_mults = 0;          // multiplications by A used by the last subspace solve (0 = full Jacobi)
 };
 
 namespace {
@@ -168,6 +171,36 @@ __global__ __launch_bounds__(256) void select_topk_kernel(const double *__restri
     if (lane == 0) lam[r] = sqrt(nrm2);
 }
 
+// In-place svd_flip sign convention on unit rows Vk[k][dp] (first n entries valid), zero padding beyond n.
+__global__ __launch_bounds__(256) void signfix_rows_kernel(double *__restrict__ Vk, int n, int dp, int k) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= k) return;
+    double *row = Vk + (int64_t)r * dp;
+    double best = -1.0, bestv = 0.0;
+    int besti = 0x7fffffff;
+    for (int e = lane; e < n; e += 64) {
+        const double v = row[e], a = fabs(v);
+        if (a > best) {
+            best = a;
+            bestv = v;
+            besti = e;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const double ob = __shfl_xor(best, o, 64), ov = __shfl_xor(bestv, o, 64);
+        const int oi = __shfl_xor(besti, o, 64);
+        if (ob > best || (ob == best && oi < besti)) {
+            best = ob;
+            bestv = ov;
+            besti = oi;
+        }
+    }
+    const double sgn = (bestv < 0) ? -1.0 : 1.0;
+    for (int e = lane; e < dp; e += 64) row[e] = (e < n) ? row[e] * sgn : 0.0;
+}
+
 // sv = sqrt(lambda), ev = lambda/(n-1), evr = lambda/total
 __global__ void derive_outputs_kernel(const double *__restrict__ lam, const double *__restrict__ total_src,
                                       int total_len, double *__restrict__ outs, int k, double n) {
@@ -276,16 +309,39 @@ __global__ void add_vec_kernel(const double *__restrict__ src, double *__restric
     if (j < d) dst[j] += src[j];
 }
 
-int select_and_derive(gs_ipca *h, const double *total_src, int total_len, hipStream_t stream) {
+// Top-k eigenpairs of the assembled matrix h->W into h->Vk / h->lam (sign-fixed), then the derived
+// outputs.  Subspace iteration when k << n (warm-started from the previous components if `warm`),
+// full Jacobi otherwise or when the residual target is missed.
+int solve_topk(gs_ipca *h, bool warm, const double *total_src, int total_len, hipStream_t stream) {
     const int n = h->n2, dp = (int)h->dp, k = h->k;
-    int rc0 = rank_columns(h->ews, n, stream);
-    if (rc0 != GS_OK) return rc0;
-    hipLaunchKernelGGL(select_topk_kernel, dim3((unsigned)ceil_div(n, 4)), dim3(256), 0, stream, h->W,
-                       h->ews.norms, h->ews.rank, h->Vk, h->lam, n, (int64_t)dp, dp, k);
-    hipLaunchKernelGGL(derive_outputs_kernel, dim3(1), dim3(256), 0, stream, h->lam, total_src, total_len,
-                       h->outs, k, (double)h->n_seen);
-    hipLaunchKernelGGL(to_f32_kernel, dim3((unsigned)ceil_div(h->d, 256), (unsigned)(k + 1)), dim3(256), 0,
-                       stream, h->Vk, h->mean, h->comp32, h->mean32, (int)h->d, dp, k);
+    static const bool no_subspace = getenv("GS_EIGH_FULL") != nullptr;
+    bool done = false;
+    h->last_mults = 0;
+    if (h->sws.Q != nullptr && !no_subspace) {
+        int mults = 0, converged = 0;
+        int rc = eigh_topk_subspace(h->sws, h->W, n, dp, k, warm ? h->Vk : nullptr, warm ? k : 0, dp, h->Vk, dp,
+                                    h->lam, &mults, &converged, stream);
+        if (rc != GS_OK) return rc;
+        if (converged) {
+            hipLaunchKernelGGL(signfix_rows_kernel, dim3((unsigned)ceil_div(k, 4)), dim3(256), 0, stream, h->Vk, n, dp,
+                               k);
+            h->last_mults = mults;
+            h->last_sweeps = 0;
+            done = true;
+        }
+    }
+    if (!done) {
+        int rc = eigh_jacobi(h->ews, h->W, n, dp, &h->last_sweeps, stream);
+        if (rc != GS_OK) return rc;
+        rc = rank_columns(h->ews, n, stream);
+        if (rc != GS_OK) return rc;
+        hipLaunchKernelGGL(select_topk_kernel, dim3((unsigned)ceil_div(n, 4)), dim3(256), 0, stream, h->W,
+                           h->ews.norms, h->ews.rank, h->Vk, h->lam, n, (int64_t)dp, dp, k);
+    }
+    hipLaunchKernelGGL(derive_outputs_kernel, dim3(1), dim3(256), 0, stream, h->lam, total_src, total_len, h->outs, k,
+                       (double)h->n_seen);
+    hipLaunchKernelGGL(to_f32_kernel, dim3((unsigned)ceil_div(h->d, 256), (unsigned)(k + 1)), dim3(256), 0, stream,
+                       h->Vk, h->mean, h->comp32, h->mean32, (int)h->d, dp, k);
     GS_HIP_CHECK(hipGetLastError());
     return GS_OK;
 }
@@ -371,6 +427,7 @@ int gs_ipca_create(int64_t d, int k, int mode, int precision, int device, gs_ipc
     }
     rc = gram_workspace_alloc(h->gws, d);
     if (rc == GS_OK) rc = eigh_workspace_alloc(h->ews, (int)d + 2);
+    if (rc == GS_OK && subspace_dim((int)d, k) > 0) rc = subspace_workspace_alloc(h->sws, (int)d, subspace_dim((int)d, k));
     h->dp = h->gws.dp;
     const int64_t dp = h->dp;
     alloc((void **)&h->shift, sizeof(float) * dp);
@@ -400,6 +457,7 @@ int gs_ipca_destroy(gs_ipca_t *h) {
     gram_workspace_free(h->gws);
     eigh_workspace_free(h->ews);
     smallside_free(h->ss);
+    subspace_workspace_free(h->sws);
     void *ptrs[] = {h->shift, h->S1, h->G64, h->W,   h->mean,   h->m2,    h->vec, h->bs,
                     h->Vk,    h->lam, h->scal, h->outs, h->comp32, h->mean32};
     for (void *p : ptrs)
@@ -438,6 +496,7 @@ int gs_ipca_update(gs_ipca_t *h, const float *X, int64_t rows, int64_t ld, void 
         int rc = smallside_update(h->ss, X, rows, ld, (double)h->n_seen, h->comp32, h->lam, h->mean, h->m2, h->vec,
                                   h->bs, &h->last_sweeps, stream);
         if (rc != GS_OK) return rc;
+        h->last_mults = h->ss.last_mults;
         h->n_seen += rows;
         h->blocks += 1;
         hipLaunchKernelGGL(derive_outputs_kernel, dim3(1), dim3(256), 0, stream, h->lam, h->m2, (int)h->d, h->outs,
@@ -468,11 +527,9 @@ int gs_ipca_update(gs_ipca_t *h, const float *X, int64_t rows, int64_t ld, void 
                        h->shift, h->mean, h->vec, d, dp, n0, m);
     hipLaunchKernelGGL(faithful_assemble_kernel, dim3((unsigned)ceil_div(d, 256), (unsigned)d), dim3(256), 0,
                        stream, h->G64, h->vec, h->Vk, h->lam, h->W, h->m2, d, dp, h->k, n0, m);
-    rc = eigh_jacobi(h->ews, h->W, h->n2, dp, &h->last_sweeps, stream);
-    if (rc != GS_OK) return rc;
     h->n_seen += rows;
     h->blocks += 1;
-    rc = select_and_derive(h, h->m2, d, stream);
+    rc = solve_topk(h, /*warm=*/n0 > 0, h->m2, d, stream);
     if (rc != GS_OK) return rc;
     hipLaunchKernelGGL(mean_to_shift_kernel, dim3((unsigned)ceil_div(dp, 256)), dim3(256), 0, stream, h->mean,
                        h->shift, d, dp);
@@ -542,9 +599,7 @@ int gs_ipca_finalize(gs_ipca_t *h, float *components_host, double *singular_valu
     if (h->mode == GS_MODE_EXACT && !h->finalized) {
         int rc = exact_solve(h, stream);
         if (rc != GS_OK) return rc;
-        rc = eigh_jacobi(h->ews, h->W, h->n2, h->dp, &h->last_sweeps, stream);
-        if (rc != GS_OK) return rc;
-        rc = select_and_derive(h, h->scal, 1, stream);
+        rc = solve_topk(h, /*warm=*/false, h->scal, 1, stream);
         if (rc != GS_OK) return rc;
         h->finalized = true;
     }
@@ -573,6 +628,7 @@ int gs_ipca_finalize(gs_ipca_t *h, float *components_host, double *singular_valu
 }
 
 int gs_ipca_last_sweeps(const gs_ipca_t *h) { return h ? h->last_sweeps : GS_EINVAL; }
+int gs_ipca_last_mults(const gs_ipca_t *h) { return h ? h->last_mults : GS_EINVAL; }
 
 int gs_ipca_components_device(gs_ipca_t *h, const float **components, const float **mean) {
     GS_REQUIRE(h != nullptr, GS_EINVAL, "gs_ipca_components_device: NULL handle");

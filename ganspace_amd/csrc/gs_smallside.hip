@@ -15,6 +15,8 @@
 // M is materialised once per block in HBM (1.09 GB at r = 2081, d = 131 072: 288 GB of HBM make
 // that the simple choice) and streamed: once for T (row panels re-read through L2/MALL), once
 // for V'.
+#include <cstdlib>
+
 #include "gs_common.h"
 
 namespace gs {
@@ -324,6 +326,19 @@ __global__ void ss_coef_kernel(const double *__restrict__ W, int64_t ldw, const 
     if (t == 0) lam[i] = dead ? 0.0 : w;
 }
 
+// Same from unit eigenvector ROWS Uk[i][:] (subspace solver output) with eigenvalues wk[i]
+__global__ void ss_coef_rows_kernel(const double *__restrict__ Uk, int64_t ldu, const double *__restrict__ wk, int r,
+                                    int rp, int k, int kp, float *__restrict__ Ct, double *__restrict__ lam) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = blockIdx.y;
+    if (i >= k || t >= rp) return;
+    const double w = wk[i];
+    const bool dead = !(w > wk[0] * 1e-13);
+    const double c = (dead || t >= r) ? 0.0 : Uk[(int64_t)i * ldu + t] / sqrt(w);
+    Ct[(int64_t)t * kp + i] = (float)c;
+    if (t == 0) lam[i] = dead ? 0.0 : w;
+}
+
 // per row: sign of the largest-magnitude entry (first index wins ties), V[i] = sign * Vtmp[i]
 __global__ __launch_bounds__(1024) void ss_sign_kernel(const float *__restrict__ Vtmp, int64_t ldv,
                                                        float *__restrict__ V, int64_t d) {
@@ -387,14 +402,18 @@ int smallside_alloc(SmallSide &ss, int64_t d, int k, int m) {
     if (rc == GS_OK) rc = alloc((void **)&ss.Vtmp, sizeof(float) * (size_t)ss.kp * d);
     if (rc == GS_OK) rc = alloc((void **)&ss.colsq, sizeof(double) * d);
     if (rc == GS_OK) rc = eigh_workspace_alloc(ss.ews, ss.rp + 2);
+    if (rc == GS_OK) rc = alloc((void **)&ss.Uk, sizeof(double) * (size_t)k * ss.rp);
+    if (rc == GS_OK) rc = alloc((void **)&ss.wk, sizeof(double) * (size_t)k);
+    if (rc == GS_OK && subspace_dim(ss.r_cap, k) > 0) rc = subspace_workspace_alloc(ss.sws, ss.rp, subspace_dim(ss.r_cap, k));
     return rc;
 }
 
 void smallside_free(SmallSide &ss) {
-    void *ptrs[] = {ss.M, ss.T, ss.slab, ss.Ct, ss.Vtmp, ss.colsq};
+    void *ptrs[] = {ss.M, ss.T, ss.slab, ss.Ct, ss.Vtmp, ss.colsq, ss.Uk, ss.wk};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     eigh_workspace_free(ss.ews);
+    subspace_workspace_free(ss.sws);
     ss = SmallSide();
 }
 
@@ -428,15 +447,35 @@ int smallside_update(SmallSide &ss, const float *X, int64_t rows, int64_t ldx, d
     hipLaunchKernelGGL(rowgram_fold_kernel, dim3((unsigned)ceil_div(rused, 256), (unsigned)rused), dim3(256), 0,
                        stream, ss.slab, ss.T, rp, ss.nsplit);
     GS_HIP_CHECK(hipGetLastError());
-    // 5. eigen-decomposition of T
-    rc = eigh_jacobi(ss.ews, ss.T, r, rp, sweeps_out, stream);
-    if (rc != GS_OK) return rc;
-    // 6. top-k coefficients, V' = Ct^T M, sign convention
-    rc = rank_columns(ss.ews, r, stream);
-    if (rc != GS_OK) return rc;
+    // 5. leading k eigenpairs of T: subspace iteration (the top-left k x k block of T is diag(S^2), so the
+    //    first k unit vectors are a good start from the second block on); full Jacobi as the fallback
     GS_HIP_CHECK(hipMemsetAsync(ss.Ct, 0, sizeof(float) * (size_t)rp * kp, stream));
-    hipLaunchKernelGGL(ss_coef_kernel, dim3((unsigned)ceil_div(rp, 256), (unsigned)r), dim3(256), 0, stream, ss.T,
-                       (int64_t)rp, ss.ews.norms, ss.ews.offmax + 1, ss.ews.rank, r, rp, k, kp, ss.Ct, lam);
+    bool done = false;
+    ss.last_mults = 0;
+    static const bool no_subspace = getenv("GS_EIGH_FULL") != nullptr;
+    if (ss.sws.Q != nullptr && subspace_dim(r, k) > 0 && !no_subspace) {
+        int mults = 0, converged = 0;
+        rc = eigh_topk_subspace(ss.sws, ss.T, r, rp, k, nullptr, n0 > 0 ? k : 0, 0, ss.Uk, rp, ss.wk, &mults,
+                                &converged, stream);
+        if (rc != GS_OK) return rc;
+        if (converged) {
+            hipLaunchKernelGGL(ss_coef_rows_kernel, dim3((unsigned)ceil_div(rp, 256), (unsigned)k), dim3(256), 0,
+                               stream, ss.Uk, (int64_t)rp, ss.wk, r, rp, k, kp, ss.Ct, lam);
+            ss.last_mults = mults;
+            if (sweeps_out) *sweeps_out = 0;
+            done = true;
+        }
+    }
+    if (!done) {
+        rc = eigh_jacobi(ss.ews, ss.T, r, rp, sweeps_out, stream);
+        if (rc != GS_OK) return rc;
+        rc = rank_columns(ss.ews, r, stream);
+        if (rc != GS_OK) return rc;
+        hipLaunchKernelGGL(ss_coef_kernel, dim3((unsigned)ceil_div(rp, 256), (unsigned)r), dim3(256), 0, stream,
+                           ss.T, (int64_t)rp, ss.ews.norms, ss.ews.offmax + 1, ss.ews.rank, r, rp, k, kp, ss.Ct,
+                           lam);
+    }
+    // 6. V' = Ct^T M, sign convention
     const int64_t ntn = ceil_div(d, kRT);
     hipLaunchKernelGGL(tn_gemm_kernel, dim3((unsigned)((kp / kRT) * ntn)), dim3(256), 0, stream, ss.Ct, kp, ss.M, d,
                        d, r, ss.Vtmp, d);

@@ -1,0 +1,390 @@
+// Top-k symmetric eigensolver (float64): orthogonal (subspace) iteration with Rayleigh-Ritz.
+//
+// The PCA only keeps the k leading eigenpairs (k = 80 of n = 512 in the Gram-side modes, of
+// n = k + m + 1 ~ 2100 in the small-side mode), so instead of a full Jacobi diagonalisation
+// (gs_eigh.hip: O(n^3) per sweep, 10-20 sweeps) a p = 2k dimensional subspace is iterated:
+//
+//     Q <- orth(A A Q)   (CholeskyQR2; A Q is a float64 GEMM)            a few times
+//     B = Q^T A Q (p x p) -> Jacobi eigh(B) -> Ritz pairs, residuals    until ||A v - theta v||
+//     Q <- Q U                                                           is at rounding level
+//
+// Convergence of the i-th Ritz vector is (lambda_{p+1} / lambda_i)^its; PCA spectra decay, so
+// ~10-20 multiplications suffice (measured on the StyleGAN2 W-space covariance: 12 at p = 160).
+// If the residual target is not met within the iteration budget the caller falls back to the
+// full Jacobi solver, so robustness never depends on the spectrum.  A warm start (the previous
+// block's components) makes the per-block solve of the sklearn-faithful recurrence converge in
+// a handful of multiplications.
+#include <utility>
+#include <vector>
+
+#include "gs_common.h"
+
+namespace gs {
+
+constexpr int kTM = 64, kTN = 64, kTK = 16;
+
+// C[M x N] (row-major, ldc) = sum_t A(i,t) B(t,j) with arbitrary element strides, float64 VALU FMAs
+// (the f64 vector and matrix peaks coincide on gfx950).  64 x 64 x 16 tiles, 4 x 4 micro-tiles.
+__global__ __launch_bounds__(256) void gemm_f64_kernel(int M, int N, int K, const double *__restrict__ A,
+                                                       int64_t a_i, int64_t a_t, const double *__restrict__ B,
+                                                       int64_t b_t, int64_t b_j, double *__restrict__ C,
+                                                       int64_t ldc, double alpha, double beta) {
+    __shared__ double As[kTK][kTM + 1];
+    __shared__ double Bs[kTK][kTN + 1];
+    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+    const int i0 = blockIdx.y * kTM, j0 = blockIdx.x * kTN;
+    double acc[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[r][c] = 0.0;
+    const bool a_t_fast = (a_t == 1), b_j_fast = (b_j == 1);
+    for (int k0 = 0; k0 < K; k0 += kTK) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int e = tid + 256 * q;
+            int i, t;
+            if (a_t_fast) {
+                t = e % kTK;
+                i = e / kTK;
+            } else {
+                i = e % kTM;
+                t = e / kTM;
+            }
+            const int gi = i0 + i, gt = k0 + t;
+            As[t][i] = (gi < M && gt < K) ? A[gi * a_i + gt * a_t] : 0.0;
+            int j, t2;
+            if (b_j_fast) {
+                j = e % kTN;
+                t2 = e / kTN;
+            } else {
+                t2 = e % kTK;
+                j = e / kTK;
+            }
+            const int gj = j0 + j, gt2 = k0 + t2;
+            Bs[t2][j] = (gj < N && gt2 < K) ? B[gt2 * b_t + gj * b_j] : 0.0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < kTK; ++t) {
+            double a[4], b[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) a[r] = As[t][ty + 16 * r];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) b[c] = Bs[t][tx + 16 * c];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[r][c] += a[r] * b[c];
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int gi = i0 + ty + 16 * r;
+        if (gi >= M) continue;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int gj = j0 + tx + 16 * c;
+            if (gj < N) {
+                double *dst = C + (int64_t)gi * ldc + gj;
+                *dst = (beta == 0.0) ? alpha * acc[r][c] : beta * *dst + alpha * acc[r][c];
+            }
+        }
+    }
+}
+
+static void gemm_f64(int M, int N, int K, const double *A, int64_t a_i, int64_t a_t, const double *B, int64_t b_t,
+                     int64_t b_j, double *C, int64_t ldc, hipStream_t stream, double alpha = 1.0, double beta = 0.0) {
+    if (M <= 0 || N <= 0) return;
+    dim3 grid((unsigned)ceil_div(N, kTN), (unsigned)ceil_div(M, kTM));
+    hipLaunchKernelGGL(gemm_f64_kernel, grid, dim3(256), 0, stream, M, N, K, A, a_i, a_t, B, b_t, b_j, C, ldc, alpha,
+                       beta);
+}
+
+// deterministic pseudo-random start: Q[i][j] in (-1, 1)
+__global__ void subspace_init_kernel(double *__restrict__ Q, int n, int p, int64_t ldq, int col0) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = blockIdx.y;
+    if (j >= p || j < col0) return;
+    unsigned long long x = ((unsigned long long)i * 0x9E3779B97F4A7C15ULL) ^ ((unsigned long long)(j + 1) * 0xC2B2AE3D27D4EB4FULL);
+    x ^= x >> 29;
+    x *= 0xBF58476D1CE4E5B9ULL;
+    x ^= x >> 32;
+    x *= 0x94D049BB133111EBULL;
+    x ^= x >> 29;
+    Q[(int64_t)i * ldq + j] = (double)(x >> 11) * (2.0 / 9007199254740992.0) - 1.0;
+}
+
+// warm start: first k0 columns of Q <- rows of V0 (k0 x ldv)
+__global__ void subspace_seed_kernel(double *__restrict__ Q, int n, int64_t ldq, const double *__restrict__ V0,
+                                     int k0, int64_t ldv) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = blockIdx.y;
+    if (j < k0) Q[(int64_t)i * ldq + j] = V0 ? V0[(int64_t)j * ldv + i] : (i == j ? 1.0 : 0.0);
+}
+
+// Diagonal block of the blocked Cholesky: factors H[j0:j0+nb, j0:j0+nb] = R_JJ^T R_JJ (one wave, block
+// padded to 32 x 32 with an identity tail so that every loop is static), stores R_JJ into Rm and
+// its inverse (upper, leading dim kCB) into Dinv.  A pivot that has lost more than ~13 digits
+// against the column's original squared norm (origdiag, captured at j0 == 0) marks a numerically
+// dependent basis column: it gets R_jj = 1 and a ZERO column in Dinv, so the panel row and the
+// resulting Q column are exactly zero (the subspace simply shrinks by one) instead of NaN/garbage.
+constexpr int kCB = 32;
+__global__ __launch_bounds__(64) void chol_diag_kernel(const double *__restrict__ H, int64_t ldh, int p, int j0,
+                                                       int nb, double *__restrict__ Rm, double *__restrict__ Dinv,
+                                                       double *__restrict__ origdiag) {
+    __shared__ double R[kCB][kCB + 1];
+    __shared__ double s_ref[kCB];
+    __shared__ int s_dead[kCB];
+    const int tid = threadIdx.x;
+    if (j0 == 0)
+        for (int i = tid; i < p; i += 64) origdiag[i] = H[(int64_t)i * ldh + i];
+    __syncthreads();
+    if (tid < kCB) s_ref[tid] = (tid < nb) ? (j0 == 0 ? H[(int64_t)tid * ldh + tid] : origdiag[j0 + tid]) : 1.0;
+    for (int e = tid; e < kCB * kCB; e += 64) {
+        const int r = e >> 5, c = e & 31;
+        double v = (r == c) ? 1.0 : 0.0;
+        if (r < nb && c < nb) v = (c >= r) ? H[(int64_t)(j0 + r) * ldh + j0 + c] : 0.0;
+        R[r][c] = v;
+    }
+    if (tid < kCB) s_dead[tid] = 0;
+    __syncthreads();
+    const int r = tid & 31, ch = tid >> 5;  // trailing update: row r, column half ch
+    for (int j = 0; j < kCB; ++j) {
+        const double d = R[j][j];
+        const double ref = s_ref[j];
+        const bool dead = !(d > ref * 1e-13);
+        const double piv = dead ? 1.0 : sqrt(d);
+        __syncthreads();
+        if (tid < kCB && tid >= j) R[j][tid] = (tid == j) ? piv : (dead ? 0.0 : R[j][tid] / piv);
+        if (tid == 0 && dead) s_dead[j] = 1;
+        __syncthreads();
+        if (!dead && r > j) {
+            const double rj = R[j][r];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int c = ch * 16 + q;
+                if (c >= r) R[r][c] -= rj * R[j][c];
+            }
+        }
+    }
+    __syncthreads();
+    // inverse: thread c holds column c of X = R^-1 in registers (static indices), back substitution
+    if (tid < kCB) {
+        const int c = tid;
+        double x[kCB];
+#pragma unroll
+        for (int i = kCB - 1; i >= 0; --i) {
+            double sum = (i == c) ? 1.0 : 0.0;
+#pragma unroll
+            for (int t = i + 1; t < kCB; ++t) sum -= R[i][t] * x[t];
+            x[i] = (i <= c) ? sum / R[i][i] : 0.0;
+        }
+        const bool dead_c = s_dead[c] != 0;
+#pragma unroll
+        for (int i = 0; i < kCB; ++i) Dinv[i * kCB + c] = (dead_c || i >= nb || c >= nb) ? 0.0 : x[i];
+    }
+    for (int e = tid; e < kCB * kCB; e += 64) {
+        const int rr = e >> 5, c = e & 31;
+        if (rr < nb && c < nb) Rm[(int64_t)(j0 + rr) * ldh + j0 + c] = (c >= rr) ? R[rr][c] : 0.0;
+    }
+}
+
+// Qout <- orth(Y) by CholeskyQR with a blocked (32-wide) factorisation whose panel / trailing / back-
+// substitution steps are float64 GEMMs:  H = Y^T Y = R^T R,  Qout = Y R^-1.   Y is used as scratch.
+static int cholqr(SubspaceWorkspace &ws, double *Y, double *Qout, int n, int p, hipStream_t stream) {
+    const int64_t ld = ws.pp;
+    double *H = ws.H, *Rm = ws.Rm;
+    gemm_f64(p, p, n, Y, 1, ld, Y, ld, 1, H, ld, stream);  // H = Y^T Y
+    for (int j0 = 0, J = 0; j0 < p; j0 += kCB, ++J) {
+        const int nb = (p - j0 < kCB) ? p - j0 : kCB;
+        const int j1 = j0 + nb, rem = p - j1;
+        double *Dinv = ws.Dinv + (size_t)J * kCB * kCB;
+        hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(64), 0, stream, H, ld, p, j0, nb, Rm, Dinv, ws.theta + 2 * ws.pp);
+        if (rem > 0) {
+            // panel  R[J, rest] = R_JJ^-T H[J, rest]
+            gemm_f64(nb, rem, nb, Dinv, 1, kCB, H + (int64_t)j0 * ld + j1, ld, 1, Rm + (int64_t)j0 * ld + j1, ld, stream);
+            // trailing  H[rest, rest] -= R[J, rest]^T R[J, rest]
+            gemm_f64(rem, rem, nb, Rm + (int64_t)j0 * ld + j1, 1, ld, Rm + (int64_t)j0 * ld + j1, ld, 1,
+                     H + (int64_t)j1 * ld + j1, ld, stream, -1.0, 1.0);
+        }
+        // column block J of Q:  (Y_J - Q_{<J} R[<J, J]) R_JJ^-1
+        if (j0 > 0)
+            gemm_f64(n, nb, j0, Qout, ld, 1, Rm + j0, ld, 1, Y + j0, ld, stream, -1.0, 1.0);
+        gemm_f64(n, nb, nb, Y + j0, ld, 1, Dinv, kCB, 1, Qout + j0, ld, stream);
+    }
+    GS_HIP_CHECK(hipGetLastError());
+    return GS_OK;
+}
+
+// Ritz data from the Jacobi output on B: column j of Wb = theta_j u_j (norms = theta^2).  U[:, rank] sorted.
+__global__ void ritz_vectors_kernel(const double *__restrict__ Wb, int64_t ldw, const double *__restrict__ norms,
+                                    const int *__restrict__ rank, int p, double *__restrict__ U, int64_t ldu,
+                                    double *__restrict__ theta) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = blockIdx.y;
+    if (t >= p) return;
+    const double n2 = norms[j];
+    const double inv = n2 > 0 ? 1.0 / sqrt(n2) : 0.0;
+    const int r = rank[j];
+    U[(int64_t)t * ldu + r] = Wb[(int64_t)j * ldw + t] * inv;
+    if (t == 0) theta[r] = sqrt(n2);
+}
+
+// resid[i] = || Y U_i - theta_i V_i ||^2 for i < k   (YU, V: n x k)
+__global__ __launch_bounds__(256) void resid_kernel(const double *__restrict__ YU, const double *__restrict__ V,
+                                                    int64_t ld, const double *__restrict__ theta, int n, int k,
+                                                    double *__restrict__ resid) {
+    __shared__ double scr[256];
+    const int i = blockIdx.x;
+    double s = 0;
+    for (int r = threadIdx.x; r < n; r += 256) {
+        const double v = YU[(int64_t)r * ld + i] - theta[i] * V[(int64_t)r * ld + i];
+        s += v * v;
+    }
+    scr[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) scr[threadIdx.x] += scr[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) resid[i] = scr[0];
+}
+
+// Vk[i][:] (k x ldv rows) <- column i of V (n x ld); lam[i] = theta[i]
+__global__ void emit_rows_kernel(const double *__restrict__ V, int64_t ld, const double *__restrict__ theta, int n,
+                                 int k, double *__restrict__ Vk, int64_t ldv, double *__restrict__ lam) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = blockIdx.y;
+    if (e < n) Vk[(int64_t)i * ldv + e] = V[(int64_t)e * ld + i];
+    if (e == 0) lam[i] = theta[i];
+}
+
+int subspace_workspace_alloc(SubspaceWorkspace &ws, int n, int p) {
+    subspace_workspace_free(ws);
+    ws.n_cap = n;
+    ws.p_cap = p;
+    ws.pp = (int)round_up(p, 16);
+    auto alloc = [&](double **ptr, size_t count) -> int {
+        if (hipMalloc((void **)ptr, sizeof(double) * count) != hipSuccess) {
+            set_error("subspace: hipMalloc failed");
+            return GS_ENOMEM;
+        }
+        return GS_OK;
+    };
+    int rc = GS_OK;
+    const size_t np = (size_t)n * ws.pp, ppp = (size_t)ws.pp * ws.pp;
+    if (rc == GS_OK) rc = alloc(&ws.Q, np);
+    if (rc == GS_OK) rc = alloc(&ws.Y, np);
+    if (rc == GS_OK) rc = alloc(&ws.Z, np);
+    if (rc == GS_OK) rc = alloc(&ws.R, np);
+    if (rc == GS_OK) rc = alloc(&ws.H, ppp);
+    if (rc == GS_OK) rc = alloc(&ws.B, ppp);
+    if (rc == GS_OK) rc = alloc(&ws.U, ppp);
+    if (rc == GS_OK) rc = alloc(&ws.theta, 2 * (size_t)ws.pp + 8);
+    if (rc == GS_OK) rc = alloc(&ws.Rm, ppp);
+    if (rc == GS_OK) rc = alloc(&ws.Dinv, (size_t)(ws.pp / 16 + 1) * kCB * kCB);
+    if (rc == GS_OK && hipMemset(ws.Rm, 0, sizeof(double) * ppp) != hipSuccess) rc = GS_EHIP;
+    if (rc == GS_OK) rc = eigh_workspace_alloc(ws.ews, ws.pp + 2);
+    return rc;
+}
+
+void subspace_workspace_free(SubspaceWorkspace &ws) {
+    double *ptrs[] = {ws.Q, ws.Y, ws.Z, ws.R, ws.H, ws.B, ws.U, ws.theta, ws.Rm, ws.Dinv};
+    for (double *p : ptrs)
+        if (p) (void)hipFree(p);
+    eigh_workspace_free(ws.ews);
+    ws = SubspaceWorkspace();
+}
+
+int subspace_dim(int n, int k) {
+    int p = k + (k > 48 ? k : 48);
+    p = (int)round_up(p, 16);
+    // the subspace must stay well below n for the iteration to pay off
+    if (p > 256 || 2 * p > n) return 0;
+    return p;
+}
+
+// Top-k eigenpairs of the symmetric PSD matrix A (n x n, leading dim lda): Vk rows (k x ldv, unit norm, sign
+// arbitrary), lam[k] descending.  V0 (k0 rows) optionally seeds the subspace.  Returns GS_OK with
+// *converged = 0 when the residual target was missed (the caller then uses the full Jacobi solver).
+int eigh_topk_subspace(SubspaceWorkspace &ws, const double *A, int n, int64_t lda, int k, const double *V0, int k0,
+                       int64_t ldv0, double *Vk, int64_t ldv, double *lam, int *iters_out, int *converged,
+                       hipStream_t stream) {
+    const int p = subspace_dim(n, k);
+    GS_REQUIRE(p > 0 && n <= ws.n_cap && p <= ws.p_cap, GS_EINVAL, "eigh_topk_subspace: bad sizes");
+    const int64_t ld = ws.pp;
+    double *Q = ws.Q, *Y = ws.Y, *Z = ws.Z;
+    const dim3 gnp((unsigned)ceil_div(p, 64), (unsigned)n), b64(64);
+    const bool warm = (k0 > 0);   // V0 == nullptr with k0 > 0 seeds with the first k0 unit vectors
+    hipLaunchKernelGGL(subspace_init_kernel, gnp, b64, 0, stream, Y, n, p, ld, 0);
+    if (warm)
+        hipLaunchKernelGGL(subspace_seed_kernel, dim3((unsigned)ceil_div(k0, 64), (unsigned)n), b64, 0, stream, Y, n,
+                           ld, V0, k0, ldv0);
+    int rc = cholqr(ws, Y, Q, n, p, stream);
+    if (rc != GS_OK) return rc;
+
+    const int max_mults = 200;
+    // target: ||A v - theta v|| <= 1e-10 theta_1 for the k wanted pairs.  The angle error is residual / gap and
+    // the PCA output is float32, so this is ~3 digits beyond what the caller can observe.
+    const double tol2 = 1e-20;
+    int mults = 0, next_rr = warm ? 4 : 12;
+    *converged = 0;
+    std::vector<double> host(k + 1);
+    while (true) {
+        // multiply by A until the next Rayleigh-Ritz step, re-orthonormalising every 2 products (steep
+        // spectra - lambda_1/lambda_p up to ~1e7 in the fixtures - lose the trailing basis columns otherwise)
+        int since_orth = 0;
+        while (mults < next_rr) {
+            gemm_f64(n, p, n, A, lda, 1, Q, ld, 1, Y, ld, stream);
+            std::swap(Q, Y);
+            ++mults;
+            if (++since_orth == 2 && mults < next_rr) {
+                rc = cholqr(ws, Q, Y, n, p, stream);
+                if (rc != GS_OK) return rc;
+                std::swap(Q, Y);
+                since_orth = 0;
+            }
+        }
+        // CholeskyQR2 before projecting
+        rc = cholqr(ws, Q, Y, n, p, stream);
+        if (rc == GS_OK) rc = cholqr(ws, Y, Q, n, p, stream);
+        if (rc != GS_OK) return rc;
+
+        // ---- Rayleigh-Ritz on span(Q) -------------------------------------------------------------
+        gemm_f64(n, p, n, A, lda, 1, Q, ld, 1, Y, ld, stream);    // Y = A Q
+        gemm_f64(p, p, n, Q, 1, ld, Y, ld, 1, ws.B, ld, stream);  // B = Q^T Y
+        int sweeps = 0;
+        rc = eigh_jacobi(ws.ews, ws.B, p, ld, &sweeps, stream);   // columns of B -> theta_j u_j
+        if (rc == GS_OK) rc = rank_columns(ws.ews, p, stream);
+        if (rc != GS_OK) return rc;
+        hipLaunchKernelGGL(ritz_vectors_kernel, dim3((unsigned)ceil_div(p, 64), (unsigned)p), b64, 0, stream, ws.B,
+                           ld, ws.ews.norms, ws.ews.rank, p, ws.U, ld, ws.theta);
+        gemm_f64(n, p, p, Q, ld, 1, ws.U, ld, 1, Z, ld, stream);     // Z = Q U  : Ritz vectors (all p)
+        gemm_f64(n, k, p, Y, ld, 1, ws.U, ld, 1, ws.R, ld, stream);  // R = (A Q) U_k
+        hipLaunchKernelGGL(resid_kernel, dim3((unsigned)k), dim3(256), 0, stream, ws.R, Z, ld, ws.theta, n, k,
+                           ws.theta + ws.pp);
+        GS_HIP_CHECK(hipMemcpyAsync(host.data(), ws.theta + ws.pp, sizeof(double) * k, hipMemcpyDeviceToHost, stream));
+        GS_HIP_CHECK(hipMemcpyAsync(host.data() + k, ws.theta, sizeof(double), hipMemcpyDeviceToHost, stream));
+        GS_HIP_CHECK(hipStreamSynchronize(stream));
+        double worst = 0;
+        for (int i = 0; i < k; ++i) worst = worst > host[i] ? worst : host[i];
+        const double th1 = host[k];
+        const bool ok = worst <= tol2 * th1 * th1;
+        if (ok || mults >= max_mults) {
+            *converged = ok ? 1 : 0;
+            hipLaunchKernelGGL(emit_rows_kernel, dim3((unsigned)ceil_div(n, 256), (unsigned)k), dim3(256), 0, stream,
+                               Z, ld, ws.theta, n, k, Vk, ldv, lam);
+            GS_HIP_CHECK(hipGetLastError());
+            break;
+        }
+        std::swap(Q, Z);  // continue from the Ritz basis (B stays nearly diagonal: warm Jacobi next time)
+        next_rr = mults + 4;
+        if (next_rr > max_mults) next_rr = max_mults;
+    }
+    if (iters_out) *iters_out = mults;
+    return GS_OK;
+}
+
+}  // namespace gs

@@ -105,6 +105,8 @@ int gs_ipca_finalize(gs_ipca_t *h, float *components_host, double *singular_valu
 
 /* Jacobi sweeps used by the most recent eigensolve of this handle (diagnostic). */
 int gs_ipca_last_sweeps(const gs_ipca_t *h);
+/* Multiplications by A used by the most recent top-k subspace solve (0 = the full Jacobi solver ran). */
+int gs_ipca_last_mults(const gs_ipca_t *h);
 
 /* Device-resident results of the last finalize/block close (float32 [k*d] components,
  * float32 [d] mean) for projection without a host round trip.                            */
