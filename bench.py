@@ -66,6 +66,7 @@ def main():
     ap.add_argument("--mode", default="exact", choices=["exact", "faithful"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-blocks", type=int, default=16)
+    ap.add_argument("--no-wide", action="store_true", help="skip the cfg3/cfg5-shape small-side timings")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -217,6 +218,28 @@ def main():
                 cos[mode]["samples_per_s"] = round(nb * NB / (time.perf_counter() - t0), 1)
         out["cos_sim_vs_reference"] = cos
         out["vs_cpu_baseline"] = round(value / out["cpu_baseline"]["value"], 1)
+
+    # ---- the wide-feature BASELINE shapes (cfg3 d = 32 768, cfg5 d = 131 072; NB = 2 000, k = 80): PCA-only
+    #      throughput of the small-side recurrence on synthetic low-rank-plus-noise device buffers -----------
+    if rank == 0 and world == 1 and not args.no_wide:
+        wide = {}
+        for name, dd in (("cfg3_shape_d32768", 32768), ("cfg5_shape_d131072", 131072)):
+            g = torch.Generator(device=dev).manual_seed(7)
+            A = torch.randn(128, dd, device=dev, generator=g) * (1.03 ** -torch.arange(128, device=dev))[:, None]
+            e = IPCAEstimator(K_COMP, "faithful")
+            ts = []
+            for i in range(4):
+                X = torch.randn(2000, 128, device=dev, generator=g) @ A + 0.05 * torch.randn(2000, dd, device=dev, generator=g) + 0.3
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                e.fit_partial(X)
+                torch.cuda.synchronize()
+                ts.append(time.perf_counter() - t0)
+            steady = sum(ts[1:]) / len(ts[1:])
+            wide[name] = {"block_rows": 2000, "ms_per_block": round(steady * 1e3, 2),
+                          "samples_per_s": round(2000 / steady, 1), "mode": "ipca (small-side, sklearn-faithful)"}
+            del e, A
+        out["wide_feature_shapes"] = wide
 
     if rank == 0:
         print(json.dumps(out), flush=True)

@@ -21,85 +21,136 @@
 
 namespace gs {
 
-constexpr int kTM = 64, kTN = 64, kTK = 16;
+constexpr int kTK = 16;
 
-// C[M x N] (row-major, ldc) = sum_t A(i,t) B(t,j) with arbitrary element strides, float64 VALU FMAs
-// (the f64 vector and matrix peaks coincide on gfx950).  64 x 64 x 16 tiles, 4 x 4 micro-tiles.
+// C[M x N] (row-major, ldc) = beta C + alpha sum_t A(i,t) B(t,j) with arbitrary element strides, float64
+// VALU FMAs (the f64 vector and matrix peaks coincide on gfx950).  TM x TN x 16 tiles (64 x 64 with
+// 4 x 4 micro-tiles, or 32 x 32 with 2 x 2 for small outputs), next tile prefetched into registers
+// while the current one is multiplied, optional split-K over blockIdx.z (atomic float64 epilogue on a
+// pre-zeroed C).  The products here are small (n <= 4096, p <= 256): the kernel is tuned for launch
+// latency and CU coverage, not for peak.
+template <int TM, int TN>
 __global__ __launch_bounds__(256) void gemm_f64_kernel(int M, int N, int K, const double *__restrict__ A,
                                                        int64_t a_i, int64_t a_t, const double *__restrict__ B,
                                                        int64_t b_t, int64_t b_j, double *__restrict__ C,
-                                                       int64_t ldc, double alpha, double beta) {
-    __shared__ double As[kTK][kTM + 1];
-    __shared__ double Bs[kTK][kTN + 1];
+                                                       int64_t ldc, double alpha, double beta, int kchunk) {
+    constexpr int RM = TM / 16, RN = TN / 16;            // micro-tile
+    constexpr int EA = TM * kTK / 256, EB = TN * kTK / 256;  // elements staged per thread
+    __shared__ double As[kTK][TM + 1];
+    __shared__ double Bs[kTK][TN + 1];
     const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
-    const int i0 = blockIdx.y * kTM, j0 = blockIdx.x * kTN;
-    double acc[4][4];
+    const int i0 = blockIdx.y * TM, j0 = blockIdx.x * TN;
+    const int kb = blockIdx.z * kchunk;
+    const int ke = (kb + kchunk < K) ? kb + kchunk : K;
+    double acc[RM][RN];
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
+    for (int r = 0; r < RM; ++r)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) acc[r][c] = 0.0;
+        for (int c = 0; c < RN; ++c) acc[r][c] = 0.0;
     const bool a_t_fast = (a_t == 1), b_j_fast = (b_j == 1);
-    for (int k0 = 0; k0 < K; k0 += kTK) {
+    double ra[EA], rb[EB];
+    auto fetch = [&](int k0) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < EA; ++q) {
             const int e = tid + 256 * q;
-            int i, t;
-            if (a_t_fast) {
-                t = e % kTK;
-                i = e / kTK;
-            } else {
-                i = e % kTM;
-                t = e / kTM;
-            }
+            const int t = a_t_fast ? (e & (kTK - 1)) : (e / TM);
+            const int i = a_t_fast ? (e / kTK) : (e & (TM - 1));
             const int gi = i0 + i, gt = k0 + t;
-            As[t][i] = (gi < M && gt < K) ? A[gi * a_i + gt * a_t] : 0.0;
-            int j, t2;
-            if (b_j_fast) {
-                j = e % kTN;
-                t2 = e / kTN;
-            } else {
-                t2 = e % kTK;
-                j = e / kTK;
-            }
-            const int gj = j0 + j, gt2 = k0 + t2;
-            Bs[t2][j] = (gj < N && gt2 < K) ? B[gt2 * b_t + gj * b_j] : 0.0;
+            ra[q] = (gi < M && gt < ke) ? A[gi * a_i + gt * a_t] : 0.0;
         }
+#pragma unroll
+        for (int q = 0; q < EB; ++q) {
+            const int e = tid + 256 * q;
+            const int j = b_j_fast ? (e & (TN - 1)) : (e / kTK);
+            const int t = b_j_fast ? (e / TN) : (e & (kTK - 1));
+            const int gj = j0 + j, gt = k0 + t;
+            rb[q] = (gj < N && gt < ke) ? B[gt * b_t + gj * b_j] : 0.0;
+        }
+    };
+    auto stash = [&]() {
+#pragma unroll
+        for (int q = 0; q < EA; ++q) {
+            const int e = tid + 256 * q;
+            const int t = a_t_fast ? (e & (kTK - 1)) : (e / TM);
+            const int i = a_t_fast ? (e / kTK) : (e & (TM - 1));
+            As[t][i] = ra[q];
+        }
+#pragma unroll
+        for (int q = 0; q < EB; ++q) {
+            const int e = tid + 256 * q;
+            const int j = b_j_fast ? (e & (TN - 1)) : (e / kTK);
+            const int t = b_j_fast ? (e / TN) : (e & (kTK - 1));
+            Bs[t][j] = rb[q];
+        }
+    };
+    if (kb < ke) fetch(kb);
+    for (int k0 = kb; k0 < ke; k0 += kTK) {
+        stash();
         __syncthreads();
+        if (k0 + kTK < ke) fetch(k0 + kTK);
 #pragma unroll
         for (int t = 0; t < kTK; ++t) {
-            double a[4], b[4];
+            double a[RM], b[RN];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) a[r] = As[t][ty + 16 * r];
+            for (int r = 0; r < RM; ++r) a[r] = As[t][ty + 16 * r];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) b[c] = Bs[t][tx + 16 * c];
+            for (int c = 0; c < RN; ++c) b[c] = Bs[t][tx + 16 * c];
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
+            for (int r = 0; r < RM; ++r)
 #pragma unroll
-                for (int c = 0; c < 4; ++c) acc[r][c] += a[r] * b[c];
+                for (int c = 0; c < RN; ++c) acc[r][c] += a[r] * b[c];
         }
         __syncthreads();
     }
+    const bool split = gridDim.z > 1;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
+    for (int r = 0; r < RM; ++r) {
         const int gi = i0 + ty + 16 * r;
         if (gi >= M) continue;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
+        for (int c = 0; c < RN; ++c) {
             const int gj = j0 + tx + 16 * c;
             if (gj < N) {
                 double *dst = C + (int64_t)gi * ldc + gj;
-                *dst = (beta == 0.0) ? alpha * acc[r][c] : beta * *dst + alpha * acc[r][c];
+                if (split)
+                    atomicAdd(dst, alpha * acc[r][c]);
+                else
+                    *dst = (beta == 0.0) ? alpha * acc[r][c] : beta * *dst + alpha * acc[r][c];
             }
         }
     }
 }
 
+__global__ void zero_rows_kernel(double *__restrict__ C, int M, int N, int64_t ldc) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < N) C[(int64_t)blockIdx.y * ldc + j] = 0.0;
+}
+
 static void gemm_f64(int M, int N, int K, const double *A, int64_t a_i, int64_t a_t, const double *B, int64_t b_t,
                      int64_t b_j, double *C, int64_t ldc, hipStream_t stream, double alpha = 1.0, double beta = 0.0) {
     if (M <= 0 || N <= 0) return;
-    dim3 grid((unsigned)ceil_div(N, kTN), (unsigned)ceil_div(M, kTM));
-    hipLaunchKernelGGL(gemm_f64_kernel, grid, dim3(256), 0, stream, M, N, K, A, a_i, a_t, B, b_t, b_j, C, ldc, alpha,
-                       beta);
+    const bool small_tiles = ceil_div(M, 64) * ceil_div(N, 64) < 64;
+    const int TMv = small_tiles ? 32 : 64;
+    const int64_t tiles = ceil_div(M, TMv) * ceil_div(N, TMv);
+    // split K (atomic epilogue) when the output alone cannot cover the chip and K is long enough
+    int splits = 1;
+    if (beta == 0.0 && tiles < 128 && K >= 256) {
+        splits = (int)ceil_div(160, tiles);
+        if (splits > K / 64) splits = K / 64;
+        if (splits < 1) splits = 1;
+    }
+    const int kchunk = (int)round_up(ceil_div(K, splits), kTK);
+    splits = (int)ceil_div(K, kchunk);
+    if (splits > 1)
+        hipLaunchKernelGGL(zero_rows_kernel, dim3((unsigned)ceil_div(N, 256), (unsigned)M), dim3(256), 0, stream, C, M, N,
+                           ldc);
+    dim3 grid((unsigned)ceil_div(N, TMv), (unsigned)ceil_div(M, TMv), (unsigned)splits);
+    if (small_tiles)
+        hipLaunchKernelGGL((gemm_f64_kernel<32, 32>), grid, dim3(256), 0, stream, M, N, K, A, a_i, a_t, B, b_t, b_j, C,
+                           ldc, alpha, beta, kchunk);
+    else
+        hipLaunchKernelGGL((gemm_f64_kernel<64, 64>), grid, dim3(256), 0, stream, M, N, K, A, a_i, a_t, B, b_t, b_j, C,
+                           ldc, alpha, beta, kchunk);
 }
 
 // deterministic pseudo-random start: Q[i][j] in (-1, 1)
