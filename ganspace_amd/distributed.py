@@ -62,7 +62,7 @@ def allreduce_state(state, d, group=None):
     """In-place global merge of every rank's exported state (two sum all-reduces)."""
     import torch
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return state
     hdr = torch.cat([state[:1], state[0] * state[1:1 + d]])
     dist.all_reduce(hdr, op=dist.ReduceOp.SUM, group=group)

@@ -66,6 +66,21 @@ def test_allreduce_state_world_size_2_gloo(tmp_path):
         np.testing.assert_allclose(got, full, rtol=1e-10, atol=1e-9)
 
 
+def _worker_single(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    st = _state_of(_data([321], seed=9)[0])
+    ref = st.clone()
+    D.allreduce_state(st, 24)
+    np.save(os.path.join(out_dir, "single.npy"), (st - ref).abs().max().numpy())
+    dist.destroy_process_group()
+
+
+def test_allreduce_with_one_rank_is_a_fixed_point(tmp_path):
+    mp.spawn(_worker_single, args=(1, _free_port(), str(tmp_path)), nprocs=1, join=True)
+    assert float(np.load(tmp_path / "single.npy")) < 1e-9
+
+
 def test_allreduce_is_identity_without_process_group():
     st = _state_of(_data([50])[0])
     assert D.allreduce_state(st.clone(), 24).equal(st)

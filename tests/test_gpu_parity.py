@@ -327,3 +327,31 @@ def test_full_size_block_properties(dev):
     np.testing.assert_allclose(t.var_ * n, torch.diag(Cc).cpu().numpy(), rtol=1e-5)
     assert abs(float(np.sum(t.explained_variance_ratio_)) - (lam.sum() / torch.trace(Cc)).item()) < 1e-6
     assert int(t.n_samples_seen_) == n
+
+
+def test_nccl_single_rank_allreduce_of_estimator_state(dev):
+    """The RCCL path with one rank (all a 1-GPU box can run): export -> two all-reduces -> re-centre
+    (HIP kernel) -> import must leave the fitted result unchanged."""
+    import torch.distributed as dist
+    from ganspace_amd import distributed as D
+    from ganspace_amd.estimators import IPCAEstimator
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29577")
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        created = True
+    try:
+        case = gin.IPCA_CASES["d512_k20"]
+        est = IPCAEstimator(case["k"], "exact")
+        for X in gin.ipca_blocks(case):
+            est.fit_partial(torch.from_numpy(X).to(dev))
+        before = est.transformer.components_.copy()
+        sv = est.transformer.singular_values_.copy()
+        D.allreduce_estimator(est)
+        cos = O.signed_cosines(est.transformer.components_, before)
+        assert cos.min() > 1 - 1e-9
+        np.testing.assert_allclose(est.transformer.singular_values_, sv, rtol=2e-6)
+    finally:
+        if created:
+            dist.destroy_process_group()
