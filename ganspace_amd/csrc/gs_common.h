@@ -36,10 +36,16 @@ constexpr int kWaveTile = 64;
 constexpr int kSubTile = 32;     // granularity of the valid (upper-triangle) region of slabs / G64
 
 struct GramWorkspace {
-    float *partial = nullptr;      // [chunks][dp][dp] f32 per-chunk partial Grams (upper 32x32 sub-tiles)
-    float *colsum_partial = nullptr;  // [chunks][dp]
+    // two slab sets: while one launch fills set `cur`, its spare workgroups (the CUs the compute tiles leave
+    // idle) fold the previous launch's set into the float64 accumulators
+    float *partial[2] = {nullptr, nullptr};         // [chunks][dp][dp] f32 partial Grams (upper 32x32 sub-tiles)
+    float *colsum_partial[2] = {nullptr, nullptr};  // [chunks][dp]
     int64_t dp = 0;                // d rounded up to kMacroTile
     int max_chunks = 0;
+    int cur = 0;
+    bool pend_valid = false;       // a slab set still waits to be folded
+    int pend_buf = 0, pend_nchunks = 0;
+    bool pend_acc = false;         // fold adds to (true) or overwrites (false) the accumulators
 };
 
 int gram_workspace_alloc(GramWorkspace &ws, int64_t d);
@@ -48,11 +54,14 @@ void gram_workspace_free(GramWorkspace &ws);
 // Launch colsum+Gram partials for X[rows, ld] and fold them in float64 into
 // G64 (upper 32x32 sub-tiles of a [dp][dp] row-major array) and S1[dp].
 // accumulate=false overwrites G64/S1 instead of adding.
-int gram_update(const GramWorkspace &ws, const float *X, int64_t rows, int64_t ld, int64_t d,
-                const float *shift, double *G64, double *S1, bool accumulate, hipStream_t stream);
+// defer = true leaves the fold of this launch's slabs to the NEXT launch (or to gram_flush).
+int gram_update(GramWorkspace &ws, const float *X, int64_t rows, int64_t ld, int64_t d, const float *shift,
+                double *G64, double *S1, bool accumulate, bool defer, hipStream_t stream);
+// fold whatever is still pending into G64 / S1
+int gram_flush(GramWorkspace &ws, double *G64, double *S1, hipStream_t stream);
 
 // average duration of the partial-Gram kernel alone (HIP events on `stream`)
-int gram_partial_time(const GramWorkspace &ws, const float *X, int64_t rows, int64_t ld, int64_t d,
+int gram_partial_time(GramWorkspace &ws, const float *X, int64_t rows, int64_t ld, int64_t d,
                       const float *shift, int iters, float *avg_ms, hipStream_t stream);
 
 // column means of X[rows, ld] -> out[dp] f32 (padded columns zero)

@@ -235,13 +235,86 @@ __device__ __forceinline__ void gram_tile(const GramTileCtx &c, float (*lds)[2][
     }
 }
 
+// Fold `nchunks` float32 slabs into the float64 accumulators: element e of the upper 32x32 sub-tiles
+// (then the dp column sums), grid-stride over `nworkers` workgroups of `nthreads`.
+__device__ __forceinline__ void fold_elements(const float *__restrict__ P, const float *__restrict__ CS,
+                                              double *__restrict__ G64, double *__restrict__ S1, int dp, int nchunks,
+                                              int T32, int ntiles, int accumulate, int worker, int nworkers,
+                                              int nthreads) {
+    // work item = 4 consecutive elements of a sub-tile row (one float4 per chunk, 8 chunks in flight)
+    const int64_t stride = (int64_t)dp * dp;
+    const int ngroups = ntiles * 256;
+    const int total = ngroups + dp;
+    for (int e = worker * nthreads + threadIdx.x; e < total; e += nworkers * nthreads) {
+        if (e < ngroups) {
+            int ti, tj;
+            decode_upper(e >> 8, T32, ti, tj);
+            const int w = e & 255;
+            const int64_t off = (int64_t)(ti * kSubTile + (w >> 3)) * dp + tj * kSubTile + (w & 7) * 4;
+            double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+            int c = 0;
+            for (; c + 8 <= nchunks; c += 8) {
+                float4 v[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] = *reinterpret_cast<const float4 *>(P + (c + q) * stride + off);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    s0 += v[q].x;
+                    s1 += v[q].y;
+                    s2 += v[q].z;
+                    s3 += v[q].w;
+                }
+            }
+            for (; c < nchunks; ++c) {
+                const float4 v = *reinterpret_cast<const float4 *>(P + c * stride + off);
+                s0 += v.x;
+                s1 += v.y;
+                s2 += v.z;
+                s3 += v.w;
+            }
+            double *g = G64 + off;
+            if (accumulate) {
+                g[0] += s0;
+                g[1] += s1;
+                g[2] += s2;
+                g[3] += s3;
+            } else {
+                g[0] = s0;
+                g[1] = s1;
+                g[2] = s2;
+                g[3] = s3;
+            }
+        } else {
+            const int col = e - ngroups;
+            double s = 0;
+            for (int c = 0; c < nchunks; ++c) s += CS[(int64_t)c * dp + col];
+            if (accumulate)
+                S1[col] += s;
+            else
+                S1[col] = s;
+        }
+    }
+}
+
+struct FoldJob {
+    const float *P, *CS;  // previous launch's slabs (nullptr: nothing to fold)
+    double *G64, *S1;
+    int nchunks, T32, ntiles, accumulate;
+};
+
 template <bool VEC>
 __global__ __launch_bounds__(kThreads, 1) void gram_partial_kernel(
     const float *__restrict__ X, int64_t rows, int64_t ld, int d, const float *__restrict__ shift,
     float *__restrict__ P, float *__restrict__ CS, int dp, int nchunks, int64_t chunk_rows, int nmt,
-    int T, int ablate) {
+    int T, int ablate, int ncompute, FoldJob fold) {
     __shared__ __attribute__((aligned(16))) float lds[2][2][kKB][kMacroTile];  // 128 KiB
 
+    if ((int)blockIdx.x >= ncompute) {
+        // spare workgroups (they land on the CUs the compute tiles leave idle): fold the PREVIOUS launch's slabs
+        fold_elements(fold.P, fold.CS, fold.G64, fold.S1, dp, fold.nchunks, fold.T32, fold.ntiles, fold.accumulate,
+                      (int)blockIdx.x - ncompute, (int)gridDim.x - ncompute, kThreads);
+        return;
+    }
     const int b = blockIdx.x;
     const int xcd = b & 7, local = b >> 3;
     GramTileCtx c;
@@ -264,51 +337,13 @@ __global__ __launch_bounds__(kThreads, 1) void gram_partial_kernel(
         gram_tile<VEC, false>(c, lds);
 }
 
-// Fold the per-chunk float32 slabs into the float64 accumulators (upper 32x32 sub-tiles; T64 here
-// is the number of 32-wide sub-tiles per side).
-// One thread per output element (147 k threads at d = 512) so that the ~15 MB of slab reads are
-// spread over every CU with many independent loads in flight; lanes walk a tile row (coalesced).
+// Stand-alone fold (faithful mode needs the block's Gram immediately; also the final flush).
 __global__ __launch_bounds__(256) void gram_fold_kernel(const float *__restrict__ P,
                                                         const float *__restrict__ CS,
                                                         double *__restrict__ G64,
                                                         double *__restrict__ S1, int dp, int nchunks,
-                                                        int T64, int ntiles, int accumulate) {
-    const int bid = blockIdx.x;
-    const int tid = threadIdx.x;
-    if (bid < ntiles * 4) {
-        int ti, tj;
-        decode_upper(bid >> 2, T64, ti, tj);
-        const int e = (bid & 3) * 256 + tid;
-        const int row = ti * kSubTile + (e >> 5), col = tj * kSubTile + (e & 31);
-        const int64_t off = (int64_t)row * dp + col;
-        const int64_t stride = (int64_t)dp * dp;
-        double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-        int c = 0;
-        for (; c + 4 <= nchunks; c += 4) {
-            const float v0 = P[(c + 0) * stride + off], v1 = P[(c + 1) * stride + off];
-            const float v2 = P[(c + 2) * stride + off], v3 = P[(c + 3) * stride + off];
-            s0 += v0;
-            s1 += v1;
-            s2 += v2;
-            s3 += v3;
-        }
-        for (; c < nchunks; ++c) s0 += P[c * stride + off];
-        const double s = (s0 + s1) + (s2 + s3);
-        if (accumulate)
-            G64[off] += s;
-        else
-            G64[off] = s;
-    } else {
-        const int col = (bid - ntiles * 4) * 256 + tid;
-        if (col < dp) {
-            double s = 0;
-            for (int c = 0; c < nchunks; ++c) s += CS[(int64_t)c * dp + col];
-            if (accumulate)
-                S1[col] += s;
-            else
-                S1[col] = s;
-        }
-    }
+                                                        int T32, int ntiles, int accumulate) {
+    fold_elements(P, CS, G64, S1, dp, nchunks, T32, ntiles, accumulate, (int)blockIdx.x, (int)gridDim.x, 256);
 }
 
 int gram_workspace_alloc(GramWorkspace &ws, int64_t d) {
@@ -319,14 +354,18 @@ int gram_workspace_alloc(GramWorkspace &ws, int64_t d) {
     if (mc > 64) mc = 64;
     if (mc < 8) mc = 8;
     ws.max_chunks = (int)mc;
-    GS_HIP_CHECK(hipMalloc(&ws.partial, sizeof(float) * ws.max_chunks * ws.dp * ws.dp));
-    GS_HIP_CHECK(hipMalloc(&ws.colsum_partial, sizeof(float) * ws.max_chunks * ws.dp));
+    for (int i = 0; i < 2; ++i) {
+        GS_HIP_CHECK(hipMalloc(&ws.partial[i], sizeof(float) * ws.max_chunks * ws.dp * ws.dp));
+        GS_HIP_CHECK(hipMalloc(&ws.colsum_partial[i], sizeof(float) * ws.max_chunks * ws.dp));
+    }
     return GS_OK;
 }
 
 void gram_workspace_free(GramWorkspace &ws) {
-    if (ws.partial) (void)hipFree(ws.partial);
-    if (ws.colsum_partial) (void)hipFree(ws.colsum_partial);
+    for (int i = 0; i < 2; ++i) {
+        if (ws.partial[i]) (void)hipFree(ws.partial[i]);
+        if (ws.colsum_partial[i]) (void)hipFree(ws.colsum_partial[i]);
+    }
     ws = GramWorkspace();
 }
 
@@ -360,55 +399,95 @@ static GramGeom gram_geometry(const GramWorkspace &ws, int64_t n) {
     return g;
 }
 
-static void launch_partial(const GramWorkspace &ws, const GramGeom &g, const float *Xb, int64_t n, int64_t ld,
-                           int64_t d, const float *shift, hipStream_t stream) {
+static void launch_partial(const GramWorkspace &ws, const GramGeom &g, int buf, const float *Xb, int64_t n,
+                           int64_t ld, int64_t d, const float *shift, const FoldJob &fold, hipStream_t stream) {
     const bool vec = (ld % 4 == 0) && (d % 4 == 0) && ((reinterpret_cast<uintptr_t>(Xb) & 15) == 0);
     const int dp = (int)ws.dp;
     static const int ablate = []() {
         const char *e = getenv("GS_GRAM_ABLATE");
         return e ? atoi(e) : 0;
     }();
+    // spare workgroups for the piggy-backed fold: the CUs the compute grid leaves idle (at least 8)
+    int nfold = 0;
+    if (fold.P != nullptr) {
+        nfold = 256 - g.grid % 256;
+        if (nfold < 8 || nfold > 64) nfold = 16;
+    }
+    const dim3 grid((unsigned)(g.grid + nfold));
     if (vec)
-        hipLaunchKernelGGL(gram_partial_kernel<true>, dim3(g.grid), dim3(kThreads), 0, stream, Xb, n, ld, (int)d,
-                           shift, ws.partial, ws.colsum_partial, dp, g.nchunks, g.chunk_rows, g.nmt, g.T, ablate);
+        hipLaunchKernelGGL(gram_partial_kernel<true>, grid, dim3(kThreads), 0, stream, Xb, n, ld, (int)d, shift,
+                           ws.partial[buf], ws.colsum_partial[buf], dp, g.nchunks, g.chunk_rows, g.nmt, g.T, ablate,
+                           g.grid, fold);
     else
-        hipLaunchKernelGGL(gram_partial_kernel<false>, dim3(g.grid), dim3(kThreads), 0, stream, Xb, n, ld, (int)d,
-                           shift, ws.partial, ws.colsum_partial, dp, g.nchunks, g.chunk_rows, g.nmt, g.T, ablate);
+        hipLaunchKernelGGL(gram_partial_kernel<false>, grid, dim3(kThreads), 0, stream, Xb, n, ld, (int)d, shift,
+                           ws.partial[buf], ws.colsum_partial[buf], dp, g.nchunks, g.chunk_rows, g.nmt, g.T, ablate,
+                           g.grid, fold);
 }
 
-int gram_update(const GramWorkspace &ws, const float *X, int64_t rows, int64_t ld, int64_t d,
-                const float *shift, double *G64, double *S1, bool accumulate, hipStream_t stream) {
-    if (rows <= 0) return GS_OK;
+static FoldJob pending_job(const GramWorkspace &ws, double *G64, double *S1) {
+    FoldJob f = {};
     const int dp = (int)ws.dp;
-    const int T64 = dp / kSubTile, ntiles = T64 * (T64 + 1) / 2;
-    const int64_t rows_per_launch = gram_geometry(ws, rows).rows_per_launch;
-
-    bool acc = accumulate;
-    for (int64_t base = 0; base < rows; base += rows_per_launch) {
-        const int64_t n = (rows - base < rows_per_launch) ? rows - base : rows_per_launch;
-        const GramGeom g = gram_geometry(ws, n);
-        const int nchunks = g.nchunks;
-        launch_partial(ws, g, X + base * ld, n, ld, d, shift, stream);
-        const int fold_grid = ntiles * 4 + (int)ceil_div(dp, 256);
-        hipLaunchKernelGGL(gram_fold_kernel, dim3(fold_grid), dim3(256), 0, stream, ws.partial,
-                           ws.colsum_partial, G64, S1, dp, nchunks, T64, ntiles, acc ? 1 : 0);
-        acc = true;
+    f.T32 = dp / kSubTile;
+    f.ntiles = f.T32 * (f.T32 + 1) / 2;
+    if (ws.pend_valid) {
+        f.P = ws.partial[ws.pend_buf];
+        f.CS = ws.colsum_partial[ws.pend_buf];
+        f.G64 = G64;
+        f.S1 = S1;
+        f.nchunks = ws.pend_nchunks;
+        f.accumulate = ws.pend_acc ? 1 : 0;
     }
+    return f;
+}
+
+int gram_flush(GramWorkspace &ws, double *G64, double *S1, hipStream_t stream) {
+    if (!ws.pend_valid) return GS_OK;
+    const FoldJob f = pending_job(ws, G64, S1);
+    const int grid = f.ntiles + (int)ceil_div(ws.dp, 256);
+    hipLaunchKernelGGL(gram_fold_kernel, dim3(grid), dim3(256), 0, stream, f.P, f.CS, G64, S1, (int)ws.dp, f.nchunks,
+                       f.T32, f.ntiles, f.accumulate);
+    ws.pend_valid = false;
     GS_HIP_CHECK(hipGetLastError());
     return GS_OK;
 }
 
+int gram_update(GramWorkspace &ws, const float *X, int64_t rows, int64_t ld, int64_t d, const float *shift,
+                double *G64, double *S1, bool accumulate, bool defer, hipStream_t stream) {
+    if (rows <= 0) return GS_OK;
+    const int64_t rows_per_launch = gram_geometry(ws, rows).rows_per_launch;
+    bool acc = accumulate;
+    for (int64_t base = 0; base < rows; base += rows_per_launch) {
+        const int64_t n = (rows - base < rows_per_launch) ? rows - base : rows_per_launch;
+        const GramGeom g = gram_geometry(ws, n);
+        // the previous launch's slabs are folded by this launch's spare workgroups
+        const FoldJob f = pending_job(ws, G64, S1);
+        const int buf = ws.cur;
+        launch_partial(ws, g, buf, X + base * ld, n, ld, d, shift, f, stream);
+        ws.pend_valid = true;
+        ws.pend_buf = buf;
+        ws.pend_nchunks = g.nchunks;
+        ws.pend_acc = acc;
+        ws.cur ^= 1;
+        acc = true;
+    }
+    GS_HIP_CHECK(hipGetLastError());
+    if (!defer) return gram_flush(ws, G64, S1, stream);
+    return GS_OK;
+}
+
 // Average duration (ms) of the partial-Gram kernel alone, HIP events on `stream`.
-int gram_partial_time(const GramWorkspace &ws, const float *X, int64_t rows, int64_t ld, int64_t d,
+int gram_partial_time(GramWorkspace &ws, const float *X, int64_t rows, int64_t ld, int64_t d,
                       const float *shift, int iters, float *avg_ms, hipStream_t stream) {
+    const FoldJob nofold = {};
+    const int buf = ws.pend_valid ? (ws.pend_buf ^ 1) : ws.cur;  // never clobber slabs that still wait for a fold
     const GramGeom g = gram_geometry(ws, rows);
     const int64_t n = rows < g.rows_per_launch ? rows : g.rows_per_launch;
     hipEvent_t e0, e1;
     GS_HIP_CHECK(hipEventCreate(&e0));
     GS_HIP_CHECK(hipEventCreate(&e1));
-    launch_partial(ws, g, X, n, ld, d, shift, stream);  // warm-up
+    launch_partial(ws, g, buf, X, n, ld, d, shift, nofold, stream);  // warm-up
     GS_HIP_CHECK(hipEventRecord(e0, stream));
-    for (int i = 0; i < iters; ++i) launch_partial(ws, g, X, n, ld, d, shift, stream);
+    for (int i = 0; i < iters; ++i) launch_partial(ws, g, buf, X, n, ld, d, shift, nofold, stream);
     GS_HIP_CHECK(hipEventRecord(e1, stream));
     GS_HIP_CHECK(hipEventSynchronize(e1));
     float ms = 0.f;

@@ -348,6 +348,8 @@ int solve_topk(gs_ipca *h, bool warm, const double *total_src, int total_len, hi
 
 int exact_solve(gs_ipca *h, hipStream_t stream) {
     const int d = (int)h->d, dp = (int)h->dp;
+    int rcf = gram_flush(h->gws, h->G64, h->S1, stream);
+    if (rcf != GS_OK) return rcf;
     GS_HIP_CHECK(hipMemsetAsync(h->scal, 0, sizeof(double) * 8, stream));
     hipLaunchKernelGGL(exact_assemble_kernel, dim3((unsigned)ceil_div(d, 256), (unsigned)d), dim3(256), 0,
                        stream, h->G64, h->S1, h->shift, h->W, h->mean, h->m2, h->scal, d, dp,
@@ -471,6 +473,7 @@ int gs_ipca_reset(gs_ipca_t *h) {
     h->n_seen = 0;
     h->blocks = 0;
     h->finalized = false;
+    h->gws.pend_valid = false;
     return GS_OK;
 }
 
@@ -512,7 +515,8 @@ int gs_ipca_update(gs_ipca_t *h, const float *X, int64_t rows, int64_t ld, void 
         if (rc != GS_OK) return rc;
     }
     if (h->mode == GS_MODE_EXACT) {
-        int rc = gram_update(h->gws, X, rows, ld, d, h->shift, h->G64, h->S1, h->n_seen > 0, stream);
+        // the fold of this block's slabs rides on the spare workgroups of the NEXT block's launch
+        int rc = gram_update(h->gws, X, rows, ld, d, h->shift, h->G64, h->S1, h->n_seen > 0, /*defer=*/true, stream);
         if (rc != GS_OK) return rc;
         h->n_seen += rows;
         h->blocks += 1;
@@ -520,7 +524,7 @@ int gs_ipca_update(gs_ipca_t *h, const float *X, int64_t rows, int64_t ld, void 
         return GS_OK;
     }
     // ---- FAITHFUL: close the block ---------------------------------------------------------
-    int rc = gram_update(h->gws, X, rows, ld, d, h->shift, h->G64, h->S1, false, stream);
+    int rc = gram_update(h->gws, X, rows, ld, d, h->shift, h->G64, h->S1, false, /*defer=*/false, stream);
     if (rc != GS_OK) return rc;
     const double n0 = (double)h->n_seen, m = (double)rows;
     hipLaunchKernelGGL(faithful_stats_kernel, dim3((unsigned)ceil_div(d, 256)), dim3(256), 0, stream, h->S1,
@@ -569,6 +573,7 @@ int gs_ipca_state_import(gs_ipca_t *h, const double *state, void *stream_) {
     GS_HIP_CHECK(hipMemcpyAsync(&n, state, sizeof(double), hipMemcpyDeviceToHost, stream));
     GS_HIP_CHECK(hipStreamSynchronize(stream));
     GS_REQUIRE(n >= 0 && n == std::floor(n), GS_EINVAL, "gs_ipca_state_import: bad sample count");
+    h->gws.pend_valid = false;  // the imported state replaces everything accumulated so far
     hipLaunchKernelGGL(state_import_kernel, dim3((unsigned)ceil_div(dp, 256), (unsigned)dp), dim3(256), 0,
                        stream, state, h->G64, h->S1, h->shift, d, dp);
     GS_HIP_CHECK(hipGetLastError());
@@ -666,7 +671,7 @@ int gs_gram_accumulate(const float *X, int64_t rows, int64_t ld, int64_t d, cons
     (void)hipMemsetAsync(G64, 0, sizeof(double) * dp * dp, stream);
     (void)hipMemsetAsync(S1, 0, sizeof(double) * dp, stream);
     if (shift) (void)hipMemcpyAsync(shp, shift, sizeof(float) * d, hipMemcpyDeviceToDevice, stream);
-    rc = gram_update(ws, X, rows, ld, d, shp, G64, S1, false, stream);
+    rc = gram_update(ws, X, rows, ld, d, shp, G64, S1, false, /*defer=*/false, stream);
     if (rc == GS_OK) {
         hipLaunchKernelGGL(symmetrize_out_kernel, dim3((unsigned)ceil_div(d, 256), (unsigned)d), dim3(256), 0,
                            stream, G64, G, (int)d, (int)dp, 1);
