@@ -355,3 +355,73 @@ def test_nccl_single_rank_allreduce_of_estimator_state(dev):
     finally:
         if created:
             dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("d,k,rows", [(2048, 32, 3000), (1000, 200, 2500)])
+def test_larger_feature_dims_exact_and_faithful(dev, d, k, rows):
+    """Gram-side path beyond the bench shape: more macro tiles than CUs per chunk (d = 2048) and k close
+    to the subspace-solver limit (falls back to the full Jacobi solver when 2p > d)."""
+    from ganspace_amd.estimators import IPCAEstimator
+    rs = np.random.RandomState(d)
+    A = rs.standard_normal((96, d)) * (1.07 ** -np.arange(96))[:, None]
+    blocks = [(rs.standard_normal((rows, 96)) @ A + 0.02 * rs.standard_normal((rows, d)) + 0.5).astype(np.float32)
+              for _ in range(2)]
+    ex = O.exact_pca(blocks, k)
+    est = IPCAEstimator(k, "exact")
+    for X in blocks:
+        assert est.fit_partial(torch.from_numpy(X).to(dev))
+    r = 24
+    cos = O.signed_cosines(est.transformer.components_[:r], ex["components_"][:r])
+    assert cos.min() > 1 - 1e-6, cos.min()
+    np.testing.assert_allclose(est.transformer.singular_values_[:r], ex["singular_values_"][:r], rtol=5e-5)
+    fa = IPCAEstimator(k, "faithful")
+    orc = O.IPCAEstimatorOracle(k, "gram")
+    for X in blocks:
+        assert fa.fit_partial(torch.from_numpy(X).to(dev))
+        orc.fit_partial(X)
+    cos = O.signed_cosines(fa.transformer.components_[:r], orc.transformer.components_[:r])
+    assert cos.min() > 1 - 1e-6, cos.min()
+
+
+def test_maximum_gram_side_dimension_smoke(dev):
+    """d = 8192 is the largest Gram-side feature dim (slabs + accumulators ~6 GB): shapes, orthonormality, order."""
+    from ganspace_amd.estimators import IPCAEstimator
+    g = torch.Generator(device=dev).manual_seed(3)
+    A = torch.randn(16, 8192, device=dev, generator=g) * (1.5 ** -torch.arange(16, device=dev))[:, None]
+    est = IPCAEstimator(8, "exact")
+    for _ in range(2):
+        X = torch.randn(600, 16, device=dev, generator=g) @ A + 0.01 * torch.randn(600, 8192, device=dev, generator=g)
+        assert est.fit_partial(X)
+    comp, stdev, ratio = est.get_components()
+    assert comp.shape == (8, 8192)
+    G = comp.astype(np.float64) @ comp.astype(np.float64).T
+    assert np.abs(G - np.eye(8)).max() < 1e-5
+    assert np.all(np.diff(stdev) <= 0) and 0.9 < ratio.sum() <= 1.0 + 1e-6
+
+
+def test_tiny_and_ragged_later_blocks(dev):
+    """After the first block any number of rows (even 1) is a legal partial_fit batch in sklearn."""
+    from ganspace_amd.estimators import get_estimator
+    rs = np.random.RandomState(4)
+    A = rs.standard_normal((10, 48))
+    sizes = [64, 1, 7, 130, 2]
+    blocks = [(rs.standard_normal((m, 10)) @ A + 0.1 * rs.standard_normal((m, 48))).astype(np.float32) for m in sizes]
+    est = get_estimator("ipca", 5, 1.0)
+    orc = O.IPCAEstimatorOracle(5, "svd")
+    for X in blocks:
+        assert est.fit_partial(torch.from_numpy(X).to(dev))
+        orc.fit_partial(X)
+    cos = O.signed_cosines(est.transformer.components_, orc.transformer.components_)
+    assert cos.min() > 1 - 1e-5, cos
+    np.testing.assert_allclose(est.transformer.singular_values_, orc.transformer.singular_values_, rtol=1e-4)
+    assert int(est.transformer.n_samples_seen_) == sum(sizes)
+
+
+def test_feature_count_mismatch_and_bad_k_raise(dev):
+    from ganspace_amd.estimators import get_estimator
+    est = get_estimator("ipca", 4, 1.0)
+    assert est.fit_partial(torch.randn(16, 32, device=dev))
+    with pytest.raises(ValueError):
+        est.transformer.partial_fit(torch.randn(16, 40, device=dev))      # sklearn: feature-count change
+    est2 = get_estimator("ipca", 64, 1.0)
+    assert est2.fit_partial(torch.randn(128, 32, device=dev)) is False     # k > n_features -> ValueError -> False
