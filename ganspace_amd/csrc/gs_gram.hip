@@ -145,49 +145,60 @@ __device__ __forceinline__ void gram_tile(const GramTileCtx &c, float (*lds)[2][
     float4 ra[kLoadIters], rb[kLoadIters];
     float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
 
-    auto fetch = [&](int64_t rbase) {
+    // NI row groups of 16 rows each, starting at rbase
+    auto fetch = [&](int64_t rbase, int ni) {
 #pragma unroll
         for (int i = 0; i < kLoadIters; ++i) {
-            ra[i] = load_raw<VEC>(c.X, rbase + rr + 16 * i, r1 - 1, ld, colA, d);
-            if (!DIAG) rb[i] = load_raw<VEC>(c.X, rbase + rr + 16 * i, r1 - 1, ld, colB, d);
+            if (i < ni) {
+                ra[i] = load_raw<VEC>(c.X, rbase + rr + 16 * i, r1 - 1, ld, colA, d);
+                if (!DIAG) rb[i] = load_raw<VEC>(c.X, rbase + rr + 16 * i, r1 - 1, ld, colB, d);
+            }
         }
     };
-    auto stash = [&](int buf, int64_t rbase) {
+    auto stash = [&](int buf, int64_t rbase, int ni) {
 #pragma unroll
         for (int i = 0; i < kLoadIters; ++i) {
-            const bool ok = rbase + rr + 16 * i < r1;
-            const float4 va = finish(ra[i], shA, ok, colA, d);
-            *reinterpret_cast<float4 *>(&lds[buf][0][rr + 16 * i][c4 * 4]) = va;
-            if (!DIAG) {
-                const float4 vb = finish(rb[i], shB, ok, colB, d);
-                *reinterpret_cast<float4 *>(&lds[buf][1][rr + 16 * i][c4 * 4]) = vb;
-            } else {
-                cs.x += va.x;
-                cs.y += va.y;
-                cs.z += va.z;
-                cs.w += va.w;
+            if (i < ni) {
+                const bool ok = rbase + rr + 16 * i < r1;
+                const float4 va = finish(ra[i], shA, ok, colA, d);
+                *reinterpret_cast<float4 *>(&lds[buf][0][rr + 16 * i][c4 * 4]) = va;
+                if (!DIAG) {
+                    const float4 vb = finish(rb[i], shB, ok, colB, d);
+                    *reinterpret_cast<float4 *>(&lds[buf][1][rr + 16 * i][c4 * 4]) = vb;
+                } else {
+                    cs.x += va.x;
+                    cs.y += va.y;
+                    cs.z += va.z;
+                    cs.w += va.w;
+                }
             }
         }
     };
 
     f32x16 acc0 = {0}, acc1 = {0};
     const int64_t nrows = r1 - c.r0;
-    const int nst = (int)((nrows + kKB - 1) / kKB);
+    // stage 0 is short (16 rows): the matrix pipes start after a 16 KiB fetch per workgroup instead of a
+    // 64 KiB one (the whole grid's first fetch is otherwise ~16 MB before a single MFMA issues)
+    constexpr int kFirst = 16;
+    const int64_t first = nrows < kFirst ? nrows : kFirst;
+    const int nst = (nrows > 0) ? 1 + (int)((nrows - first + kKB - 1) / kKB) : 0;
     const int arow = lane >> 5;
     const int acol = wi * 64 + (lane & 31);
     const int bcol = wj * 32 + (lane & 31);
 
     if (nst > 0) {
-        fetch(c.r0);
-        stash(0, c.r0);
+        fetch(c.r0, 1);
+        stash(0, c.r0, 1);
     }
     __syncthreads();
     for (int s = 0; s < nst; ++s) {
         const int buf = s & 1;
-        const int64_t rnext = c.r0 + (int64_t)(s + 1) * kKB;
-        if (s + 1 < nst && c.ablate != 2) fetch(rnext);
-        int rows_here = (int)(nrows - (int64_t)s * kKB);
-        if (rows_here > kKB) rows_here = kKB;
+        const int64_t rbase = (s == 0) ? c.r0 : c.r0 + first + (int64_t)(s - 1) * kKB;
+        const int64_t rnext = c.r0 + first + (int64_t)s * kKB;
+        if (s + 1 < nst && c.ablate != 2) fetch(rnext, kLoadIters);
+        int rows_here = (int)(r1 - rbase);
+        const int cap = (s == 0) ? kFirst : kKB;
+        if (rows_here > cap) rows_here = cap;
         const int ksteps = (rows_here + 1) / 2;
         const float *A = &lds[buf][0][arow][acol];
         const float *B = &lds[buf][DIAG ? 0 : 1][arow][bcol];
@@ -197,7 +208,7 @@ __device__ __forceinline__ void gram_tile(const GramTileCtx &c, float (*lds)[2][
             else if (m0)
                 mfma_stage<true, false>(A, B, ksteps, acc0, acc1);
         }
-        if (s + 1 < nst) stash(buf ^ 1, rnext);
+        if (s + 1 < nst) stash(buf ^ 1, rnext, kLoadIters);
         __syncthreads();
     }
 

@@ -23,6 +23,21 @@ namespace gs {
 
 constexpr int kTK = 16;
 
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+
+// 1/sqrt(x) for normal positive x: hardware seed + two Newton steps
+__device__ __forceinline__ double rsqrt_f64(double x) {
+    double y = __builtin_amdgcn_rsq(x);
+    const double hx = 0.5 * x;
+    y = y * (1.5 - hx * y * y);
+    y = y * (1.5 - hx * y * y);
+    return y;
+}
+
 // C[M x N] (row-major, ldc) = beta C + alpha sum_t A(i,t) B(t,j) with arbitrary element strides, float64
 // VALU FMAs (the f64 vector and matrix peaks coincide on gfx950).  TM x TN x 16 tiles (64 x 64 with
 // 4 x 4 micro-tiles, or 32 x 32 with 2 x 2 for small outputs), next tile prefetched into registers
@@ -175,70 +190,67 @@ __global__ void subspace_seed_kernel(double *__restrict__ Q, int n, int64_t ldq,
     if (j < k0) Q[(int64_t)i * ldq + j] = V0 ? V0[(int64_t)j * ldv + i] : (i == j ? 1.0 : 0.0);
 }
 
-// Diagonal block of the blocked Cholesky: factors H[j0:j0+nb, j0:j0+nb] = R_JJ^T R_JJ (one wave, block
-// padded to 32 x 32 with an identity tail so that every loop is static), stores R_JJ into Rm and
-// its inverse (upper, leading dim kCB) into Dinv.  A pivot that has lost more than ~13 digits
-// against the column's original squared norm (origdiag, captured at j0 == 0) marks a numerically
-// dependent basis column: it gets R_jj = 1 and a ZERO column in Dinv, so the panel row and the
-// resulting Q column are exactly zero (the subspace simply shrinks by one) instead of NaN/garbage.
+// Diagonal block of the blocked Cholesky: factors H[j0:j0+nb, j0:j0+nb] = R_JJ^T R_JJ, stores R_JJ into Rm
+// and its inverse (upper, leading dim kCB) into Dinv.  ONE wave, no LDS, no barriers: lane c keeps column c
+// of the (identity-padded) 32 x 32 block in registers, every loop is fully unrolled with static register
+// indices, and the values a step needs from other lanes (the pivot, row j of R) travel by v_readlane.
+// A pivot that has lost more than ~13 digits against the column's original squared norm (origdiag, captured
+// at j0 == 0) marks a numerically dependent basis column: it gets R_jj = 1 and a ZERO column in Dinv, so the
+// panel row and the resulting Q column are exactly zero (the subspace shrinks by one) instead of NaN/garbage.
 constexpr int kCB = 32;
 __global__ __launch_bounds__(64) void chol_diag_kernel(const double *__restrict__ H, int64_t ldh, int p, int j0,
                                                        int nb, double *__restrict__ Rm, double *__restrict__ Dinv,
                                                        double *__restrict__ origdiag) {
-    __shared__ double R[kCB][kCB + 1];
-    __shared__ double s_ref[kCB];
-    __shared__ int s_dead[kCB];
-    const int tid = threadIdx.x;
+    const int lane = threadIdx.x;
     if (j0 == 0)
-        for (int i = tid; i < p; i += 64) origdiag[i] = H[(int64_t)i * ldh + i];
-    __syncthreads();
-    if (tid < kCB) s_ref[tid] = (tid < nb) ? (j0 == 0 ? H[(int64_t)tid * ldh + tid] : origdiag[j0 + tid]) : 1.0;
-    for (int e = tid; e < kCB * kCB; e += 64) {
-        const int r = e >> 5, c = e & 31;
-        double v = (r == c) ? 1.0 : 0.0;
-        if (r < nb && c < nb) v = (c >= r) ? H[(int64_t)(j0 + r) * ldh + j0 + c] : 0.0;
-        R[r][c] = v;
-    }
-    if (tid < kCB) s_dead[tid] = 0;
-    __syncthreads();
-    const int r = tid & 31, ch = tid >> 5;  // trailing update: row r, column half ch
-    for (int j = 0; j < kCB; ++j) {
-        const double d = R[j][j];
-        const double ref = s_ref[j];
-        const bool dead = !(d > ref * 1e-13);
-        const double piv = dead ? 1.0 : sqrt(d);
-        __syncthreads();
-        if (tid < kCB && tid >= j) R[j][tid] = (tid == j) ? piv : (dead ? 0.0 : R[j][tid] / piv);
-        if (tid == 0 && dead) s_dead[j] = 1;
-        __syncthreads();
-        if (!dead && r > j) {
-            const double rj = R[j][r];
+        for (int i = lane; i < p; i += 64) origdiag[i] = H[(int64_t)i * ldh + i];
+    const int c = lane & 31;  // lanes 32..63 mirror lanes 0..31 (keeps every cross-lane read in range)
+    double col[kCB];          // col[r] = block(r, c), upper part r <= c
 #pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const int c = ch * 16 + q;
-                if (c >= r) R[r][c] -= rj * R[j][c];
+    for (int r = 0; r < kCB; ++r) {
+        double v = (r == c) ? 1.0 : 0.0;
+        if (r < nb && c < nb) v = (r <= c) ? H[(int64_t)(j0 + r) * ldh + j0 + c] : 0.0;
+        col[r] = v;
+    }
+    const double ref = (c < nb) ? ((j0 == 0) ? H[(int64_t)c * ldh + c] : origdiag[j0 + c]) : 1.0;
+    unsigned dead_mask = 0;
+    double invdiag = 1.0;  // lane j keeps 1 / R[j][j]
+#pragma unroll
+    for (int j = 0; j < kCB; ++j) {
+        // pivot and its reference live in lane j
+        const double d = readlane_f64(col[j], j);
+        const double rf = readlane_f64(ref, j);
+        const bool dead = !(d > rf * 1e-13);
+        const double inv = dead ? 0.0 : rsqrt_f64(d);
+        if (dead) dead_mask |= (1u << j);
+        if (c == j) invdiag = dead ? 1.0 : inv;
+        // row j of R: R[j][c] = block(j, c) / piv  (c > j), R[j][j] = piv (or 1 when dead)
+        const double rjc = (c == j) ? (dead ? 1.0 : d * inv) : ((c > j) ? col[j] * inv : 0.0);
+        col[j] = rjc;
+        if (!dead) {
+#pragma unroll
+            for (int r = j + 1; r < kCB; ++r) {
+                const double rjr = readlane_f64(rjc, r);  // R[j][r], held by lane r
+                if (r <= c) col[r] -= rjr * rjc;
             }
         }
     }
-    __syncthreads();
-    // inverse: thread c holds column c of X = R^-1 in registers (static indices), back substitution
-    if (tid < kCB) {
-        const int c = tid;
-        double x[kCB];
+    // inverse X = R^-1: lane c solves column c by back substitution; R[i][t] is lane t's col[i]
+    double x[kCB];
 #pragma unroll
-        for (int i = kCB - 1; i >= 0; --i) {
-            double sum = (i == c) ? 1.0 : 0.0;
+    for (int i = kCB - 1; i >= 0; --i) {
+        double sum = (i == c) ? 1.0 : 0.0;
 #pragma unroll
-            for (int t = i + 1; t < kCB; ++t) sum -= R[i][t] * x[t];
-            x[i] = (i <= c) ? sum / R[i][i] : 0.0;
-        }
-        const bool dead_c = s_dead[c] != 0;
-#pragma unroll
-        for (int i = 0; i < kCB; ++i) Dinv[i * kCB + c] = (dead_c || i >= nb || c >= nb) ? 0.0 : x[i];
+        for (int t = i + 1; t < kCB; ++t) sum -= readlane_f64(col[i], t) * x[t];
+        x[i] = (i <= c) ? sum * readlane_f64(invdiag, i) : 0.0;
     }
-    for (int e = tid; e < kCB * kCB; e += 64) {
-        const int rr = e >> 5, c = e & 31;
-        if (rr < nb && c < nb) Rm[(int64_t)(j0 + rr) * ldh + j0 + c] = (c >= rr) ? R[rr][c] : 0.0;
+    if (lane < kCB) {
+        const bool dead_c = (dead_mask >> c) & 1u;
+#pragma unroll
+        for (int i = 0; i < kCB; ++i) {
+            Dinv[i * kCB + c] = (dead_c || i >= nb || c >= nb) ? 0.0 : x[i];
+            if (i < nb && c < nb) Rm[(int64_t)(j0 + i) * ldh + j0 + c] = (i <= c) ? col[i] : 0.0;
+        }
     }
 }
 
