@@ -155,16 +155,19 @@ def main():
     # HBM traffic of that kernel from the committed rocprofv3 PMC passes (bench.py cannot run the
     # profiler on itself): FETCH_SIZE, x2-corrected as MI355X_MICROARCH.md prescribes, per launch
     traffic = None
+    traffic_note = None
     try:
         with open(os.path.join(ROOT, "profiles", "gram_pmc_latest.json")) as f:
             pmc = json.load(f)
         if pmc.get("rows_per_launch") == rows_l:
             traffic = pmc["hbm_read_bytes_per_launch_corrected_x2"]
+            traffic_note = pmc.get("traffic_breakdown")
     except Exception:
         pass
     roofline = {"bound": "mfma", "kernel": "gram_partial_kernel<true>", "achieved": round(ach_tf, 2),
                 "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach_tf / PEAK_F32_MFMA_TFLOPS, 4),
                 "traffic": traffic, "traffic_source": "profiles/gram_pmc_latest.json (rocprofv3 --pmc FETCH_SIZE, x2)",
+                "traffic_note": traffic_note,
                 "avg_launch_us": round(avg_ms.value * 1e3, 2), "rows_per_launch": rows_l,
                 "algorithmic_flops_per_launch": flops, "algorithmic_bytes_per_launch": bytes_,
                 "hbm_achieved_GBs": round(ach_gbs, 1), "hbm_frac_of_8TBs": round(ach_gbs / PEAK_HBM_GBS, 4)}
