@@ -24,7 +24,9 @@
 //     re-read from that XCD's L2.
 //   * the shift s (running mean, float32) is subtracted while staging, which keeps the
 //     accumulated scatter centred (no catastrophic cancellation for |mean| >> stdev).
+#include <cstdio>
 #include <cstdlib>
+#include <vector>
 
 #include "gs_common.h"
 
@@ -85,23 +87,74 @@ struct GramTileCtx {
     float *P, *CS;
     const float *shift;
     int ablate;  // profiling only: 1 = no MFMA, 2 = no global loads after the first stage, 3 = no epilogue
+    unsigned long long *trace;  // profiling only (GS_GRAM_TRACE): per-workgroup s_memtime stamps, 16 per WG
 };
 
 // MFMA k-loop over `ksteps` row pairs of one LDS stage for a wave that owns the 64 x 32 strip
 // (sub-tiles a = 0, 1 stacked in M).  M0 / M1 say which of the two sub-tiles this wave computes
 // (diagonal macro tiles skip sub-tiles that lie strictly below the diagonal).
+// ---- software-pipelined MFMA k-loop -----------------------------------------------------------------
+// hipcc schedules "ds_read operands of step k; s_waitcnt lgkmcnt(0); MFMAs of step k", which exposes the
+// LDS latency (~200 cycles with 8 waves reading) once per k-step: measured 79 % matrix-pipe duty inside
+// the loop.  Here the operand reads of step k+1 are issued BEFORE the MFMAs of step k (inline-asm
+// ds_read_b32 with immediate offsets, counted s_waitcnt), so the latency hides behind the wave's own MFMAs.
+template <int OFF>
+__device__ __forceinline__ float lds_read_off(unsigned addr) {
+    float v;
+    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+    return v;
+}
+
+template <bool M0, bool M1, int K, int KS>
+struct MfmaPipe {
+    static __device__ __forceinline__ void run(unsigned aaddr, unsigned baddr, float a0, float a1, float b0,
+                                               f32x16 &acc0, f32x16 &acc1) {
+        constexpr int kStepBytes = 2 * kMacroTile * 4;  // one k-step = two rows of the stage
+        float na0 = 0.f, na1 = 0.f, nb0 = 0.f;
+        if (K + 1 < KS) {
+            if (M0) na0 = lds_read_off<(K + 1) * kStepBytes>(aaddr);
+            if (M1) na1 = lds_read_off<(K + 1) * kStepBytes + 128>(aaddr);
+            nb0 = lds_read_off<(K + 1) * kStepBytes>(baddr);
+            // the operands of THIS step were issued one step earlier: leave only the new reads outstanding
+            constexpr int pending = (M0 ? 1 : 0) + (M1 ? 1 : 0) + 1;
+            if (pending == 3) asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");
+            if (pending == 2) asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (M0) acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc0, 0, 0, 0);
+        if (M1) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc1, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        MfmaPipe<M0, M1, K + 1, KS>::run(aaddr, baddr, na0, na1, nb0, acc0, acc1);
+    }
+};
+template <bool M0, bool M1, int KS>
+struct MfmaPipe<M0, M1, KS, KS> {
+    static __device__ __forceinline__ void run(unsigned, unsigned, float, float, float, f32x16 &, f32x16 &) {}
+};
+
+template <bool M0, bool M1, int KS>
+__device__ __forceinline__ void mfma_steps(const float *__restrict__ A, const float *__restrict__ B,
+                                           f32x16 &acc0, f32x16 &acc1) {
+    // LDS byte addresses of this lane's first operands (generic -> LDS address space: low 32 bits)
+    const unsigned aaddr = (unsigned)(uintptr_t)A, baddr = (unsigned)(uintptr_t)B;
+    float a0 = 0.f, a1 = 0.f;
+    if (M0) a0 = lds_read_off<0>(aaddr);
+    if (M1) a1 = lds_read_off<128>(aaddr);
+    const float b0 = lds_read_off<0>(baddr);
+    MfmaPipe<M0, M1, 0, KS>::run(aaddr, baddr, a0, a1, b0, acc0, acc1);
+}
+
 template <bool M0, bool M1>
 __device__ __forceinline__ void mfma_stage(const float *__restrict__ A, const float *__restrict__ B,
                                            int ksteps, f32x16 &acc0, f32x16 &acc1) {
     if (ksteps == kKB / 2) {
-#pragma unroll
-        for (int k = 0; k < kKB; k += 2) {
-            const float b0 = B[k * kMacroTile];
-            if (M0) acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(A[k * kMacroTile], b0, acc0, 0, 0, 0);
-            if (M1) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(A[k * kMacroTile + 32], b0, acc1, 0, 0, 0);
-        }
+        mfma_steps<M0, M1, kKB / 2>(A, B, acc0, acc1);
+    } else if (ksteps == kKB / 4) {
+        mfma_steps<M0, M1, kKB / 4>(A, B, acc0, acc1);
     } else {
-        // ragged last stage of a chunk: only the rows that exist (no MFMA time spent on zero padding)
+        // ragged stage of a chunk: only the rows that exist (no MFMA time spent on zero padding)
         for (int k = 0; k < 2 * ksteps; k += 2) {
             const float b0 = B[k * kMacroTile];
             if (M0) acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(A[k * kMacroTile], b0, acc0, 0, 0, 0);
@@ -175,6 +228,10 @@ __device__ __forceinline__ void gram_tile(const GramTileCtx &c, float (*lds)[2][
         }
     };
 
+    auto stamp = [&](int slot) {
+        if (c.trace != nullptr && tid == 0) c.trace[(int64_t)blockIdx.x * 16 + slot] = __builtin_amdgcn_s_memtime();
+    };
+    stamp(0);
     f32x16 acc0 = {0}, acc1 = {0};
     const int64_t nrows = r1 - c.r0;
     // stage 0 is short (16 rows): the matrix pipes start after a 16 KiB fetch per workgroup instead of a
@@ -191,6 +248,7 @@ __device__ __forceinline__ void gram_tile(const GramTileCtx &c, float (*lds)[2][
         stash(0, c.r0, 1);
     }
     __syncthreads();
+    stamp(1);
     for (int s = 0; s < nst; ++s) {
         const int buf = s & 1;
         const int64_t rbase = (s == 0) ? c.r0 : c.r0 + first + (int64_t)(s - 1) * kKB;
@@ -202,14 +260,32 @@ __device__ __forceinline__ void gram_tile(const GramTileCtx &c, float (*lds)[2][
         const int ksteps = (rows_here + 1) / 2;
         const float *A = &lds[buf][0][arow][acol];
         const float *B = &lds[buf][DIAG ? 0 : 1][arow][bcol];
-        if (c.ablate != 1) {
+        // The two waves that share a SIMD (w and w + 4) run the stage in different orders so that one of
+        // them always has MFMAs to issue while the other converts / stores the next tile:
+        //   waves 0-3:  MFMA(all k-steps)            -> stash
+        //   waves 4-7:  MFMA(first half) -> stash -> MFMA(second half)
+        const bool split = (wave >= 4) && (s + 1 < nst) && c.ablate != 4;
+        const int kh = split ? ksteps / 2 : ksteps;
+        auto run = [&](const float *Ap, const float *Bp, int ks) {
+            if (c.ablate == 1) return;
+            if (c.ablate == 5) {  // profiling: MFMA stream with register operands (no LDS reads)
+                const float fa = (float)lane, fb = (float)wave;
+                for (int k = 0; k < ks; ++k) {
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa, fb, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fb, fa, acc1, 0, 0, 0);
+                }
+                return;
+            }
             if (m0 && m1)
-                mfma_stage<true, true>(A, B, ksteps, acc0, acc1);
+                mfma_stage<true, true>(Ap, Bp, ks, acc0, acc1);
             else if (m0)
-                mfma_stage<true, false>(A, B, ksteps, acc0, acc1);
-        }
+                mfma_stage<true, false>(Ap, Bp, ks, acc0, acc1);
+        };
+        run(A, B, kh);
         if (s + 1 < nst) stash(buf ^ 1, rnext, kLoadIters);
+        if (split) run(A + 2 * kh * kMacroTile, B + 2 * kh * kMacroTile, ksteps - kh);
         __syncthreads();
+        if (s < 12) stamp(2 + s);
     }
 
     // ---- epilogue: 32x32 sub-tiles -> this chunk's float32 slab --------------------------------
@@ -229,6 +305,7 @@ __device__ __forceinline__ void gram_tile(const GramTileCtx &c, float (*lds)[2][
                 Pc[(int64_t)(row_base + 32 + (r & 3) + 8 * (r >> 2)) * dp + col] = acc1[r];
         }
     }
+    stamp(14);
     // ---- column sums of panel I (diagonal macro tiles only; each panel is diagonal once) --------
     if (DIAG) {
         float *scr = &lds[0][0][0][0];
@@ -311,6 +388,7 @@ struct FoldJob {
     const float *P, *CS;  // previous launch's slabs (nullptr: nothing to fold)
     double *G64, *S1;
     int nchunks, T32, ntiles, accumulate;
+    unsigned long long *trace;  // profiling only
 };
 
 template <bool VEC>
@@ -340,6 +418,7 @@ __global__ __launch_bounds__(kThreads, 1) void gram_partial_kernel(
     c.CS = CS;
     c.shift = shift;
     c.ablate = ablate;
+    c.trace = fold.trace;
     c.r0 = (int64_t)c.chunk * chunk_rows;
     c.r1 = (c.r0 + chunk_rows < rows) ? c.r0 + chunk_rows : rows;
     if (c.I == c.J)
@@ -424,15 +503,51 @@ static void launch_partial(const GramWorkspace &ws, const GramGeom &g, int buf, 
         nfold = 256 - g.grid % 256;
         if (nfold < 8 || nfold > 64) nfold = 16;
     }
+    static unsigned long long *trace_buf = []() -> unsigned long long * {
+        if (!getenv("GS_GRAM_TRACE")) return nullptr;
+        unsigned long long *p = nullptr;
+        if (hipMalloc(&p, sizeof(unsigned long long) * 16 * 4096) != hipSuccess) return nullptr;
+        (void)hipMemset(p, 0, sizeof(unsigned long long) * 16 * 4096);
+        return p;
+    }();
+    FoldJob fj = fold;
+    fj.trace = trace_buf;
     const dim3 grid((unsigned)(g.grid + nfold));
     if (vec)
         hipLaunchKernelGGL(gram_partial_kernel<true>, grid, dim3(kThreads), 0, stream, Xb, n, ld, (int)d, shift,
                            ws.partial[buf], ws.colsum_partial[buf], dp, g.nchunks, g.chunk_rows, g.nmt, g.T, ablate,
-                           g.grid, fold);
+                           g.grid, fj);
     else
         hipLaunchKernelGGL(gram_partial_kernel<false>, grid, dim3(kThreads), 0, stream, Xb, n, ld, (int)d, shift,
                            ws.partial[buf], ws.colsum_partial[buf], dp, g.nchunks, g.chunk_rows, g.nmt, g.T, ablate,
-                           g.grid, fold);
+                           g.grid, fj);
+    if (trace_buf && getenv("GS_GRAM_TRACE_DUMP")) {
+        // debug only (synchronises): mean s_memtime deltas of this launch's compute workgroups, relative to each
+        // workgroup's own start; slots: 0 start, 1 first tile staged, 2+s end of stage s, 14 slab written
+        (void)hipStreamSynchronize(stream);
+        static std::vector<unsigned long long> h(16 * 4096);
+        (void)hipMemcpy(h.data(), trace_buf, sizeof(unsigned long long) * 16 * g.grid, hipMemcpyDeviceToHost);
+        (void)hipMemset(trace_buf, 0, sizeof(unsigned long long) * 16 * 4096);
+        unsigned long long first = ~0ull, last = 0;
+        double sum[16] = {0};
+        int cnt[16] = {0};
+        for (int b = 0; b < g.grid; ++b) {
+            const unsigned long long s0 = h[b * 16];
+            if (!s0) continue;
+            if (s0 < first) first = s0;
+            if (h[b * 16 + 14] > last && h[b * 16 + 14] < s0 + 100000000ull) last = h[b * 16 + 14];
+            for (int q = 1; q < 15; ++q)
+                if (h[b * 16 + q] > s0) {
+                    sum[q] += (double)(h[b * 16 + q] - s0);
+                    cnt[q]++;
+                }
+        }
+        fprintf(stderr, "[gram trace] span first-start..last-end %.0f ticks; mean ticks since own start:",
+                (double)(last - first));
+        for (int q = 1; q < 15; ++q)
+            if (cnt[q]) fprintf(stderr, " s%d=%.0f(n=%d)", q, sum[q] / cnt[q], cnt[q]);
+        fprintf(stderr, "\n");
+    }
 }
 
 static FoldJob pending_job(const GramWorkspace &ws, double *G64, double *S1) {
