@@ -27,7 +27,7 @@ from types import SimpleNamespace
 import numpy as np
 import torch
 
-from . import ops
+from . import _zgen, ops
 from .estimators import get_estimator
 from .nethook import InstrumentedModel
 from .wrappers import get_instrumented_model
@@ -180,8 +180,17 @@ def compute(config, dump_name, instrumented_model):
     n_lat = ((N + NB - 1) // B + 1) * B
     latents = torch.zeros((n_lat, *input_shape[1:]), dtype=torch.float32, device=device)
     with torch.no_grad():
-        for i in _progress(range(n_lat // B), desc="Sampling latents"):
-            latents[i * B:(i + 1) * B] = model.sample_latent(n_samples=B)
+        if hasattr(model, "z_spec") and hasattr(model, "latent_from_z"):
+            # same stream consumption as n_lat // B calls of sample_latent(): one randint per mini-batch
+            # (wrappers.py:168-169); the batches themselves are generated by parallel worker processes
+            kind, zdim = model.z_spec
+            seeds = [np.random.randint(np.iinfo(np.int32).max) for _ in range(n_lat // B)]
+            zs = _zgen.generate(kind, seeds, B, zdim, getattr(model, "truncation", 1.0) if kind == "biggan" else 1.0)
+            for i, z in enumerate(_progress(zs, desc="Sampling latents")):
+                latents[i * B:(i + 1) * B] = model.latent_from_z(z)
+        else:
+            for i in _progress(range(n_lat // B), desc="Sampling latents"):
+                latents[i * B:(i + 1) * B] = model.sample_latent(n_samples=B)
 
     samples_are_latents = layer_key in ["g_mapping", "style"] and inst.model.latent_space_name() == "W"
 

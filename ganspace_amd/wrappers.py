@@ -33,7 +33,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import ops
+from . import _zgen, ops
 from .config import Config
 from .nethook import InstrumentedModel
 
@@ -277,8 +277,14 @@ class StyleGAN2(BaseModel):
     def sample_latent(self, n_samples=1, seed=None, truncation=None):
         if seed is None:
             seed = np.random.randint(np.iinfo(np.int32).max)  # use (reproducible) global rand state
-        rng = np.random.RandomState(seed)
-        z = torch.from_numpy(rng.standard_normal(512 * n_samples).reshape(n_samples, 512)).float().to(self.device)
+        return self.latent_from_z(_zgen.stylegan_z(seed, n_samples, 512))
+
+    # host z -> primary latent on the device (W when w_primary); lets the driver generate z batches in
+    # parallel worker processes while keeping the reference's seeding protocol bit for bit
+    z_spec = ("stylegan", 512)
+
+    def latent_from_z(self, z_host):
+        z = torch.from_numpy(z_host).float().to(self.device)
         if self.w_primary:
             z = self.model.style(z)
         return z
@@ -465,6 +471,11 @@ class BigGAN(BaseModel):
         noise_vector = truncated_noise_sample(truncation=truncation or self.truncation, batch_size=n_samples,
                                               seed=seed)
         return torch.from_numpy(noise_vector).to(self.device)
+
+    z_spec = ("biggan", 128)
+
+    def latent_from_z(self, z_host):
+        return torch.from_numpy(z_host).to(self.device)
 
     def get_max_latents(self):
         return len(self.model.config.layers) + 1

@@ -162,3 +162,16 @@ def test_mapping_oracle_matches_reference_gmapping(golden_dir):
     np.testing.assert_allclose(w, g["w_f64"], rtol=1e-9, atol=1e-11)
     scale = np.abs(g["w_f64"]).max()
     assert np.abs(w - g["w_f32"]).max() < 5e-5 * scale
+
+
+def test_parallel_z_generation_is_bit_identical_to_the_serial_protocol(monkeypatch):
+    from ganspace_amd import _zgen
+    seeds = zstream.batch_seeds(6)
+    serial = [zstream.stylegan_z_batch(s, 64, 512) for s in seeds]
+    monkeypatch.setenv("GANSPACE_ZGEN_WORKERS", "3")       # force the process pool
+    pooled = list(_zgen.generate("stylegan", seeds, 64, 512))
+    for a, b in zip(serial, pooled):
+        np.testing.assert_array_equal(a, b)
+    big = list(_zgen.generate("biggan", seeds[:4], 16, 128, 1.0))
+    for s, b in zip(seeds[:4], big):
+        np.testing.assert_array_equal(zstream.biggan_z_batch(s, 16), b)
