@@ -35,12 +35,6 @@ __device__ __forceinline__ double wave_sum(double v) {
     return v;
 }
 
-__device__ __forceinline__ double wave_max(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
-    return v;
-}
-
 // ---- cheap wave-level pieces for the LDS-resident solver -----------------------------------------
 // 64-lane sum with DPP inside each row of 16 lanes (no LDS crossbar traffic) and v_readlane across
 // the four rows; every lane returns the full sum.
