@@ -6,14 +6,14 @@
 // the d x d scatter  sum_r (x_r - s)(x_r - s)^T  and the column sums  sum_r (x_r - s)
 // of the [rows, d] float32 activation block are accumulated on the matrix cores.
 //
-// Work decomposition (one launch per <= 48 x 512 rows):
+// Work decomposition (one launch per <= 24 x 1024 rows at d = 512):
 //   * output: upper-triangle 128 x 128 macro tiles of the d x d Gram (symmetry: the lower
 //     triangle is never computed); one workgroup (4 waves) per (macro tile, row chunk);
 //     wave (wi, wj) owns a 64 x 64 tile = 2 x 2 accumulators of v_mfma_f32_32x32x2_f32;
 //     on diagonal macro tiles the strictly-lower wave tile is skipped.
 //   * split-K over row chunks: each chunk's partial tile goes to a float32 slab; a second
 //     kernel folds the slabs in float64 into the persistent accumulator, so float32
-//     fma chains never exceed 512 rows.
+//     fma chains never exceed 1024 rows (417 at the 10 000-row block of the bench).
 //   * X is row-major [rows, d]; for X^T X both MFMA operands are "row k, 32 consecutive
 //     columns" (A[i][k] = X[k][I+i], B[k][j] = X[k][J+j]) so global reads are fully
 //     coalesced 512-B row segments and LDS reads are conflict-free ds_read_b32 without
@@ -37,7 +37,7 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 constexpr int kKB = 64;        // rows per LDS stage (2 x 2 x 64 x 128 f32 = 128 KiB of LDS per workgroup)
 constexpr int kLoadIters = kKB / 16;
 constexpr int kThreads = 512;   // 8 waves: two per SIMD
-constexpr int kMaxChunkRows = 512;
+constexpr int kMaxChunkRows = 1024;  // longest float32 fma chain before the float64 fold
 
 __device__ __forceinline__ void decode_upper(int idx, int T, int &I, int &J) {
     int i = 0, len = T;
