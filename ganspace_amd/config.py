@@ -1,56 +1,78 @@
-"""``Config``: argparse-backed option bag, same flags/defaults/semantics as the reference
-(``/root/reference/config.py:16-72``): defaults are obtained by parsing ``[]``, keyword
-arguments override, ``from_args`` re-parses a command line, ``__str__`` prints the
-custom-vs-default split as JSON.  New knobs of this implementation are plain attributes
-with defaults so that reference call sites are unaffected.
+"""Run configuration with the reference's command-line surface.
+
+Drop-in for the reference ``Config`` (``/root/reference/config.py:16-72``): the same option names,
+flags and defaults (``--model --layer --class --est --sparsity --video --batch -b -c -n --use_w --sigma
+--inputs --seed``), keyword overrides in the constructor, ``from_args`` / ``from_dict``, and a JSON
+``str()`` that separates customised from default values.  The options live in ONE declarative table
+below (flag, attribute, type, default, help); both the defaults and the argument parser are derived
+from it, and knobs specific to this implementation can be appended without touching any call site.
 """
+from __future__ import annotations
+
 import argparse
 import json
 import sys
-from copy import deepcopy
+from collections import namedtuple
+
+Option = namedtuple("Option", "flags dest kind default help")
+
+OPTIONS = (
+    Option(("--model",), "model", str, "StyleGAN", "generator to analyse (StyleGAN2, BigGAN-512, ...)"),
+    Option(("--layer",), "layer", str, "g_mapping", "name of the layer whose activations are decomposed"),
+    Option(("--class",), "output_class", str, None, "output class (BigGAN: ImageNet id, StyleGAN2: dataset)"),
+    Option(("--est",), "estimator", str, "ipca", "estimator: ipca (sklearn-faithful) | ipca-exact"),
+    Option(("--sparsity",), "sparsity", float, 1.0, "sparsity weight (SPCA of the reference; unused here)"),
+    Option(("--video",), "make_video", bool, False, "render videos of the edits"),
+    Option(("--batch",), "batch_mode", bool, False, "no windows: write results to files"),
+    Option(("-b",), "batch_size", int, None, "generator mini-batch size (default: probe, at most 20)"),
+    Option(("-c",), "components", int, 80, "number of principal components kept"),
+    Option(("-n",), "n", int, 300_000, "number of latent samples fed to the PCA"),
+    Option(("--use_w",), "use_w", bool, False, "decompose StyleGAN's W space instead of Z"),
+    Option(("--sigma",), "sigma", float, 2.0, "edit strength in standard deviations (visualisation)"),
+    Option(("--inputs",), "inputs", str, None, "directory with named, exported components"),
+    Option(("--seed",), "seed", int, None, "seed of the latent stream (default 1)"),
+)
+
+
+def _parser() -> argparse.ArgumentParser:
+    parser = argparse.ArgumentParser(description="GAN component analysis (MI355X)")
+    for opt in OPTIONS:
+        if opt.kind is bool:
+            parser.add_argument(*opt.flags, dest=opt.dest, action="store_true", help=opt.help)
+        else:
+            parser.add_argument(*opt.flags, dest=opt.dest, type=opt.kind, default=opt.default, help=opt.help)
+    return parser
 
 
 class Config:
-    def __init__(self, **kwargs):
-        self.from_args([])
-        self.default_args = deepcopy(self.__dict__)
-        self.from_dict(kwargs)
+    """Attribute bag: table defaults, then keyword overrides."""
 
-    def __str__(self):
-        custom, default = {}, {}
-        for k, v in self.__dict__.items():
-            if k == "default_args":
-                continue
-            if k in self.default_args and self.default_args.get(k) == v:
-                default[k] = v
-            else:
-                custom[k] = v
-        return json.dumps({"custom": custom, "default": default}, indent=4)
+    def __init__(self, **overrides):
+        self.default_args = {opt.dest: opt.default for opt in OPTIONS}
+        self.from_dict(self.default_args)
+        self.from_dict(overrides)
 
-    __repr__ = __str__
-
-    def from_dict(self, dictionary):
-        for k, v in dictionary.items():
-            setattr(self, k, v)
+    def from_dict(self, values):
+        for key, value in dict(values).items():
+            setattr(self, key, value)
         return self
 
     def from_args(self, args=None):
-        if args is None:
-            args = sys.argv[1:]
-        p = argparse.ArgumentParser(description="GAN component analysis config")
-        p.add_argument("--model", dest="model", type=str, default="StyleGAN", help="The network to analyze")
-        p.add_argument("--layer", dest="layer", type=str, default="g_mapping", help="The layer to analyze")
-        p.add_argument("--class", dest="output_class", type=str, default=None, help="Output class to generate")
-        p.add_argument("--est", dest="estimator", type=str, default="ipca",
-                       help="The algorithm to use [ipca, ipca-exact]")
-        p.add_argument("--sparsity", type=float, default=1.0, help="Sparsity parameter of SPCA")
-        p.add_argument("--video", dest="make_video", action="store_true", help="Generate output videos (MP4s)")
-        p.add_argument("--batch", dest="batch_mode", action="store_true", help="Don't open windows")
-        p.add_argument("-b", dest="batch_size", type=int, default=None, help="Minibatch size")
-        p.add_argument("-c", dest="components", type=int, default=80, help="Number of components to keep")
-        p.add_argument("-n", type=int, default=300_000, help="Number of examples to use in decomposition")
-        p.add_argument("--use_w", action="store_true", help="Use W latent space (StyleGAN(2))")
-        p.add_argument("--sigma", type=float, default=2.0, help="Number of stdevs to walk in visualize.py")
-        p.add_argument("--inputs", type=str, default=None, help="Path to directory with named components")
-        p.add_argument("--seed", type=int, default=None, help="Seed used in decomposition")
-        return self.from_dict(p.parse_args(args).__dict__)
+        """Parse a command line (``sys.argv[1:]`` by default) on top of the current values."""
+        parsed = _parser().parse_args(sys.argv[1:] if args is None else args)
+        return self.from_dict(vars(parsed))
+
+    def _split(self):
+        custom, default = {}, {}
+        for key, value in vars(self).items():
+            if key == "default_args":
+                continue
+            untouched = key in self.default_args and self.default_args[key] == value
+            (default if untouched else custom)[key] = value
+        return custom, default
+
+    def __str__(self):
+        custom, default = self._split()
+        return json.dumps({"custom": custom, "default": default}, indent=4)
+
+    __repr__ = __str__

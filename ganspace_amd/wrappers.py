@@ -302,51 +302,53 @@ class StyleGAN2(BaseModel):
                             truncation_latent=self.latent_avg, input_is_w=self.w_primary)
         return 0.5 * (out + 1)
 
-    def partial_forward(self, x, layer_name):
-        styles = x if isinstance(x, list) else [x]
-        inject_index = None
-        noise = self.noise
+    def _w_plus(self, x):
+        """Latent(s) -> the per-layer style tensor ``[N, n_latent, 512]`` (wrappers.py:195-219): one global
+        latent, two latents mixed at a random crossover, or one latent per layer."""
+        g = self.model
+        styles = list(x) if isinstance(x, list) else [x]
         if not self.w_primary:
-            styles = [self.model.style(s) for s in styles]
+            styles = [g.style(s) for s in styles]
         if len(styles) == 1:
-            inject_index = self.model.n_latent
-            latent = self.model.strided_style(styles[0].unsqueeze(1).repeat(1, inject_index, 1))
+            stacked = styles[0].unsqueeze(1).repeat(1, g.n_latent, 1)
         elif len(styles) == 2:
-            if inject_index is None:
-                inject_index = random.randint(1, self.model.n_latent - 1)
-            latent = styles[0].unsqueeze(1).repeat(1, inject_index, 1)
-            latent2 = styles[1].unsqueeze(1).repeat(1, self.model.n_latent - inject_index, 1)
-            latent = self.model.strided_style(torch.cat([latent, latent2], 1))
+            cut = random.randint(1, g.n_latent - 1)
+            stacked = torch.cat([styles[0].unsqueeze(1).repeat(1, cut, 1),
+                                 styles[1].unsqueeze(1).repeat(1, g.n_latent - cut, 1)], 1)
         else:
-            assert len(styles) == self.model.n_latent, \
-                f"Expected {self.model.n_latent} latents, got {len(styles)}"
-            latent = self.model.strided_style(torch.stack(styles, dim=1))
+            assert len(styles) == g.n_latent, f"Expected {g.n_latent} latents, got {len(styles)}"
+            stacked = torch.stack(styles, dim=1)
+        return g.strided_style(stacked)
 
+    def _synthesis_stages(self, latent):
+        """Run the synthesis network stage by stage, yielding ``(module name, exact)`` after each one;
+        ``exact`` tells whether the reference matches that name exactly or as a substring."""
+        g, noise = self.model, self.noise
+        out = g.input(latent)
+        yield "input", True
+        out = g.conv1(out, latent[:, 0], noise=noise[0])
+        yield "conv1", False
+        skip = g.to_rgb1(out, latent[:, 1])
+        yield "to_rgb1", False
+        for j, (up, conv, rgb) in enumerate(zip(g.convs[::2], g.convs[1::2], g.to_rgbs)):
+            i = 1 + 2 * j
+            out = up(out, latent[:, i], noise=noise[i])
+            yield f"convs.{2 * j}", False
+            out = conv(out, latent[:, i + 1], noise=noise[i + 1])
+            yield f"convs.{2 * j + 1}", False
+            skip = rgb(out, latent[:, i + 2], skip)
+            yield f"to_rgbs.{j}", False
+
+    def partial_forward(self, x, layer_name):
+        """Evaluate the generator only as far as ``layer_name`` (wrappers.py:194-259): the mapping network
+        (+ ``strided_style``) for any layer whose name contains 'style', otherwise the synthesis prefix.
+        Returns ``None`` - the activation is read from the hook."""
+        latent = self._w_plus(x)
         if "style" in layer_name:
             return
-        out = self.model.input(latent)
-        if "input" == layer_name:
-            return
-        out = self.model.conv1(out, latent[:, 0], noise=noise[0])
-        if "conv1" in layer_name:
-            return
-        skip = self.model.to_rgb1(out, latent[:, 1])
-        if "to_rgb1" in layer_name:
-            return
-        i = 1
-        noise_i = 1
-        for conv1, conv2, to_rgb in zip(self.model.convs[::2], self.model.convs[1::2], self.model.to_rgbs):
-            out = conv1(out, latent[:, i], noise=noise[noise_i])
-            if f"convs.{i-1}" in layer_name:
+        for name, exact in self._synthesis_stages(latent):
+            if (name == layer_name) if exact else (name in layer_name):
                 return
-            out = conv2(out, latent[:, i + 1], noise=noise[noise_i + 1])
-            if f"convs.{i}" in layer_name:
-                return
-            skip = to_rgb(out, latent[:, i + 2], skip)
-            if f"to_rgbs.{i//2}" in layer_name:
-                return
-            i += 2
-            noise_i += 2
         raise RuntimeError(f"Layer {layer_name} not encountered in partial_forward")
 
     def set_noise_seed(self, seed):
