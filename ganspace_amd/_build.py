@@ -17,7 +17,7 @@ ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIBDIR = os.path.join(PKG, "lib")
 LIBNAME = "libganspace_hip.so"
-SOURCES = ["gs_gram.hip", "gs_eigh.hip", "gs_ipca.hip", "gs_linear.hip", "gs_smallside.hip", "gs_subspace.hip"]
+SOURCES = ["gs_gram.hip", "gs_eigh.hip", "gs_ipca.hip", "gs_linear.hip", "gs_smallside.hip", "gs_subspace.hip", "gs_gram_bf16.hip"]
 
 
 def lib_path() -> str:
@@ -41,24 +41,39 @@ def needs_build() -> bool:
 
 
 def build(force: bool = False, verbose: bool = True) -> str:
+    """Compile every source whose object is older than it (or than any header), then link.
+    ``GS_HIPCC_FLAGS`` appends flags (e.g. ``-DGS_GRAM_ABLATE_BUILD`` for the measurement variants); objects are
+    rebuilt when the flags change."""
     os.makedirs(LIBDIR, exist_ok=True)
     out = lib_path()
+    extra = os.environ.get("GS_HIPCC_FLAGS", "").split()
+    stamp = os.path.join(LIBDIR, "flags.txt")
+    old = open(stamp).read() if os.path.exists(stamp) else ""
+    if old != " ".join(extra):
+        force = True
     if not force and not needs_build():
         return out
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    headers.append(os.path.join(ROOT, "include", "ganspace_hip.h"))
+    newest_header = max(os.path.getmtime(h) for h in headers)
     objs = []
     for src in SOURCES:
+        path = os.path.join(CSRC, src)
         obj = os.path.join(LIBDIR, src.replace(".hip", ".o"))
-        cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c",
-               "-I", os.path.join(ROOT, "include"), "-I", CSRC,
-               os.path.join(CSRC, src), "-o", obj]
+        objs.append(obj)
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(path), newest_header):
+            continue
+        cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", *extra,
+               "-I", os.path.join(ROOT, "include"), "-I", CSRC, path, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
-        objs.append(obj)
     cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", out]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)
+    with open(stamp, "w") as f:
+        f.write(" ".join(extra))
     return out
 
 

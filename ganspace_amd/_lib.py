@@ -13,7 +13,8 @@ from . import _build
 
 GS_OK, GS_EINVAL, GS_EHIP, GS_ENOMEM, GS_ESTATE, GS_ENOTIMPL = 0, -1, -2, -3, -4, -5
 GS_MODE_EXACT, GS_MODE_FAITHFUL, GS_MODE_SMALLSIDE = 0, 1, 2
-GS_PREC_F32 = 0
+GS_PREC_F32, GS_PREC_BF16X3, GS_PREC_BF16X6 = 0, 1, 2
+PRECISIONS = {"f32": GS_PREC_F32, "bf16x3": GS_PREC_BF16X3, "bf16x6": GS_PREC_BF16X6}
 
 _vp, _i64, _int, _f32 = C.c_void_p, C.c_int64, C.c_int, C.c_float
 
@@ -35,6 +36,7 @@ SIGNATURES = {
     "gs_ipca_last_mults": (_int, [_vp]),
     "gs_ipca_components_device": (_int, [_vp, C.POINTER(_vp), C.POINTER(_vp)]),
     "gs_gram_accumulate": (_int, [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp]),
+    "gs_gram_accumulate_prec": (_int, [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _int, _vp]),
     "gs_gram_kernel_time": (_int, [_vp, _vp, _i64, _i64, _int, _vp, _vp, _vp]),
     "gs_eigh_sym": (_int, [_vp, _vp, _int, _vp, _vp]),
     "gs_mapping_forward": (_int, [_vp, _vp, _vp, _vp, _vp, _int, _int, _f32, _f32, _f32, _f32, _int, _i64, _vp]),

@@ -43,6 +43,7 @@ struct GramWorkspace {
     int64_t dp = 0;                // d rounded up to kMacroTile
     int max_chunks = 0;
     int cur = 0;
+    int precision = 0;             // GS_PREC_*: which MFMA path computes the partial Grams
     bool pend_valid = false;       // a slab set still waits to be folded
     int pend_buf = 0, pend_nchunks = 0;
     bool pend_acc = false;         // fold adds to (true) or overwrites (false) the accumulators

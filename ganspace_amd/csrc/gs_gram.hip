@@ -29,6 +29,7 @@
 #include <vector>
 
 #include "gs_common.h"
+#include "gs_gram_internal.h"
 
 namespace gs {
 
@@ -38,17 +39,6 @@ constexpr int kKB = 64;        // rows per LDS stage (2 x 2 x 64 x 128 f32 = 128
 constexpr int kLoadIters = kKB / 16;
 constexpr int kThreads = 512;   // 8 waves: two per SIMD
 constexpr int kMaxChunkRows = 1024;  // longest float32 fma chain before the float64 fold
-
-__device__ __forceinline__ void decode_upper(int idx, int T, int &I, int &J) {
-    int i = 0, len = T;
-    while (idx >= len) {
-        idx -= len;
-        ++i;
-        --len;
-    }
-    I = i;
-    J = i + idx;
-}
 
 // Raw (un-shifted) float4 of X at a CLAMPED address: never out of bounds, never branches, and
 // nothing depends on the loaded value until `finish` runs - so all loads of a stage stay in
@@ -323,78 +313,10 @@ __device__ __forceinline__ void gram_tile(const GramTileCtx &c, float (*lds)[2][
     }
 }
 
-// Fold `nchunks` float32 slabs into the float64 accumulators: element e of the upper 32x32 sub-tiles
-// (then the dp column sums), grid-stride over `nworkers` workgroups of `nthreads`.
-__device__ __forceinline__ void fold_elements(const float *__restrict__ P, const float *__restrict__ CS,
-                                              double *__restrict__ G64, double *__restrict__ S1, int dp, int nchunks,
-                                              int T32, int ntiles, int accumulate, int worker, int nworkers,
-                                              int nthreads) {
-    // work item = 4 consecutive elements of a sub-tile row (one float4 per chunk, 8 chunks in flight)
-    const int64_t stride = (int64_t)dp * dp;
-    const int ngroups = ntiles * 256;
-    const int total = ngroups + dp;
-    for (int e = worker * nthreads + threadIdx.x; e < total; e += nworkers * nthreads) {
-        if (e < ngroups) {
-            int ti, tj;
-            decode_upper(e >> 8, T32, ti, tj);
-            const int w = e & 255;
-            const int64_t off = (int64_t)(ti * kSubTile + (w >> 3)) * dp + tj * kSubTile + (w & 7) * 4;
-            double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-            int c = 0;
-            for (; c + 8 <= nchunks; c += 8) {
-                float4 v[8];
-#pragma unroll
-                for (int q = 0; q < 8; ++q) v[q] = *reinterpret_cast<const float4 *>(P + (c + q) * stride + off);
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    s0 += v[q].x;
-                    s1 += v[q].y;
-                    s2 += v[q].z;
-                    s3 += v[q].w;
-                }
-            }
-            for (; c < nchunks; ++c) {
-                const float4 v = *reinterpret_cast<const float4 *>(P + c * stride + off);
-                s0 += v.x;
-                s1 += v.y;
-                s2 += v.z;
-                s3 += v.w;
-            }
-            double *g = G64 + off;
-            if (accumulate) {
-                g[0] += s0;
-                g[1] += s1;
-                g[2] += s2;
-                g[3] += s3;
-            } else {
-                g[0] = s0;
-                g[1] = s1;
-                g[2] = s2;
-                g[3] = s3;
-            }
-        } else {
-            const int col = e - ngroups;
-            double s = 0;
-            for (int c = 0; c < nchunks; ++c) s += CS[(int64_t)c * dp + col];
-            if (accumulate)
-                S1[col] += s;
-            else
-                S1[col] = s;
-        }
-    }
-}
-
-struct FoldJob {
-    const float *P, *CS;  // previous launch's slabs (nullptr: nothing to fold)
-    double *G64, *S1;
-    int nchunks, T32, ntiles, accumulate;
-    unsigned long long *trace;  // profiling only
-};
-
 template <bool VEC>
 __global__ __launch_bounds__(kThreads, 1) void gram_partial_kernel(
     const float *__restrict__ X, int64_t rows, int64_t ld, int d, const float *__restrict__ shift,
-    float *__restrict__ P, float *__restrict__ CS, int dp, int nchunks, int64_t chunk_rows, int nmt,
+    float *__restrict__ P, float *__restrict__ CS, int dp, int nchunks, ChunkPlan plan, int nmt,
     int T, int ablate, int ncompute, FoldJob fold) {
     __shared__ __attribute__((aligned(16))) float lds[2][2][kKB][kMacroTile];  // 128 KiB
 
@@ -419,8 +341,7 @@ __global__ __launch_bounds__(kThreads, 1) void gram_partial_kernel(
     c.shift = shift;
     c.ablate = ablate;
     c.trace = fold.trace;
-    c.r0 = (int64_t)c.chunk * chunk_rows;
-    c.r1 = (c.r0 + chunk_rows < rows) ? c.r0 + chunk_rows : rows;
+    chunk_range(plan, c.chunk, rows, c.r0, c.r1);
     if (c.I == c.J)
         gram_tile<VEC, true>(c, lds);
     else
@@ -462,7 +383,8 @@ void gram_workspace_free(GramWorkspace &ws) {
 // Launch geometry of one partial-Gram launch over n rows.
 struct GramGeom {
     int nmt, T, want, nchunks, grid;
-    int64_t chunk_rows, rows_per_launch;
+    ChunkPlan plan;
+    int64_t rows_per_launch;
 };
 
 static GramGeom gram_geometry(const GramWorkspace &ws, int64_t n) {
@@ -482,11 +404,46 @@ static GramGeom gram_geometry(const GramWorkspace &ws, int64_t n) {
     if (g.want > ws.max_chunks) g.want = ws.max_chunks;
     g.rows_per_launch = (int64_t)g.want * kMaxChunkRows;
     if (n > g.rows_per_launch) n = g.rows_per_launch;
-    g.chunk_rows = round_up(ceil_div(n, g.want), 8);
-    if (g.chunk_rows < 64) g.chunk_rows = 64;
-    g.nchunks = (int)ceil_div(n, g.chunk_rows);
+    // deal the rows out in units of kRowUnit, at least 64 rows per chunk
+    const int64_t units = ceil_div(n, (int64_t)kRowUnit);
+    const int64_t most = units / (64 / kRowUnit) > 0 ? units / (64 / kRowUnit) : 1;
+    g.nchunks = (int)(most < g.want ? most : g.want);
+    g.plan.q = (int)(units / g.nchunks);
+    g.plan.rem = (int)(units % g.nchunks);
     g.grid = (int)round_up(g.nchunks, 8) * g.nmt;
     return g;
+}
+
+// debug only (GS_GRAM_TRACE + GS_GRAM_TRACE_DUMP; synchronises): s_memtime stamps (100 MHz) of one launch's compute
+// workgroups.  slots: 0 start, 1 first tile staged, 2+s end of stage s / phase s, 14 slab written
+static void dump_trace(unsigned long long *trace_buf, int grid, hipStream_t stream) {
+    if (!trace_buf || !getenv("GS_GRAM_TRACE_DUMP")) return;
+    (void)hipStreamSynchronize(stream);
+    static std::vector<unsigned long long> h(16 * 4096);
+    (void)hipMemcpy(h.data(), trace_buf, sizeof(unsigned long long) * 16 * grid, hipMemcpyDeviceToHost);
+    (void)hipMemset(trace_buf, 0, sizeof(unsigned long long) * 16 * 4096);
+    unsigned long long first = ~0ull, last = 0, last_start = 0;
+    double sum[16] = {0}, mx[16] = {0};
+    int cnt[16] = {0};
+    for (int b = 0; b < grid; ++b) {
+        const unsigned long long s0 = h[b * 16];
+        if (!s0) continue;
+        if (s0 < first) first = s0;
+        if (s0 > last_start) last_start = s0;
+        if (h[b * 16 + 14] > last && h[b * 16 + 14] < s0 + 100000000ull) last = h[b * 16 + 14];
+        for (int q = 1; q < 15; ++q)
+            if (h[b * 16 + q] > s0) {
+                const double dt = (double)(h[b * 16 + q] - s0);
+                sum[q] += dt;
+                if (dt > mx[q]) mx[q] = dt;
+                cnt[q]++;
+            }
+    }
+    fprintf(stderr, "[gram trace] span first-start..last-end %.0f ticks, start spread %.0f; mean(max) ticks since own start:",
+            (double)(last - first), (double)(last_start - first));
+    for (int q = 1; q < 15; ++q)
+        if (cnt[q]) fprintf(stderr, " s%d=%.0f(%.0f)", q, sum[q] / cnt[q], mx[q]);
+    fprintf(stderr, "\n");
 }
 
 static void launch_partial(const GramWorkspace &ws, const GramGeom &g, int buf, const float *Xb, int64_t n,
@@ -512,42 +469,22 @@ static void launch_partial(const GramWorkspace &ws, const GramGeom &g, int buf, 
     }();
     FoldJob fj = fold;
     fj.trace = trace_buf;
+    if (ws.precision != GS_PREC_F32) {
+        (void)launch_gram_bf16(ws.precision, g.grid, nfold, Xb, n, ld, (int)d, shift, ws.partial[buf],
+                               ws.colsum_partial[buf], dp, g.nchunks, g.plan, g.nmt, g.T, fj, stream);
+        dump_trace(trace_buf, g.grid, stream);
+        return;
+    }
     const dim3 grid((unsigned)(g.grid + nfold));
     if (vec)
         hipLaunchKernelGGL(gram_partial_kernel<true>, grid, dim3(kThreads), 0, stream, Xb, n, ld, (int)d, shift,
-                           ws.partial[buf], ws.colsum_partial[buf], dp, g.nchunks, g.chunk_rows, g.nmt, g.T, ablate,
+                           ws.partial[buf], ws.colsum_partial[buf], dp, g.nchunks, g.plan, g.nmt, g.T, ablate,
                            g.grid, fj);
     else
         hipLaunchKernelGGL(gram_partial_kernel<false>, grid, dim3(kThreads), 0, stream, Xb, n, ld, (int)d, shift,
-                           ws.partial[buf], ws.colsum_partial[buf], dp, g.nchunks, g.chunk_rows, g.nmt, g.T, ablate,
+                           ws.partial[buf], ws.colsum_partial[buf], dp, g.nchunks, g.plan, g.nmt, g.T, ablate,
                            g.grid, fj);
-    if (trace_buf && getenv("GS_GRAM_TRACE_DUMP")) {
-        // debug only (synchronises): mean s_memtime deltas of this launch's compute workgroups, relative to each
-        // workgroup's own start; slots: 0 start, 1 first tile staged, 2+s end of stage s, 14 slab written
-        (void)hipStreamSynchronize(stream);
-        static std::vector<unsigned long long> h(16 * 4096);
-        (void)hipMemcpy(h.data(), trace_buf, sizeof(unsigned long long) * 16 * g.grid, hipMemcpyDeviceToHost);
-        (void)hipMemset(trace_buf, 0, sizeof(unsigned long long) * 16 * 4096);
-        unsigned long long first = ~0ull, last = 0;
-        double sum[16] = {0};
-        int cnt[16] = {0};
-        for (int b = 0; b < g.grid; ++b) {
-            const unsigned long long s0 = h[b * 16];
-            if (!s0) continue;
-            if (s0 < first) first = s0;
-            if (h[b * 16 + 14] > last && h[b * 16 + 14] < s0 + 100000000ull) last = h[b * 16 + 14];
-            for (int q = 1; q < 15; ++q)
-                if (h[b * 16 + q] > s0) {
-                    sum[q] += (double)(h[b * 16 + q] - s0);
-                    cnt[q]++;
-                }
-        }
-        fprintf(stderr, "[gram trace] span first-start..last-end %.0f ticks; mean ticks since own start:",
-                (double)(last - first));
-        for (int q = 1; q < 15; ++q)
-            if (cnt[q]) fprintf(stderr, " s%d=%.0f(n=%d)", q, sum[q] / cnt[q], cnt[q]);
-        fprintf(stderr, "\n");
-    }
+    dump_trace(trace_buf, g.grid, stream);
 }
 
 static FoldJob pending_job(const GramWorkspace &ws, double *G64, double *S1) {

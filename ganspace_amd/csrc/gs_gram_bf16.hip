@@ -1,0 +1,372 @@
+// Split-precision X^T X on the bf16 matrix cores (gfx950), opt-in: GS_PREC_BF16X3 / GS_PREC_BF16X6.
+//
+// The exact-f32 MFMA (gs_gram.hip) runs at 1/16 of the bf16 MFMA rate, which makes the Gram update
+// MFMA-bound at d = 512.  Here every float32 element is split on the fly into bf16 terms,
+//     x = hi + mid + lo      (8 + 8 + 8 significant bits: exact for normal float32),
+// and the product x*y is rebuilt from bf16 MFMAs with float32 accumulation:
+//     BF16X6:  hi*hi + hi*mid + mid*hi + hi*lo + lo*hi + mid*mid   (dropped terms <= 2^-24 |xy|: float32 class)
+//     BF16X3:  hi*hi + hi*mid + mid*hi                             (dropped terms <= 2^-16 |xy|)
+// i.e. 6/16 resp. 3/16 of the f32-MFMA time per product.  Same work decomposition, slab format, fused column
+// sums, shift subtraction and piggy-backed fold as the f32 kernel; what differs:
+//   * v_mfma_f32_32x32x16_bf16 wants 8 CONSECUTIVE k (= rows of X) per lane for a fixed column, i.e. the
+//     transpose of the row-major activation block.  Each thread therefore loads a column strip (8 rows of one
+//     column; lanes = consecutive columns, so a wave still reads 256 contiguous bytes per row), splits it
+//     and writes one 16-byte vector per plane into a column-major LDS image [plane][panel][col][k];
+//   * column rows are padded 64 -> 80 bytes: the 16-lane groups of ds_read_b128 (fragment reads) and of
+//     ds_write_b128 (staging) then hit distinct banks;
+//   * 4 waves x (64 x 64) per workgroup: one fragment read feeds 2 x NPROD MFMAs, which keeps the LDS read rate
+//     (<= 85 B/clk/CU) under the ds_read_b128 peak;
+//   * software pipeline with two stages of global loads in flight.
+// Measured limit (profiles/): with the matrix work this cheap the kernel is bound by the L2 -> CU path -
+// every panel is fetched by the 4 macro tiles that use it, ~50 GB/s per CU - not by MFMA issue: dedicating
+// separate load/split waves (wave specialisation), deeper prefetch and wider loads were tried and did not help.
+#include <cstdlib>
+#include <type_traits>
+
+#include "gs_common.h"
+#include "gs_gram_internal.h"
+
+namespace gs {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
+
+constexpr int kBThreads = 256;
+constexpr int kBK = 32;                       // rows per LDS stage (two k16 MFMA steps)
+constexpr int kColBytes = 80;                 // 32 bf16 (64 B) + 16 B pad per column
+constexpr int kPanelBytes = kMacroTile * kColBytes;
+constexpr int kOutStride = 68;                // floats per row of a wave's 64 x 64 output tile in LDS (epilogue)
+
+// 8 float32 (consecutive rows of one column) -> NPL planes of 8 bf16 each.  v_cvt_pk_bf16_f32 rounds to nearest
+// even and packs two rows per dword - already the operand order of the MFMA; the remainder x - bf16(x) is exact
+// in float32, so after three planes nothing is left of a normal float32.
+template <int NPL>
+__device__ __forceinline__ void split8(const float (&v)[8], uint4 (&planes)[NPL]) {
+    float rem[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) rem[r] = v[r];
+#pragma unroll
+    for (int p = 0; p < NPL; ++p) {
+        unsigned w[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x2 pr = {rem[2 * q], rem[2 * q + 1]};
+            const unsigned u = __builtin_bit_cast(unsigned, __builtin_convertvector(pr, bf16x2));
+            w[q] = u;
+            if (p + 1 < NPL) {
+                rem[2 * q] -= __uint_as_float(u << 16);
+                rem[2 * q + 1] -= __uint_as_float(u & 0xFFFF0000u);
+            }
+        }
+        planes[p] = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+}
+
+// One fetch set = the 32 rows x (1 column of panel A, 1 of panel B) a thread stages per LDS stage.
+struct FetchSet {
+    float a[2][8], b[2][8];
+};
+
+template <int NPROD, bool DIAG, int ABL>
+__device__ __forceinline__ void gram_bf16_body(const float *__restrict__ X, int64_t rows, int64_t ld, int d,
+                                               const float *__restrict__ shift, float *__restrict__ P,
+                                               float *__restrict__ CS, int dp, int chunk, int64_t r0, int64_t r1, int I,
+                                               int J, unsigned char *lds, unsigned long long *trace) {
+#ifdef GS_GRAM_ABLATE_BUILD
+    auto stamp = [&](int slot) {
+        if (trace != nullptr && threadIdx.x == 0) trace[(int64_t)blockIdx.x * 16 + slot] = __builtin_amdgcn_s_memtime();
+    };
+#else
+    auto stamp = [&](int) {};
+#endif
+    stamp(0);
+    constexpr int NPL = (NPROD == 3) ? 2 : 3;
+    constexpr int kStageBytes = NPL * 2 * kPanelBytes;       // [plane][panel A|B][128 cols][80 B]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wi = wave >> 1, wj = wave & 1;
+    // sub-tile (a, b) of this wave's 64 x 64 tile is needed unless it lies strictly below the diagonal
+    auto need = [&](int a, int bb) { return !DIAG || (wi * 2 + a <= wj * 2 + bb); };
+    const bool active = !DIAG || wi <= wj;
+
+    // staging: thread -> (column, row group); it handles groups rg and rg + 2 of the 4 groups of 8 rows per stage
+    const int col = tid & 127, rg = tid >> 7;
+    const int colA = I * kMacroTile + col, colB = J * kMacroTile + col;
+    const bool okA = colA < d, okB = colB < d;
+    const bool ragged_cols = (I + 1) * kMacroTile > d || (J + 1) * kMacroTile > d;   // workgroup-uniform
+    const float shA = shift[colA], shB = shift[colB];
+    const float *Xa = X + (okA ? colA : d - 1);
+    const float *Xb = X + (okB ? colB : d - 1);
+    float cs = 0.f;
+
+    // safe = false_type: the 32 rows exist in X (fetch) / all lie inside the chunk and every column of the tile
+    // exists (stash)
+    auto fetch = [&](FetchSet &f, int64_t rbase, auto safe) {
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const int64_t off = (rbase + (rg + 2 * g) * 8) * ld;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                int64_t o = off + r * ld;
+                if (decltype(safe)::value) {
+                    int64_t row = rbase + (rg + 2 * g) * 8 + r;
+                    row = row < r1 ? row : r1 - 1;
+                    o = row * ld;
+                }
+                if (ABL == 3) {
+                    f.a[g][r] = shA + (float)r;
+                    if (!DIAG) f.b[g][r] = shB + (float)r;
+                    continue;
+                }
+                f.a[g][r] = Xa[o];
+                if (!DIAG) f.b[g][r] = Xb[o];
+            }
+        }
+    };
+    auto put = [&](unsigned char *dst, const float (&v)[8]) {
+        uint4 pl[NPL];
+        if (ABL == 2) {
+#pragma unroll
+            for (int p = 0; p < NPL; ++p)
+                pl[p] = make_uint4(__float_as_uint(v[0]) + p, __float_as_uint(v[2]), __float_as_uint(v[4]),
+                                   __float_as_uint(v[6]) ^ __float_as_uint(v[1] + v[3] + v[5] + v[7]));
+        } else {
+            split8<NPL>(v, pl);
+        }
+#pragma unroll
+        for (int p = 0; p < NPL; ++p) *reinterpret_cast<uint4 *>(dst + p * 2 * kPanelBytes) = pl[p];
+    };
+    auto stash = [&](const FetchSet &f, int buf, int64_t rbase, auto safe) {
+        unsigned char *base = lds + buf * kStageBytes + col * kColBytes;
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const int grp = rg + 2 * g;
+            float va[8], vb[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                if (decltype(safe)::value) {
+                    const bool rowok = rbase + grp * 8 + r < r1;
+                    va[r] = (rowok && okA) ? f.a[g][r] - shA : 0.f;
+                    if (!DIAG) vb[r] = (rowok && okB) ? f.b[g][r] - shB : 0.f;
+                } else {
+                    va[r] = f.a[g][r] - shA;
+                    if (!DIAG) vb[r] = f.b[g][r] - shB;
+                }
+                if (DIAG) cs += va[r];
+            }
+            put(base + grp * 16, va);
+            if (!DIAG) put(base + kPanelBytes + grp * 16, vb);
+        }
+    };
+
+    f32x16 acc[2][2] = {{{0}, {0}}, {{0}, {0}}};
+    const int fragA = (wi * 64 + (lane & 31)) * kColBytes + (lane >> 5) * 16;
+    const int fragB = (DIAG ? 0 : kPanelBytes) + (wj * 64 + (lane & 31)) * kColBytes + (lane >> 5) * 16;
+    // one k16 step of the stage in LDS buffer `buf`: fragments of every plane, then the NPROD plane products
+    auto mma_step = [&](int buf, int ks) {
+        if (ABL == 1) return;
+        const unsigned char *base = lds + buf * kStageBytes + ks * 32;
+        bf16x8 A[NPL][2], B[NPL][2];
+#pragma unroll
+        for (int p = 0; p < NPL; ++p)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                if (ABL == 4) {      // matrix pipe only: fragments from registers
+                    const float fv = (float)(buf + ks + p + q);
+                    const uint4 u = make_uint4(__float_as_uint(fv), lane, 3u, 5u);
+                    A[p][q] = __builtin_bit_cast(bf16x8, u);
+                    B[p][q] = __builtin_bit_cast(bf16x8, u);
+                    continue;
+                }
+                A[p][q] = *reinterpret_cast<const bf16x8 *>(base + p * 2 * kPanelBytes + fragA + q * 32 * kColBytes);
+                B[p][q] = *reinterpret_cast<const bf16x8 *>(base + p * 2 * kPanelBytes + fragB + q * 32 * kColBytes);
+            }
+        // plane 0 = leading bf16 term, 1 = second, 2 = third; smallest products first, and consecutive MFMAs
+        // go to different accumulators
+        constexpr int PA6[6] = {1, 0, 2, 1, 0, 0}, PB6[6] = {1, 2, 0, 0, 1, 0};
+        constexpr int PA3[3] = {1, 0, 0}, PB3[3] = {0, 1, 0};
+#pragma unroll
+        for (int t = 0; t < NPROD; ++t) {
+            const int pa = (NPROD == 3) ? PA3[t % 3] : PA6[t];
+            const int pb = (NPROD == 3) ? PB3[t % 3] : PB6[t];
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int bb = 0; bb < 2; ++bb)
+                    if (need(a, bb))
+                        acc[a][bb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[pa][a], B[pb][bb], acc[a][bb], 0, 0, 0);
+        }
+    };
+
+    using Safe = std::true_type;
+    using Fast = std::false_type;
+    const int64_t nrows = r1 - r0;
+    const int nst = (int)((nrows + kBK - 1) / kBK);
+    const int nfull = ragged_cols ? 0 : (int)(nrows / kBK);          // complete stages: the Fast path may stash them
+    // the Fast fetch only needs its 32 rows to exist in X (rows past r1 belong to the next chunk and are never
+    // used: a stage that is not complete is stashed by the Safe path, which masks them)
+    const int nfetch = (int)((rows - r0) / kBK);
+
+    // Software pipeline, two stages of global loads in flight:
+    //   iteration s:  issue loads of stage s+2 -> set s&1 | MFMA on stage s (LDS buffer s&1)
+    //                 | split + write stage s+1 (set (s+1)&1, loaded one iteration ago) -> LDS buffer (s+1)&1
+    FetchSet f0, f1;
+    fetch(f0, r0, Safe{});
+    if (nst > 1) fetch(f1, r0 + kBK, Safe{});
+    stash(f0, 0, r0, Safe{});
+    __syncthreads();
+    stamp(1);
+    int s = 0;
+    auto steady = [&](FetchSet &fnext2, const FetchSet &fnext1) {      // needs s + 1 < nfull and s + 2 < nfetch
+        const int buf = s & 1;
+        fetch(fnext2, r0 + (int64_t)(s + 2) * kBK, Fast{});
+        if (active) {
+            mma_step(buf, 0);
+            mma_step(buf, 1);
+        }
+        stash(fnext1, buf ^ 1, r0 + (int64_t)(s + 1) * kBK, Fast{});
+        __syncthreads();
+        ++s;
+    };
+    while (s + 2 < nfull && s + 3 < nfetch) {
+        steady(f0, f1);
+        steady(f1, f0);
+    }
+    if (s + 1 < nfull && s + 2 < nfetch) steady(f0, f1);
+    stamp(2);
+    auto generic = [&](FetchSet &fnext2, const FetchSet &fnext1) {
+        const int buf = s & 1;
+        if (s + 2 < nst) fetch(fnext2, r0 + (int64_t)(s + 2) * kBK, Safe{});
+        if (active) {
+            mma_step(buf, 0);
+            if (nrows - (int64_t)s * kBK > 16) mma_step(buf, 1);
+        }
+        if (s + 1 < nst) stash(fnext1, buf ^ 1, r0 + (int64_t)(s + 1) * kBK, Safe{});
+        __syncthreads();
+        ++s;
+    };
+    while (s < nst) {
+        if (s & 1)
+            generic(f1, f0);
+        else
+            generic(f0, f1);
+    }
+    stamp(3);
+
+    // ---- epilogue: the wave's 64 x 64 tile goes through LDS so that it leaves as 256-byte row segments --------
+    // (16 float4 stores per lane instead of 64 scalar ones, whose address/data registers the compiler recycles
+    // behind s_waitcnt: measured 5.2k -> ~1k clk)
+    if (active) {
+        float *t = reinterpret_cast<float *>(lds) + wave * (64 * kOutStride);
+        const int c = lane & 31, h = lane >> 5;
+        if (DIAG && wi == wj) {
+            // The products of a sub-tile ON the diagonal are accumulated in an order that is not symmetric under
+            // i <-> j (hi*mid before mid*hi): mirror its upper triangle so the slab is exactly symmetric.
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) t[((r & 3) + 8 * (r >> 2) + 4 * h) * 33 + c] = acc[a][a][r];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+                    const float m = t[c * 33 + row];
+                    if (row > c) acc[a][a][r] = m;
+                }
+            }
+        }
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int bb = 0; bb < 2; ++bb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    t[(a * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * kOutStride + bb * 32 + c] = acc[a][bb][r];
+        // sub-tiles below the diagonal of a diagonal macro tile hold zeros; nobody reads those slab cells
+        const int lr = lane >> 4, lc = (lane & 15) * 4;
+        float *dst = P + (int64_t)chunk * dp * dp + (int64_t)(I * kMacroTile + wi * 64 + lr) * dp + J * kMacroTile +
+                     wj * 64 + lc;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const float4 v = *reinterpret_cast<const float4 *>(t + (lr + 4 * k) * kOutStride + lc);
+            *reinterpret_cast<float4 *>(dst + (int64_t)(4 * k) * dp) = v;
+        }
+    }
+    stamp(14);
+    // ---- column sums of panel I (diagonal macro tiles; two row-group threads per column) -----------------------
+    if (DIAG) {
+        float *scr = reinterpret_cast<float *>(lds + 4 * 64 * kOutStride * sizeof(float));
+        scr[rg * kMacroTile + col] = cs;
+        __syncthreads();
+        if (tid < kMacroTile) CS[(int64_t)chunk * dp + I * kMacroTile + tid] = scr[tid] + scr[kMacroTile + tid];
+    }
+}
+
+template <int NPROD, int ABL>
+__global__ __launch_bounds__(kBThreads, 1) void gram_bf16_kernel(
+    const float *__restrict__ X, int64_t rows, int64_t ld, int d, const float *__restrict__ shift,
+    float *__restrict__ P, float *__restrict__ CS, int dp, int nchunks, ChunkPlan plan, int nmt, int T,
+    int ncompute, FoldJob fold) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];  // [2 buffers][NPL][2][128][80]
+    if ((int)blockIdx.x >= ncompute) {
+        fold_elements(fold.P, fold.CS, fold.G64, fold.S1, dp, fold.nchunks, fold.T32, fold.ntiles, fold.accumulate,
+                      (int)blockIdx.x - ncompute, (int)gridDim.x - ncompute, kBThreads);
+        return;
+    }
+    const int b = blockIdx.x;
+    const int xcd = b & 7, local = b >> 3;
+    const int chunk = (local / nmt) * 8 + xcd;
+    if (chunk >= nchunks) return;
+    int I, J;
+    decode_upper(local % nmt, T, I, J);
+    int64_t r0, r1;
+    chunk_range(plan, chunk, rows, r0, r1);
+    if (I == J)
+        gram_bf16_body<NPROD, true, ABL>(X, rows, ld, d, shift, P, CS, dp, chunk, r0, r1, I, J, lds, fold.trace);
+    else
+        gram_bf16_body<NPROD, false, ABL>(X, rows, ld, d, shift, P, CS, dp, chunk, r0, r1, I, J, lds, fold.trace);
+}
+
+template <int NPROD, int ABL>
+static int launch_variant(size_t lds_bytes, int grid, int nfold, const float *X, int64_t n, int64_t ld, int d,
+                          const float *shift, float *P, float *CS, int dp, int nchunks, ChunkPlan plan, int nmt, int T,
+                          const FoldJob &fold, hipStream_t stream) {
+    static bool attr = false;
+    if (!attr) {
+        GS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gram_bf16_kernel<NPROD, ABL>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        attr = true;
+    }
+    hipLaunchKernelGGL((gram_bf16_kernel<NPROD, ABL>), dim3((unsigned)(grid + nfold)), dim3(kBThreads), lds_bytes, stream,
+                       X, n, ld, d, shift, P, CS, dp, nchunks, plan, nmt, T, grid, fold);
+    return GS_OK;
+}
+
+int launch_gram_bf16(int precision, int grid, int nfold, const float *X, int64_t n, int64_t ld, int d,
+                     const float *shift, float *P, float *CS, int dp, int nchunks, ChunkPlan plan, int nmt, int T,
+                     const FoldJob &fold, hipStream_t stream) {
+    const int npl = (precision == GS_PREC_BF16X3) ? 2 : 3;
+    const size_t lds_bytes = (size_t)2 * npl * 2 * kPanelBytes;
+#define GS_BF16_ARGS lds_bytes, grid, nfold, X, n, ld, d, shift, P, CS, dp, nchunks, plan, nmt, T, fold, stream
+#ifdef GS_GRAM_ABLATE_BUILD
+    // measurement builds only (results are wrong): 1 no MFMA/LDS reads, 2 no split, 3 no global loads, 4 MFMA from registers
+    static const int ablate = []() {
+        const char *e = getenv("GS_GRAM_ABLATE");
+        return e ? atoi(e) : 0;
+    }();
+    if (precision == GS_PREC_BF16X3) {
+        switch (ablate) {
+            case 1: return launch_variant<3, 1>(GS_BF16_ARGS);
+            case 2: return launch_variant<3, 2>(GS_BF16_ARGS);
+            case 3: return launch_variant<3, 3>(GS_BF16_ARGS);
+            case 4: return launch_variant<3, 4>(GS_BF16_ARGS);
+            default: break;
+        }
+    }
+#endif
+    if (precision == GS_PREC_BF16X3) return launch_variant<3, 0>(GS_BF16_ARGS);
+    return launch_variant<6, 0>(GS_BF16_ARGS);
+#undef GS_BF16_ARGS
+}
+
+}  // namespace gs

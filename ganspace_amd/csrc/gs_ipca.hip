@@ -379,7 +379,10 @@ int gs_ipca_create(int64_t d, int k, int mode, int precision, int device, gs_ipc
     *out = nullptr;
     GS_REQUIRE(mode == GS_MODE_EXACT || mode == GS_MODE_FAITHFUL || mode == GS_MODE_SMALLSIDE, GS_EINVAL,
                "gs_ipca_create: bad mode");
-    GS_REQUIRE(precision == GS_PREC_F32, GS_ENOTIMPL, "gs_ipca_create: only GS_PREC_F32 is implemented");
+    GS_REQUIRE(precision == GS_PREC_F32 || precision == GS_PREC_BF16X3 || precision == GS_PREC_BF16X6, GS_ENOTIMPL,
+               "gs_ipca_create: unknown precision (GS_PREC_F32 / GS_PREC_BF16X3 / GS_PREC_BF16X6)");
+    GS_REQUIRE(precision == GS_PREC_F32 || mode != GS_MODE_SMALLSIDE, GS_ENOTIMPL,
+               "gs_ipca_create: the split-bf16 contraction is implemented for the Gram-side modes only");
     if (mode == GS_MODE_SMALLSIDE) {
         GS_REQUIRE(d >= 4 && d <= ((int64_t)1 << 21), GS_EINVAL, "gs_ipca_create: feature dim out of range");
         GS_REQUIRE(d % 4 == 0, GS_ENOTIMPL, "gs_ipca_create: small-side mode needs feat_dim % 4 == 0");
@@ -428,6 +431,7 @@ int gs_ipca_create(int64_t d, int k, int mode, int precision, int device, gs_ipc
         return GS_OK;
     }
     rc = gram_workspace_alloc(h->gws, d);
+    h->gws.precision = precision;
     if (rc == GS_OK) rc = eigh_workspace_alloc(h->ews, (int)d + 2);
     if (rc == GS_OK && subspace_dim((int)d, k) > 0) rc = subspace_workspace_alloc(h->sws, (int)d, subspace_dim((int)d, k));
     h->dp = h->gws.dp;
@@ -645,12 +649,19 @@ int gs_ipca_components_device(gs_ipca_t *h, const float **components, const floa
 
 int gs_gram_accumulate(const float *X, int64_t rows, int64_t ld, int64_t d, const float *shift, double *G,
                        double *colsum, void *stream_) {
+    return gs_gram_accumulate_prec(X, rows, ld, d, shift, G, colsum, GS_PREC_F32, stream_);
+}
+
+int gs_gram_accumulate_prec(const float *X, int64_t rows, int64_t ld, int64_t d, const float *shift, double *G,
+                            double *colsum, int precision, void *stream_) {
+    GS_REQUIRE(precision >= GS_PREC_F32 && precision <= GS_PREC_BF16X6, GS_EINVAL, "gs_gram_accumulate: bad precision");
     GS_REQUIRE(X && G && colsum, GS_EINVAL, "gs_gram_accumulate: NULL argument");
     GS_REQUIRE(d >= 1 && d <= 8192 && rows >= 0 && ld >= d, GS_EINVAL, "gs_gram_accumulate: bad shape");
     hipStream_t stream = (hipStream_t)stream_;
     GramWorkspace ws;
     int rc = gram_workspace_alloc(ws, d);
     if (rc != GS_OK) return rc;
+    ws.precision = precision;
     const int64_t dp = ws.dp;
     float *shp = nullptr;
     double *G64 = nullptr, *S1 = nullptr;

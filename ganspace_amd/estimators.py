@@ -41,7 +41,8 @@ class _DeviceIncrementalPCA:
 
     GRAM_SIDE_MAX_FEATURES = 8192
 
-    def __init__(self, n_components: int, mode: int, device=None):
+    def __init__(self, n_components: int, mode: int, device=None, precision: str = "f32"):
+        self._precision = _lib.PRECISIONS[precision]
         self.n_components = int(n_components)
         self.whiten = False
         self.batch_size = max(100, 2 * self.n_components)     # estimators.py:59
@@ -68,7 +69,7 @@ class _DeviceIncrementalPCA:
             # handled from the small side of the stacked matrix
             self._mode = _lib.GS_MODE_SMALLSIDE
         h = C.c_void_p()
-        _lib.check(self._lib.gs_ipca_create(d, self.n_components, self._mode, _lib.GS_PREC_F32,
+        _lib.check(self._lib.gs_ipca_create(d, self.n_components, self._mode, self._precision,
                                             self._device.index or 0, C.byref(h)))
         self._h, self._d = h, d
 
@@ -209,13 +210,13 @@ class _DeviceIncrementalPCA:
 class IPCAEstimator:
     """Drop-in for the reference ``IPCAEstimator`` (estimators.py:55-81)."""
 
-    def __init__(self, n_components, mode="faithful", device=None):
+    def __init__(self, n_components, mode="faithful", device=None, precision="f32"):
         self.n_components = n_components
         self.whiten = False
         self.mode = mode
         m = {"faithful": _lib.GS_MODE_FAITHFUL, "exact": _lib.GS_MODE_EXACT,
              "smallside": _lib.GS_MODE_SMALLSIDE}[mode]
-        self.transformer = _DeviceIncrementalPCA(n_components, m, device)
+        self.transformer = _DeviceIncrementalPCA(n_components, m, device, precision)
         self.batch_support = True
 
     def get_param_str(self):

@@ -21,7 +21,7 @@ def _need_cuda(*ts):
             raise RuntimeError("ganspace_amd ops need device tensors (no CPU fallback)")
 
 
-def gram_accumulate(X, G=None, colsum=None, shift=None):
+def gram_accumulate(X, G=None, colsum=None, shift=None, precision="f32"):
     """``G += (X-shift)^T (X-shift)`` (float64 ``[d,d]``), ``colsum += sum(X-shift)`` (float64 ``[d]``)."""
     import torch
     lib = _lib.load()
@@ -35,8 +35,8 @@ def gram_accumulate(X, G=None, colsum=None, shift=None):
     assert G.is_contiguous() and colsum.is_contiguous()
     if shift is not None:
         shift = shift.to(torch.float32).contiguous()
-    _lib.check(lib.gs_gram_accumulate(_p(X), rows, X.stride(0), d, _p(shift), _p(G), _p(colsum),
-                                      _lib.current_stream_ptr()))
+    _lib.check(lib.gs_gram_accumulate_prec(_p(X), rows, X.stride(0), d, _p(shift), _p(G), _p(colsum),
+                                           _lib.PRECISIONS[precision], _lib.current_stream_ptr()))
     return G, colsum
 
 

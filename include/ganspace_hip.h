@@ -53,9 +53,16 @@ enum {
  *                  Needs feat_dim % 4 == 0.                                                    */
 enum { GS_MODE_EXACT = 0, GS_MODE_FAITHFUL = 1, GS_MODE_SMALLSIDE = 2 };
 
-/* Arithmetic of the X^T X contraction.  GS_PREC_F32 = exact-f32 MFMA
- * (v_mfma_f32_32x32x2_f32), f32 accumulate per row-chunk, f64 across chunks/blocks. */
-enum { GS_PREC_F32 = 0 };
+/* Arithmetic of the X^T X contraction (always f32 accumulate per row-chunk, f64 across
+ * chunks/blocks).
+ * GS_PREC_F32     exact-f32 MFMA (v_mfma_f32_32x32x2_f32): an fma chain per element.   [default]
+ * GS_PREC_BF16X6  every f32 element split into three bf16 terms, each product rebuilt from six
+ *                 v_mfma_f32_32x32x16_bf16: dropped terms <= 2^-24 |xy| - float32-class results
+ *                 at 6/16 of the f32-MFMA time.
+ * GS_PREC_BF16X3  two bf16 terms, three MFMAs: dropped terms <= 2^-16 |xy| with random sign
+ *                 (averaging out over the rows of a block); 3/16 of the f32-MFMA time.
+ * The split modes exist for the Gram-side modes (EXACT / FAITHFUL).                        */
+enum { GS_PREC_F32 = 0, GS_PREC_BF16X3 = 1, GS_PREC_BF16X6 = 2 };
 
 typedef struct gs_ipca gs_ipca_t;
 
@@ -120,6 +127,11 @@ int gs_ipca_components_device(gs_ipca_t *h, const float **components, const floa
  * sum is wanted.                                                                         */
 int gs_gram_accumulate(const float *X, int64_t rows, int64_t ld, int64_t d,
                        const float *shift, double *G, double *colsum, void *stream);
+
+/* gs_gram_accumulate with an explicit GS_PREC_* contraction mode. */
+int gs_gram_accumulate_prec(const float *X, int64_t rows, int64_t ld, int64_t d,
+                            const float *shift, double *G, double *colsum, int precision,
+                            void *stream);
 
 /* Measurement hook for bench.py: average duration in ms of the dominant kernel alone (the
  * partial X^T X MFMA kernel of gs_ipca_update, without the float64 fold), `iters`

@@ -65,6 +65,88 @@ def test_gram_accumulates_and_is_linear(dev):
     assert (Gb - G1).abs().max().item() <= 2e-6 * G1.abs().max().item()
 
 
+# ---- split-bf16 contraction modes (opt-in precision) ---------------------------------------------
+
+@pytest.mark.parametrize("rows,d,ld_extra", [(1, 4, 0), (17, 100, 3), (1000, 512, 0), (10000, 512, 0),
+                                             (2311, 640, 0), (4097, 96, 5)])
+@pytest.mark.parametrize("precision,tol", [("bf16x6", 3e-6), ("bf16x3", 6e-5)])
+def test_gram_split_bf16_matches_float64(dev, rows, d, ld_extra, precision, tol):
+    """x = hi + mid (+ lo) in bf16, products rebuilt from 3 / 6 bf16 MFMAs: dropped terms are 2^-16 / 2^-24 of
+    |x||y| per product, so the elementwise error is bounded on the Cauchy-Schwarz scale."""
+    from ganspace_amd import ops
+    rs = np.random.RandomState(rows + d)
+    Xh = (rs.standard_normal((rows, d + ld_extra)) * rs.uniform(0.2, 3.0, d + ld_extra) + 0.7).astype(np.float32)
+    X = torch.from_numpy(Xh).to(dev)[:, :d]
+    sh = (Xh[:, :d].mean(0) + 0.01).astype(np.float32)
+    G, cs = ops.gram_accumulate(X, shift=torch.from_numpy(sh).to(dev), precision=precision)
+    Xc = Xh[:, :d].astype(np.float64) - sh.astype(np.float64)
+    Gref = Xc.T @ Xc
+    scale = np.sqrt(np.outer(np.diag(Gref), np.diag(Gref)))
+    Gh = G.cpu().numpy()
+    assert np.abs((Gh - Gref) / scale).max() <= tol, np.abs((Gh - Gref) / scale).max()
+    np.testing.assert_allclose(cs.cpu().numpy(), Xc.sum(0), atol=2e-6 * np.abs(Xc).sum(0).max())
+    np.testing.assert_array_equal(Gh, Gh.T)
+
+
+def test_gram_split_bf16x6_is_float32_class(dev):
+    """The six-product mode is as close to the float64 Gram as the exact-f32 MFMA path (same slabs, same f64 fold)."""
+    from ganspace_amd import ops
+    rs = np.random.RandomState(11)
+    Xh = (rs.standard_normal((10000, 512)) * rs.uniform(0.1, 4.0, 512)).astype(np.float32)
+    X = torch.from_numpy(Xh).to(dev)
+    Gref = Xh.astype(np.float64).T @ Xh.astype(np.float64)
+    scale = np.sqrt(np.outer(np.diag(Gref), np.diag(Gref)))
+    e32 = np.abs((ops.gram_accumulate(X)[0].cpu().numpy() - Gref) / scale).max()
+    e6 = np.abs((ops.gram_accumulate(X, precision="bf16x6")[0].cpu().numpy() - Gref) / scale).max()
+    e3 = np.abs((ops.gram_accumulate(X, precision="bf16x3")[0].cpu().numpy() - Gref) / scale).max()
+    assert e6 <= max(2.0 * e32, 1e-6), (e32, e6)
+    assert e3 <= 6e-5, e3
+
+
+@pytest.mark.parametrize("name", ["d64_k8", "d512_k20", "d512_k80_nb10000", "d96_k12_bigmean"])
+@pytest.mark.parametrize("precision", ["bf16x6", "bf16x3"])
+def test_exact_mode_split_bf16_matches_exact_oracle(dev, golden_dir, name, precision):
+    from ganspace_amd.estimators import IPCAEstimator
+    case = gin.IPCA_CASES[name]
+    est = IPCAEstimator(case["k"], "exact", precision=precision)
+    for X in gin.ipca_blocks(case):
+        assert est.fit_partial(torch.from_numpy(X).to(dev)) is True
+    ex = O.exact_pca(gin.ipca_blocks(case), case["k"])
+    t = est.transformer
+    r = case["ncheck"]
+    cos = O.signed_cosines(t.components_[:r], ex["components_"][:r])
+    x6 = precision == "bf16x6"
+    assert cos.min() > 1 - (1e-6 if x6 else 2e-5), cos.min()
+    np.testing.assert_allclose(t.singular_values_[:r], ex["singular_values_"][:r], rtol=2e-5 if x6 else 2e-4)
+    np.testing.assert_allclose(t.mean_, ex["mean_"], atol=2e-6 * max(1.0, np.abs(ex["mean_"]).max()))
+    g = _golden(golden_dir, name)
+    top = min(20, max(1, case["k"] // 4))
+    assert np.abs(O.signed_cosines(t.components_[:top], g["components"][:top])).min() > 0.999
+
+
+@pytest.mark.parametrize("name", ["d512_k20", "d200_k200_ragged"])
+def test_faithful_mode_split_bf16x6_matches_reference_fixture(dev, golden_dir, name):
+    from ganspace_amd.estimators import IPCAEstimator
+    case = gin.IPCA_CASES[name]
+    g = _golden(golden_dir, name)
+    est = IPCAEstimator(case["k"], "faithful", precision="bf16x6")
+    for X in gin.ipca_blocks(case):
+        assert est.fit_partial(torch.from_numpy(X).to(dev)) is True
+    r = case["ncheck"]
+    cos = O.signed_cosines(est.transformer.components_[:r], g["components"][:r])
+    assert cos.min() > 1 - 5e-6, cos.min()
+    np.testing.assert_allclose(est.transformer.singular_values_[:r], g["singular_values"][:r], rtol=1e-4)
+
+
+def test_split_bf16_rejected_for_smallside(dev):
+    from ganspace_amd.estimators import IPCAEstimator
+    from ganspace_amd._lib import GanspaceHipError, GS_ENOTIMPL
+    est = IPCAEstimator(4, "smallside", precision="bf16x3")
+    with pytest.raises(GanspaceHipError) as e:
+        est.fit_partial(torch.randn(64, 128, device=dev))
+    assert e.value.code == GS_ENOTIMPL
+
+
 # ---- eigensolver -----------------------------------------------------------------------------
 
 @pytest.mark.parametrize("n,rank", [(8, 8), (64, 64), (129, 129), (200, 50), (512, 512)])
@@ -134,7 +216,9 @@ def test_faithful_mode_matches_gram_oracle_tightly(dev, name):
         orc.fit_partial(X)
     r = case["ncheck"]
     cos = O.signed_cosines(est.transformer.components_[:r], orc.transformer.components_[:r])
-    assert cos.min() > 1 - 1e-6
+    # float32 partial sums per row chunk (the chunk boundaries are a launch-geometry detail) against the oracle's
+    # float64 Gram: closely spaced tail components of the k = d case move by a few 1e-6
+    assert cos.min() > 1 - (3e-6 if name == "d200_k200_ragged" else 1e-6)
     np.testing.assert_allclose(est.transformer.singular_values_[:r], orc.transformer.singular_values_[:r], rtol=1e-4)
     np.testing.assert_allclose(est.transformer.mean_, orc.transformer.mean_,
                                atol=1e-6 * max(1.0, np.abs(orc.transformer.mean_).max()))
