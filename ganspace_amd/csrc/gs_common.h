@@ -93,7 +93,7 @@ struct SubspaceWorkspace {
     int n_cap = 0, p_cap = 0, pp = 0;
     double *Q = nullptr, *Y = nullptr, *Z = nullptr, *R = nullptr;  // [n][pp]
     double *H = nullptr, *B = nullptr, *U = nullptr;                // [pp][pp]
-    double *theta = nullptr;                                        // [2*pp + 8]: Ritz values | residuals | pivot floor
+    double *theta = nullptr;                                        // [3*pp + 16]: Ritz values | residuals | pivot floors | R-diagonal statistics
     double *Rm = nullptr;                                           // [pp][pp] Cholesky factor
     double *Dinv = nullptr;                                         // inverses of its 32 x 32 diagonal blocks
     EighWorkspace ews;

@@ -249,13 +249,97 @@ __global__ __launch_bounds__(64) void chol_diag_kernel(const double *__restrict_
 #pragma unroll
         for (int i = 0; i < kCB; ++i) {
             Dinv[i * kCB + c] = (dead_c || i >= nb || c >= nb) ? 0.0 : x[i];
-            if (i < nb && c < nb) Rm[(int64_t)(j0 + i) * ldh + j0 + c] = (i <= c) ? col[i] : 0.0;
+            // the diagonal block of Rm is only read by rdiag_stats_kernel: a dead pivot shows up there as 0
+            if (i < nb && c < nb) Rm[(int64_t)(j0 + i) * ldh + j0 + c] = (i < c || (i == c && !dead_c)) ? col[i] : 0.0;
         }
     }
 }
 
-// Qout <- orth(Y) by CholeskyQR with a blocked (32-wide) factorisation whose panel / trailing / back-
-// substitution steps are float64 GEMMs:  H = Y^T Y = R^T R,  Qout = Y R^-1.   Y is used as scratch.
+constexpr int kPanelMax = 256 - kCB;
+
+// Qout = Y R^-1, parallel over rows: a workgroup takes 16 rows and walks the column blocks,
+//   Q_J = (Y_J - sum_{I<J} Q_I R[I, J]) R_JJ^-1,
+// with the finished part of its Q rows in LDS; R and the block inverses come from L2.
+__global__ __launch_bounds__(512) void trsm_rows_kernel(const double *__restrict__ Y, double *__restrict__ Qout,
+                                                        int64_t ld, int n, int p, const double *__restrict__ Rm,
+                                                        const double *__restrict__ Dinv) {
+    __shared__ double Qs[16][256 + 1];
+    __shared__ double Ws[16][kCB + 1];
+    __shared__ double Rs[kPanelMax][kCB + 1];     // R[0:j0, J]: the block column above the diagonal block
+    __shared__ double Ds[kCB][kCB + 1];           // R_JJ^-1
+    const int ty = threadIdx.x >> 5, tx = threadIdx.x & 31;
+    const int row = blockIdx.x * 16 + ty;
+    for (int j0 = 0, J = 0; j0 < p; j0 += kCB, ++J) {
+        const int c = j0 + tx;
+        const double y = (row < n && c < p) ? Y[(int64_t)row * ld + c] : 0.0;
+        // stage this step's operands (independent loads, one round trip)
+        for (int t = ty; t < j0; t += 16) Rs[t][tx] = (c < p) ? Rm[(int64_t)t * ld + c] : 0.0;
+        const double *Dj = Dinv + (size_t)J * kCB * kCB;
+        Ds[ty][tx] = Dj[ty * kCB + tx];
+        Ds[ty + 16][tx] = Dj[(ty + 16) * kCB + tx];
+        __syncthreads();
+        double w = y, w2 = 0.0;
+        for (int t = 0; t + 1 < j0; t += 2) {
+            w -= Qs[ty][t] * Rs[t][tx];
+            w2 -= Qs[ty][t + 1] * Rs[t + 1][tx];
+        }
+        Ws[ty][tx] = w + w2;
+        __syncthreads();
+        double q = 0.0;
+#pragma unroll 8
+        for (int t = 0; t < kCB; ++t) q += Ws[ty][t] * Ds[t][tx];
+        Qs[ty][c] = q;
+        if (row < n && c < p) Qout[(int64_t)row * ld + c] = q;
+        __syncthreads();
+    }
+}
+
+// Diagonal of the last Cholesky factor, for the iteration schedule: out = {R_11, R_kk, R_pp*, max, min, #dead}
+// over the live (non-zero) pivots; R_pp* = the last live pivot.  After j products from an orthonormal basis whose
+// columns are roughly ordered, R_ii ~ lambda_i^j.
+__global__ __launch_bounds__(64) void rdiag_stats_kernel(const double *__restrict__ Rm, int64_t ld, int p, int k,
+                                                         double *__restrict__ out) {
+    const int lane = threadIdx.x;
+    double mx = 0.0, mn = 1e300, last = 0.0;
+    int dead = 0, last_idx = -1;
+    for (int i = lane; i < p; i += 64) {
+        const double v = Rm[(int64_t)i * ld + i];
+        if (v > 0.0) {
+            mx = v > mx ? v : mx;
+            mn = v < mn ? v : mn;
+            if (i > last_idx) {
+                last_idx = i;
+                last = v;
+            }
+        } else {
+            ++dead;
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        const double omx = __shfl_xor(mx, o), omn = __shfl_xor(mn, o), ol = __shfl_xor(last, o);
+        const int oi = __shfl_xor(last_idx, o), od = __shfl_xor(dead, o);
+        mx = omx > mx ? omx : mx;
+        mn = omn < mn ? omn : mn;
+        if (oi > last_idx) {
+            last_idx = oi;
+            last = ol;
+        }
+        dead += od;
+    }
+    if (lane == 0) {
+        out[0] = Rm[0];
+        out[1] = Rm[(int64_t)(k - 1) * ld + (k - 1)];
+        out[2] = last;
+        out[3] = mx;
+        out[4] = mn;
+        out[5] = (double)dead;
+    }
+}
+
+// Qout <- orth(Y) by CholeskyQR:  H = Y^T Y = R^T R (blocked, 32 wide: diagonal blocks in one wave, panel and
+// trailing updates as float64 GEMMs),  Qout = Y R^-1 (one row-parallel kernel).
+// (A single-workgroup fused factorisation was tried: 3 launches instead of 16, but 220 us against ~170 us - every
+// phase of it is a latency-bound dependent chain, and one CU does not hide that better than the launch queue.)
 static int cholqr(SubspaceWorkspace &ws, double *Y, double *Qout, int n, int p, hipStream_t stream) {
     const int64_t ld = ws.pp;
     double *H = ws.H, *Rm = ws.Rm;
@@ -272,11 +356,9 @@ static int cholqr(SubspaceWorkspace &ws, double *Y, double *Qout, int n, int p, 
             gemm_f64(rem, rem, nb, Rm + (int64_t)j0 * ld + j1, 1, ld, Rm + (int64_t)j0 * ld + j1, ld, 1,
                      H + (int64_t)j1 * ld + j1, ld, stream, -1.0, 1.0);
         }
-        // column block J of Q:  (Y_J - Q_{<J} R[<J, J]) R_JJ^-1
-        if (j0 > 0)
-            gemm_f64(n, nb, j0, Qout, ld, 1, Rm + j0, ld, 1, Y + j0, ld, stream, -1.0, 1.0);
-        gemm_f64(n, nb, nb, Y + j0, ld, 1, Dinv, kCB, 1, Qout + j0, ld, stream);
     }
+    hipLaunchKernelGGL(trsm_rows_kernel, dim3((unsigned)ceil_div(n, 16)), dim3(512), 0, stream, Y, Qout, ld, n, p, Rm,
+                       ws.Dinv);
     GS_HIP_CHECK(hipGetLastError());
     return GS_OK;
 }
@@ -345,7 +427,7 @@ int subspace_workspace_alloc(SubspaceWorkspace &ws, int n, int p) {
     if (rc == GS_OK) rc = alloc(&ws.H, ppp);
     if (rc == GS_OK) rc = alloc(&ws.B, ppp);
     if (rc == GS_OK) rc = alloc(&ws.U, ppp);
-    if (rc == GS_OK) rc = alloc(&ws.theta, 2 * (size_t)ws.pp + 8);
+    if (rc == GS_OK) rc = alloc(&ws.theta, 3 * (size_t)ws.pp + 16);
     if (rc == GS_OK) rc = alloc(&ws.Rm, ppp);
     if (rc == GS_OK) rc = alloc(&ws.Dinv, (size_t)(ws.pp / 16 + 1) * kCB * kCB);
     if (rc == GS_OK && hipMemset(ws.Rm, 0, sizeof(double) * ppp) != hipSuccess) rc = GS_EHIP;
@@ -391,29 +473,64 @@ int eigh_topk_subspace(SubspaceWorkspace &ws, const double *A, int n, int64_t ld
     const int max_mults = 200;
     // target: ||A v - theta v|| <= 1e-10 theta_1 for the k wanted pairs.  The angle error is residual / gap and
     // the PCA output is float32, so this is ~3 digits beyond what the caller can observe.
-    const double tol2 = 1e-20;
-    int mults = 0, next_rr = warm ? 4 : 12;
+    const double tol_rel = 1e-10, tol2 = tol_rel * tol_rel;
+    // Schedule.  The basis is re-orthonormalised (CholeskyQR) every `interval` products; the diagonal of R then
+    // tells (a) how fast the basis degenerates, cond growth per product g ~ (max R_ii / min R_ii)^(1/j): the next
+    // interval keeps g^interval below 1e6 (steep spectra - lambda_1/lambda_p up to ~1e7 in the fixtures - need
+    // every product or two, flat ones get away with four), and (b) the convergence rate of the k-th pair,
+    // rho ~ (R_pp / R_kk)^(1/j), hence how many products the residual target needs.  A cold start runs that many
+    // before its first (expensive: Jacobi on p x p) Rayleigh-Ritz step instead of probing every few products; a
+    // warm start (previous components) projects after 4.  A failed test extrapolates from the measured residual.
+    int mults = 0, interval = 2, next_rr = warm ? 4 : max_mults;
+    double rho = 0.0;
     *converged = 0;
-    std::vector<double> host(k + 1);
+    std::vector<double> host(k + 8);
+    double *stats = ws.theta + 3 * ws.pp + 8;     // 6 doubles behind the pivot floors
     while (true) {
-        // multiply by A until the next Rayleigh-Ritz step, re-orthonormalising every 2 products (steep
-        // spectra - lambda_1/lambda_p up to ~1e7 in the fixtures - lose the trailing basis columns otherwise)
-        int since_orth = 0;
-        while (mults < next_rr) {
-            gemm_f64(n, p, n, A, lda, 1, Q, ld, 1, Y, ld, stream);
-            std::swap(Q, Y);
-            ++mults;
-            if (++since_orth == 2 && mults < next_rr) {
-                rc = cholqr(ws, Q, Y, n, p, stream);
-                if (rc != GS_OK) return rc;
-                std::swap(Q, Y);
-                since_orth = 0;
+        // ---- power phase ---------------------------------------------------------------------------------
+        while (true) {
+            int j = interval;
+            if (next_rr > mults && next_rr - mults < 2 * j) {   // land on next_rr in one or two even steps
+                const int r = next_rr - mults;
+                j = r <= j ? r : (r + 1) / 2;
             }
+            if (mults + j > max_mults) j = max_mults - mults;
+            for (int i = 0; i < j; ++i) {
+                gemm_f64(n, p, n, A, lda, 1, Q, ld, 1, Y, ld, stream);
+                std::swap(Q, Y);
+                ++mults;
+            }
+            rc = cholqr(ws, Q, Y, n, p, stream);
+            if (rc != GS_OK) return rc;
+            std::swap(Q, Y);
+            hipLaunchKernelGGL(rdiag_stats_kernel, dim3(1), dim3(64), 0, stream, ws.Rm, ld, p, k, stats);
+            GS_HIP_CHECK(hipMemcpyAsync(host.data(), stats, sizeof(double) * 6, hipMemcpyDeviceToHost, stream));
+            GS_HIP_CHECK(hipStreamSynchronize(stream));
+            const double r1 = host[0], rk = host[1], rp = host[2], dmax = host[3], dmin = host[4];
+            const int ndead = (int)host[5];
+            if (j > 0 && dmin > 0.0 && dmax > dmin) {
+                const double g = pow(dmax / dmin, 1.0 / j);
+                int it = (int)floor(log(1e6) / log(g));
+                if (ndead > 0 && it >= interval) it = interval - 1;
+                interval = it < 1 ? 1 : (it > 4 ? 4 : it);
+            }
+            if (j > 0 && rk > 0.0 && rp > 0.0 && rp < rk && r1 >= rk) {
+                rho = pow(rp / rk, 1.0 / j);
+                if (!warm && mults >= 2) {
+                    const double pred = log(tol_rel * pow(r1 / rk, 1.0 / j)) / log(rho);
+                    int target = 2 * (int)floor(pred / 2.0) + 2;
+                    if (target < 4) target = 4;
+                    next_rr = target > max_mults ? max_mults : target;
+                }
+            } else if (!warm && next_rr == max_mults && mults >= 12) {
+                next_rr = mults;     // no usable estimate (rank-deficient / flat block): probe now
+            }
+            if (mults >= next_rr || mults >= max_mults) break;
         }
-        // CholeskyQR2 before projecting
+        // second CholeskyQR pass before projecting (CholeskyQR2)
         rc = cholqr(ws, Q, Y, n, p, stream);
-        if (rc == GS_OK) rc = cholqr(ws, Y, Q, n, p, stream);
         if (rc != GS_OK) return rc;
+        std::swap(Q, Y);
 
         // ---- Rayleigh-Ritz on span(Q) -------------------------------------------------------------
         gemm_f64(n, p, n, A, lda, 1, Q, ld, 1, Y, ld, stream);    // Y = A Q
@@ -443,7 +560,15 @@ int eigh_topk_subspace(SubspaceWorkspace &ws, const double *A, int n, int64_t ld
             break;
         }
         std::swap(Q, Z);  // continue from the Ritz basis (B stays nearly diagonal: warm Jacobi next time)
-        next_rr = mults + 4;
+        // products still needed: the worst residual shrinks by ~rho per product
+        int extra = 4;
+        if (rho > 0.0 && rho < 1.0 && th1 > 0.0 && worst > 0.0) {
+            const double need = log(tol_rel * th1 / sqrt(worst)) / log(rho);
+            extra = (int)ceil(need) + 1;
+            if (extra < 2) extra = 2;
+            if (extra > 16) extra = 16;
+        }
+        next_rr = mults + extra;
         if (next_rr > max_mults) next_rr = max_mults;
     }
     if (iters_out) *iters_out = mults;
