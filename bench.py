@@ -32,6 +32,7 @@ import torch
 D, NB, K_COMP = 512, 10_000, 80
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_HBM_GBS = 8000.0             # HBM3E spec
+PEAK_BF16_MFMA_TFLOPS = 2500.0    # dense bf16 MFMA peak (the 2:1-sparsity headline figure is not used)
 
 
 def log(*a):
@@ -221,6 +222,38 @@ def main():
                 cos[mode]["samples_per_s"] = round(nb * NB / (time.perf_counter() - t0), 1)
         out["cos_sim_vs_reference"] = cos
         out["vs_cpu_baseline"] = round(value / out["cpu_baseline"]["value"], 1)
+
+        # ---- opt-in split-bf16 contraction modes (precision="bf16x6" / "bf16x3"; the headline stays exact f32):
+        #      same job, same timed region; cos-sim against the same sklearn reference sample ------------------
+        if args.mode == "exact":
+            split = {}
+            for prec, nprod in (("bf16x6", 6), ("bf16x3", 3)):
+                e = IPCAEstimator(K_COMP, "exact", precision=prec)
+                for b in blocks[:nb]:
+                    e.fit_partial(b)
+                c = signed_cosines(e.get_components()[0], ref.components_)
+                e2 = IPCAEstimator(K_COMP, "exact", precision=prec)
+                e2.transformer._ensure(D)
+                run(e2, Wm)
+                e2 = IPCAEstimator(K_COMP, "exact", precision=prec)
+                e2.transformer._ensure(D)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                run(e2, K)
+                torch.cuda.synchronize()
+                job = time.perf_counter() - t0
+                ms = C.c_float(0)
+                rt = C.c_int64(0)
+                _lib.check(lib.gs_gram_kernel_time(e2.transformer._h, C.c_void_p(blocks[0].data_ptr()), NB, D, 50,
+                                                   C.cast(C.byref(ms), C.c_void_p), C.cast(C.byref(rt), C.c_void_p),
+                                                   _lib.current_stream_ptr()))
+                mfma_tf = nprod * rt.value * D * (D + 1) / (ms.value * 1e-3) / 1e12
+                split[prec] = {"samples_per_s": round(K * NB / job, 1), "gram_launch_us": round(ms.value * 1e3, 2),
+                               "bf16_mfma_TFLOPs_executed": round(mfma_tf, 1),
+                               "frac_of_bf16_dense_peak": round(mfma_tf / PEAK_BF16_MFMA_TFLOPS, 4),
+                               "top20_min_signed_cos": round(float(c[:20].min()), 7),
+                               "all80_min_abs_cos": round(float(np.abs(c).min()), 5)}
+            out["split_bf16_modes"] = split
 
     # ---- the wide-feature BASELINE shapes (cfg3 d = 32 768, cfg5 d = 131 072; NB = 2 000, k = 80): PCA-only
     #      throughput of the small-side recurrence on synthetic low-rank-plus-noise device buffers -----------

@@ -40,3 +40,36 @@ for sub in ("pmc_FETCH_SIZE", "pmc_WRITE_SIZE", "pmc_sq", "pmc_lds"):
             if c == "WRITE_SIZE":
                 note = f" KiB = {avg*1024/1e6:.2f} MB written"
             print(f"| `{k}` | {c} | {avg:.1f}{note} | {len(x)} |")
+
+# machine-readable companion for bench.py's roofline.traffic (written next to the summary when asked)
+if len(sys.argv) > 2:
+    import json
+    vals = {}
+    for sub in ("pmc_FETCH_SIZE", "pmc_WRITE_SIZE", "pmc_sq"):
+        p = os.path.join(root, sub, "p_counter_collection.csv")
+        if not os.path.exists(p):
+            continue
+        acc = collections.defaultdict(list)
+        for r in csv.DictReader(open(p)):
+            if "gram_partial_kernel" in r["Kernel_Name"]:
+                acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+        for c, x in acc.items():
+            vals[c] = (sum(x) / len(x), len(x))
+    fetch = vals.get("FETCH_SIZE", (0, 0))
+    write = vals.get("WRITE_SIZE", (0, 0))
+    out = {
+        "kernel": "gram_partial_kernel<true>", "rows_per_launch": 10000, "launches": fetch[1],
+        "FETCH_SIZE_KiB_raw": round(fetch[0], 1),
+        "hbm_read_bytes_per_launch_corrected_x2": int(fetch[0] * 2 * 1024),
+        "WRITE_SIZE_KiB_raw": round(write[0], 1), "hbm_write_bytes_per_launch": int(write[0] * 1024),
+        "note": "rocprofv3 --pmc passes on tools/gram_probe.py (separate passes per counter group; the probe launches "
+                "include the piggy-backed fold workgroups); FETCH_SIZE doubled per MI355X_MICROARCH.md HBM section",
+        "source": sys.argv[2],
+        "traffic_breakdown": "%.1f MB per launch = 20.5 MB of X rows (each fetched once: algorithmic 20.48 MB) + the "
+                             "piggy-backed fold's reads of the previous block's float32 slabs (%.1f MB written per "
+                             "launch, partly still L2/MALL-resident)" % (fetch[0] * 2 * 1024 / 1e6, write[0] * 1024 / 1e6),
+    }
+    for c in ("SQ_VALU_MFMA_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_BUSY_CYCLES"):
+        if c in vals:
+            out[c] = int(vals[c][0])
+    json.dump(out, open(os.path.join("profiles", "gram_pmc_latest.json"), "w"), indent=1)
