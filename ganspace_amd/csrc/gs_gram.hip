@@ -74,9 +74,11 @@ struct GramTileCtx {
     const float *X;
     int64_t ld, r0, r1;
     int d, dp, chunk, I, J;
+    int64_t rows_total;   // rows of X in this launch (extent of the buffer resource)
     float *P, *CS;
     const float *shift;
-    int ablate;  // profiling only: 1 = no MFMA, 2 = no global loads after the first stage, 3 = no epilogue
+    int ablate;  // profiling only, bit mask: 1 no MFMA, 2 no global loads after the first stage, 4 no split order,
+                 // 8 MFMA operands from registers (no LDS reads), 16 no stash (LDS writes), 32 no epilogue
     unsigned long long *trace;  // profiling only (GS_GRAM_TRACE): per-workgroup s_memtime stamps, 16 per WG
 };
 
@@ -88,6 +90,8 @@ struct GramTileCtx {
 // LDS latency (~200 cycles with 8 waves reading) once per k-step: measured 79 % matrix-pipe duty inside
 // the loop.  Here the operand reads of step k+1 are issued BEFORE the MFMAs of step k (inline-asm
 // ds_read_b32 with immediate offsets, counted s_waitcnt), so the latency hides behind the wave's own MFMAs.
+// Two steps of lookahead: while its SIMD partner converts / stores the next tile a wave issues alone, one
+// k-step is then only 128 clk of MFMA - about the LDS latency - and a single step of lookahead still stalled.
 template <int OFF>
 __device__ __forceinline__ float lds_read_off(unsigned addr) {
     float v;
@@ -97,18 +101,22 @@ __device__ __forceinline__ float lds_read_off(unsigned addr) {
 
 template <bool M0, bool M1, int K, int KS>
 struct MfmaPipe {
-    static __device__ __forceinline__ void run(unsigned aaddr, unsigned baddr, float a0, float a1, float b0,
-                                               f32x16 &acc0, f32x16 &acc1) {
+    // (a0, a1, b0): operands of step K (issued two steps ago); (p0, p1, pb): step K + 1, still in flight
+    static __device__ __forceinline__ void run(unsigned aaddr, unsigned baddr, float a0, float a1, float b0, float p0,
+                                               float p1, float pb, f32x16 &acc0, f32x16 &acc1) {
         constexpr int kStepBytes = 2 * kMacroTile * 4;  // one k-step = two rows of the stage
-        float na0 = 0.f, na1 = 0.f, nb0 = 0.f;
-        if (K + 1 < KS) {
-            if (M0) na0 = lds_read_off<(K + 1) * kStepBytes>(aaddr);
-            if (M1) na1 = lds_read_off<(K + 1) * kStepBytes + 128>(aaddr);
-            nb0 = lds_read_off<(K + 1) * kStepBytes>(baddr);
-            // the operands of THIS step were issued one step earlier: leave only the new reads outstanding
-            constexpr int pending = (M0 ? 1 : 0) + (M1 ? 1 : 0) + 1;
-            if (pending == 3) asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");
-            if (pending == 2) asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
+        constexpr int per = (M0 ? 1 : 0) + (M1 ? 1 : 0) + 1;   // LDS reads per k-step
+        float q0 = 0.f, q1 = 0.f, qb = 0.f;
+        if (K + 2 < KS) {
+            if (M0) q0 = lds_read_off<(K + 2) * kStepBytes>(aaddr);
+            if (M1) q1 = lds_read_off<(K + 2) * kStepBytes + 128>(aaddr);
+            qb = lds_read_off<(K + 2) * kStepBytes>(baddr);
+            // steps K + 1 and K + 2 may stay outstanding; step K must have landed
+            if (per == 3) asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+            if (per == 2) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+        } else if (K + 1 < KS) {
+            if (per == 3) asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");
+            if (per == 2) asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
         } else {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
@@ -116,24 +124,31 @@ struct MfmaPipe {
         if (M0) acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc0, 0, 0, 0);
         if (M1) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc1, 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
-        MfmaPipe<M0, M1, K + 1, KS>::run(aaddr, baddr, na0, na1, nb0, acc0, acc1);
+        MfmaPipe<M0, M1, K + 1, KS>::run(aaddr, baddr, p0, p1, pb, q0, q1, qb, acc0, acc1);
     }
 };
 template <bool M0, bool M1, int KS>
 struct MfmaPipe<M0, M1, KS, KS> {
-    static __device__ __forceinline__ void run(unsigned, unsigned, float, float, float, f32x16 &, f32x16 &) {}
+    static __device__ __forceinline__ void run(unsigned, unsigned, float, float, float, float, float, float, f32x16 &,
+                                               f32x16 &) {}
 };
 
 template <bool M0, bool M1, int KS>
 __device__ __forceinline__ void mfma_steps(const float *__restrict__ A, const float *__restrict__ B,
                                            f32x16 &acc0, f32x16 &acc1) {
     // LDS byte addresses of this lane's first operands (generic -> LDS address space: low 32 bits)
+    constexpr int kStepBytes = 2 * kMacroTile * 4;
     const unsigned aaddr = (unsigned)(uintptr_t)A, baddr = (unsigned)(uintptr_t)B;
-    float a0 = 0.f, a1 = 0.f;
+    float a0 = 0.f, a1 = 0.f, p0 = 0.f, p1 = 0.f, pb = 0.f;
     if (M0) a0 = lds_read_off<0>(aaddr);
     if (M1) a1 = lds_read_off<128>(aaddr);
     const float b0 = lds_read_off<0>(baddr);
-    MfmaPipe<M0, M1, 0, KS>::run(aaddr, baddr, a0, a1, b0, acc0, acc1);
+    if (KS > 1) {
+        if (M0) p0 = lds_read_off<kStepBytes>(aaddr);
+        if (M1) p1 = lds_read_off<kStepBytes + 128>(aaddr);
+        pb = lds_read_off<kStepBytes>(baddr);
+    }
+    MfmaPipe<M0, M1, 0, KS>::run(aaddr, baddr, a0, a1, b0, p0, p1, pb, acc0, acc1);
 }
 
 template <bool M0, bool M1>
@@ -153,31 +168,28 @@ __device__ __forceinline__ void mfma_stage(const float *__restrict__ A, const fl
     }
 }
 
-// Main loop of one (macro tile, row chunk) workgroup: 8 waves = 2 per SIMD, so that one wave's
-// LDS waits / barrier arrivals are covered by its SIMD partner's MFMAs.  Wave (i, j) owns the
-// 64 x 32 strip at rows i*64, cols j*32 of the 128 x 128 macro tile.  DIAG is uniform per
-// workgroup and a template parameter so that the pipelined loop contains no control flow.
-template <bool VEC, bool DIAG>
-__device__ __forceinline__ void gram_tile(const GramTileCtx &c, float (*lds)[2][kKB][kMacroTile]) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // strip assignment.  Off-diagonal tiles: wave w -> (w >> 2, w & 3), both sub-tiles.
-    // Diagonal tiles: only the 10 sub-tiles on/above the diagonal are computed, dealt to the waves
-    // so that the two waves sharing a SIMD (w and w + 4) issue 3,3,2,2 MFMAs per k-step.
-    int wi, wj;
-    bool m0, m1;
-    if (!DIAG) {
-        wi = wave >> 2;
-        wj = wave & 3;
-        m0 = m1 = true;
-    } else {
-        const int tab_i[8] = {0, 1, 0, 1, 0, 0, 0, 0};
-        const int tab_j[8] = {0, 2, 3, 3, 1, 2, 0, 0};
-        const int tab_m[8] = {1, 1, 3, 3, 3, 3, 0, 0};  // bit0: sub-tile a=0, bit1: a=1
-        wi = tab_i[wave];
-        wj = tab_j[wave];
-        m0 = tab_m[wave] & 1;
-        m1 = tab_m[wave] & 2;
-    }
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+
+// Main loop of one (macro tile, row chunk) workgroup: 8 waves = 2 per SIMD, so that one wave's LDS waits, store
+// phase and barrier arrivals are covered by its SIMD partner's MFMAs.  Wave (i, j) owns the 64 x 32 strip at
+// rows i*64, cols j*32 of the 128 x 128 macro tile and computes sub-tile a = 0 (M0) and / or a = 1 (M1) of it.
+//
+// What the trace and ablation runs of the earlier versions showed (profiles/): the matrix pipe itself
+// runs at exactly 64 clk per v_mfma_f32_32x32x2_f32 in this wave layout (tools/ubench/mfma_ticks.hip), a partner
+// wave's VALU work does not slow it (mfma_valu_share.hip), yet a 64-row stage took ~11.1k clk instead of 8.2k.
+// The difference was vector-ALU work that sat BETWEEN the MFMA streams of a wave:
+//   * the compiler merged the accumulators of the different k-loop variants (full stage, short stage, ragged
+//     stage, diagonal-tile sub-tile masks) through register copies: 32-48 v_mov_b64 per wave per stage, each
+//     waiting on the matrix pipe to drain;
+//   * address arithmetic and clamps of the 8 global loads, and row / column masks of the 8 LDS stores, per thread
+//     per stage (~200 VALU instructions per wave).
+// This version gives the steady state ONE code path per wave - whole stages only, M0 / M1 compile-time (the caller
+// branches once per wave) - whose accumulators never leave their registers, loads through a buffer resource
+// (row offsets in SGPRs: no per-load VALU, rows past the end of X read as 0) and stores without masks; the short
+// first stage, the chunk's ragged last stage and tiles that straddle column d use the general code outside.
+template <bool VEC, bool DIAG, bool M0, bool M1>
+__device__ __forceinline__ void gram_tile(const GramTileCtx &c, float (*lds)[2][kKB][kMacroTile], int wi, int wj) {
+    const int tid = threadIdx.x, lane = tid & 63;
     const int c4 = tid & 31, rr = tid >> 5;  // 16 row groups x 32 float4 columns
     const int colA = c.I * kMacroTile + c4 * 4, colB = c.J * kMacroTile + c4 * 4;
     const float4 shA = *reinterpret_cast<const float4 *>(c.shift + colA);
@@ -185,28 +197,35 @@ __device__ __forceinline__ void gram_tile(const GramTileCtx &c, float (*lds)[2][
     const int d = c.d;
     const int64_t r1 = c.r1, ld = c.ld;
 
-    float4 ra[kLoadIters], rb[kLoadIters];
+    struct FetchRegs {
+        float4 a[kLoadIters], b[kLoadIters];
+    };
     float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
 
-    // NI row groups of 16 rows each, starting at rbase
-    auto fetch = [&](int64_t rbase, int ni) {
+    // ---- general path: clamped addresses, row / column masks (NI row groups of 16 rows from rbase) ----------
+    auto fetch = [&](FetchRegs &f, int64_t rbase, int ni) {
 #pragma unroll
         for (int i = 0; i < kLoadIters; ++i) {
             if (i < ni) {
-                ra[i] = load_raw<VEC>(c.X, rbase + rr + 16 * i, r1 - 1, ld, colA, d);
-                if (!DIAG) rb[i] = load_raw<VEC>(c.X, rbase + rr + 16 * i, r1 - 1, ld, colB, d);
+                f.a[i] = load_raw<VEC>(c.X, rbase + rr + 16 * i, r1 - 1, ld, colA, d);
+                if (!DIAG) f.b[i] = load_raw<VEC>(c.X, rbase + rr + 16 * i, r1 - 1, ld, colB, d);
             }
         }
     };
-    auto stash = [&](int buf, int64_t rbase, int ni) {
+    auto stash = [&](const FetchRegs &f, int buf, int64_t rbase, int ni) {
 #pragma unroll
         for (int i = 0; i < kLoadIters; ++i) {
             if (i < ni) {
                 const bool ok = rbase + rr + 16 * i < r1;
-                const float4 va = finish(ra[i], shA, ok, colA, d);
+                // opaque copies: the subtraction must not be computed before this point (the compiler otherwise
+                // hoists it - and the wait for the loads - above the MFMA stream)
+                float4 la = f.a[i], lb = f.b[i];
+                asm volatile("" : "+v"(la.x), "+v"(la.y), "+v"(la.z), "+v"(la.w));
+                if (!DIAG) asm volatile("" : "+v"(lb.x), "+v"(lb.y), "+v"(lb.z), "+v"(lb.w));
+                const float4 va = finish(la, shA, ok, colA, d);
                 *reinterpret_cast<float4 *>(&lds[buf][0][rr + 16 * i][c4 * 4]) = va;
                 if (!DIAG) {
-                    const float4 vb = finish(rb[i], shB, ok, colB, d);
+                    const float4 vb = finish(lb, shB, ok, colB, d);
                     *reinterpret_cast<float4 *>(&lds[buf][1][rr + 16 * i][c4 * 4]) = vb;
                 } else {
                     cs.x += va.x;
@@ -217,79 +236,117 @@ __device__ __forceinline__ void gram_tile(const GramTileCtx &c, float (*lds)[2][
             }
         }
     };
+    // ---- steady-state path: whole 64-row stages of a tile whose 128 columns all exist -----------------------
+    // buffer resource over the rows of this launch: the per-load row offset lives in an SGPR
+    const uint64_t xbytes = (uint64_t)c.rows_total * (uint64_t)ld * 4u;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(c.X), 0, xbytes > 0xFFFFFFFFull ? 0xFFFFFFFFu : (unsigned)xbytes, 0x00020000);
+    const unsigned voffA = (unsigned)(((int64_t)rr * ld + colA) * 4), voffB = (unsigned)(((int64_t)rr * ld + colB) * 4);
+    auto fetch_fast = [&](FetchRegs &f, int64_t rbase) {
+#pragma unroll
+        for (int i = 0; i < kLoadIters; ++i) {
+            const unsigned soff = (unsigned)((rbase + 16 * i) * ld * 4);
+            const u32x4 ua = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voffA, soff, 0);
+            f.a[i] = make_float4(__uint_as_float(ua.x), __uint_as_float(ua.y), __uint_as_float(ua.z), __uint_as_float(ua.w));
+            if (!DIAG) {
+                const u32x4 ub = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voffB, soff, 0);
+                f.b[i] = make_float4(__uint_as_float(ub.x), __uint_as_float(ub.y), __uint_as_float(ub.z), __uint_as_float(ub.w));
+            }
+        }
+    };
+    auto stash_fast = [&](const FetchRegs &f, int buf) {
+#pragma unroll
+        for (int i = 0; i < kLoadIters; ++i) {
+            float4 la = f.a[i], lb = f.b[i];
+            asm volatile("" : "+v"(la.x), "+v"(la.y), "+v"(la.z), "+v"(la.w));
+            if (!DIAG) asm volatile("" : "+v"(lb.x), "+v"(lb.y), "+v"(lb.z), "+v"(lb.w));
+            const float4 va = make_float4(la.x - shA.x, la.y - shA.y, la.z - shA.z, la.w - shA.w);
+            *reinterpret_cast<float4 *>(&lds[buf][0][rr + 16 * i][c4 * 4]) = va;
+            if (!DIAG) {
+                const float4 vb = make_float4(lb.x - shB.x, lb.y - shB.y, lb.z - shB.z, lb.w - shB.w);
+                *reinterpret_cast<float4 *>(&lds[buf][1][rr + 16 * i][c4 * 4]) = vb;
+            } else {
+                cs.x += va.x;
+                cs.y += va.y;
+                cs.z += va.z;
+                cs.w += va.w;
+            }
+        }
+    };
 
     auto stamp = [&](int slot) {
-        if (c.trace != nullptr && tid == 0) c.trace[(int64_t)blockIdx.x * 16 + slot] = __builtin_amdgcn_s_memtime();
+        if (c.trace != nullptr && tid == 0 && slot < 15) c.trace[(int64_t)blockIdx.x * 16 + slot] = __builtin_amdgcn_s_memtime();
     };
     stamp(0);
     f32x16 acc0 = {0}, acc1 = {0};
     const int64_t nrows = r1 - c.r0;
-    // stage 0 is short (16 rows): the matrix pipes start after a 16 KiB fetch per workgroup instead of a
-    // 64 KiB one (the whole grid's first fetch is otherwise ~16 MB before a single MFMA issues)
+    // Stage 0 is short (16 rows): the matrix pipes start after a 16 KiB fetch per workgroup instead of a 64 KiB
+    // one (the whole grid's first fetch is otherwise ~16 MB before a single MFMA issues).  Then nfull whole
+    // stages of 64 rows, then the rest (< 64 rows).
     constexpr int kFirst = 16;
     const int64_t first = nrows < kFirst ? nrows : kFirst;
-    const int nst = (nrows > 0) ? 1 + (int)((nrows - first + kKB - 1) / kKB) : 0;
+    const int nfull = (int)((nrows - first) / kKB);
+    const int rest = (int)(nrows - first - (int64_t)nfull * kKB);
+    const int nst = (nrows > 0 ? 1 : 0) + nfull + (rest > 0 ? 1 : 0);
+    const bool tile_full = VEC && (c.I + 1) * kMacroTile <= d && (c.J + 1) * kMacroTile <= d;   // workgroup-uniform
     const int arow = lane >> 5;
     const int acol = wi * 64 + (lane & 31);
     const int bcol = wj * 32 + (lane & 31);
+    auto stage_row = [&](int k) { return (k == 0) ? c.r0 : c.r0 + first + (int64_t)(k - 1) * kKB; };
+    auto stage_rows = [&](int k) { return (k == 0) ? (int)first : (k <= nfull ? kKB : rest); };
+    auto opA = [&](int buf) { return &lds[buf][0][arow][acol]; };
+    auto opB = [&](int buf) { return &lds[buf][DIAG ? 0 : 1][arow][bcol]; };
 
+    FetchRegs f;
     if (nst > 0) {
-        fetch(c.r0, 1);
-        stash(0, c.r0, 1);
+        fetch(f, c.r0, 1);
+        stash(f, 0, c.r0, 1);
     }
     __syncthreads();
     stamp(1);
-    for (int s = 0; s < nst; ++s) {
+    int s = 0;
+    // general iteration (any stage length): loads of stage s + 1 | MFMA on stage s | store stage s + 1
+    auto general = [&]() {
         const int buf = s & 1;
-        const int64_t rbase = (s == 0) ? c.r0 : c.r0 + first + (int64_t)(s - 1) * kKB;
-        const int64_t rnext = c.r0 + first + (int64_t)s * kKB;
-        if (s + 1 < nst && c.ablate != 2) fetch(rnext, kLoadIters);
-        int rows_here = (int)(r1 - rbase);
-        const int cap = (s == 0) ? kFirst : kKB;
-        if (rows_here > cap) rows_here = cap;
-        const int ksteps = (rows_here + 1) / 2;
-        const float *A = &lds[buf][0][arow][acol];
-        const float *B = &lds[buf][DIAG ? 0 : 1][arow][bcol];
-        // The two waves that share a SIMD (w and w + 4) run the stage in different orders so that one of
-        // them always has MFMAs to issue while the other converts / stores the next tile:
-        //   waves 0-3:  MFMA(all k-steps)            -> stash
-        //   waves 4-7:  MFMA(first half) -> stash -> MFMA(second half)
-        const bool split = (wave >= 4) && (s + 1 < nst) && c.ablate != 4;
-        const int kh = split ? ksteps / 2 : ksteps;
-        auto run = [&](const float *Ap, const float *Bp, int ks) {
-            if (c.ablate == 1) return;
-            if (c.ablate == 5) {  // profiling: MFMA stream with register operands (no LDS reads)
-                const float fa = (float)lane, fb = (float)wave;
-                for (int k = 0; k < ks; ++k) {
-                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa, fb, acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fb, fa, acc1, 0, 0, 0);
-                }
-                return;
-            }
-            if (m0 && m1)
-                mfma_stage<true, true>(Ap, Bp, ks, acc0, acc1);
-            else if (m0)
-                mfma_stage<true, false>(Ap, Bp, ks, acc0, acc1);
-        };
-        run(A, B, kh);
-        if (s + 1 < nst) stash(buf ^ 1, rnext, kLoadIters);
-        if (split) run(A + 2 * kh * kMacroTile, B + 2 * kh * kMacroTile, ksteps - kh);
+        const bool more = s + 1 < nst;
+        if (more && !(c.ablate & 2)) fetch(f, stage_row(s + 1), (stage_rows(s + 1) + 15) / 16);
+        __builtin_amdgcn_sched_barrier(0);
+        if ((M0 || M1) && !(c.ablate & 1)) mfma_stage<M0, M1>(opA(buf), opB(buf), (stage_rows(s) + 1) / 2, acc0, acc1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more && !(c.ablate & 16)) stash(f, buf ^ 1, stage_row(s + 1), (stage_rows(s + 1) + 15) / 16);
         __syncthreads();
-        if (s < 12) stamp(2 + s);
+        stamp(2 + s);
+        ++s;
+    };
+    if (nst > 0) general();                                   // stage 0 (and the loads / stores of stage 1)
+    if (tile_full) {
+        // whole stages whose successor is a whole stage too: stages 1 .. nfull - 1
+        while (s < nfull) {
+            const int buf = s & 1;
+            if (!(c.ablate & 2)) fetch_fast(f, stage_row(s + 1));
+            __builtin_amdgcn_sched_barrier(0);
+            if ((M0 || M1) && !(c.ablate & 1)) mfma_steps<M0, M1, kKB / 2>(opA(buf), opB(buf), acc0, acc1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (!(c.ablate & 16)) stash_fast(f, buf ^ 1);
+            __syncthreads();
+            stamp(2 + s);
+            ++s;
+        }
     }
+    while (s < nst) general();                                // last whole stage, ragged stage; partial-column tiles
 
     // ---- epilogue: 32x32 sub-tiles -> this chunk's float32 slab --------------------------------
-    if (c.ablate != 3 || c.r0 < 0) {
+    if (!(c.ablate & 32) || c.r0 < 0) {
         float *Pc = c.P + (int64_t)c.chunk * c.dp * c.dp;
         const int row_base = c.I * kMacroTile + wi * 64 + 4 * (lane >> 5);
         const int col = c.J * kMacroTile + wj * 32 + (lane & 31);
         const int64_t dp = c.dp;
-        if (m0) {
+        if (M0) {
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 Pc[(int64_t)(row_base + (r & 3) + 8 * (r >> 2)) * dp + col] = acc0[r];
         }
-        if (m1) {
+        if (M1) {
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 Pc[(int64_t)(row_base + 32 + (r & 3) + 8 * (r >> 2)) * dp + col] = acc1[r];
@@ -311,6 +368,28 @@ __device__ __forceinline__ void gram_tile(const GramTileCtx &c, float (*lds)[2][
             c.CS[(int64_t)c.chunk * c.dp + c.I * kMacroTile + tid] = t;
         }
     }
+}
+
+// strip assignment of the 8 waves.  Off-diagonal tiles: wave w -> (w >> 2, w & 3), both sub-tiles.  Diagonal
+// tiles: only the 10 sub-tiles on / above the diagonal are computed, dealt to the waves so that the two waves
+// sharing a SIMD (w and w + 4) issue 3, 3, 2, 2 MFMAs per k-step.
+template <bool VEC>
+__device__ __forceinline__ void gram_tile_dispatch(const GramTileCtx &c, float (*lds)[2][kKB][kMacroTile]) {
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    if (c.I != c.J) {
+        gram_tile<VEC, false, true, true>(c, lds, wave >> 2, wave & 3);
+        return;
+    }
+    const int tab_i[8] = {0, 1, 0, 1, 0, 0, 0, 0};
+    const int tab_j[8] = {0, 2, 3, 3, 1, 2, 0, 0};
+    const int tab_m[8] = {1, 1, 3, 3, 3, 3, 0, 0};  // bit0: sub-tile a=0, bit1: a=1
+    const int wi = tab_i[wave], wj = tab_j[wave], m = tab_m[wave];
+    if (m == 3)
+        gram_tile<VEC, true, true, true>(c, lds, wi, wj);
+    else if (m == 1)
+        gram_tile<VEC, true, true, false>(c, lds, wi, wj);
+    else
+        gram_tile<VEC, true, false, false>(c, lds, wi, wj);
 }
 
 template <bool VEC>
@@ -342,10 +421,8 @@ __global__ __launch_bounds__(kThreads, 1) void gram_partial_kernel(
     c.ablate = ablate;
     c.trace = fold.trace;
     chunk_range(plan, c.chunk, rows, c.r0, c.r1);
-    if (c.I == c.J)
-        gram_tile<VEC, true>(c, lds);
-    else
-        gram_tile<VEC, false>(c, lds);
+    c.rows_total = rows;
+    gram_tile_dispatch<VEC>(c, lds);
 }
 
 // Stand-alone fold (faithful mode needs the block's Gram immediately; also the final flush).
@@ -416,7 +493,7 @@ static GramGeom gram_geometry(const GramWorkspace &ws, int64_t n) {
 
 // debug only (GS_GRAM_TRACE + GS_GRAM_TRACE_DUMP; synchronises): s_memtime stamps (100 MHz) of one launch's compute
 // workgroups.  slots: 0 start, 1 first tile staged, 2+s end of stage s / phase s, 14 slab written
-static void dump_trace(unsigned long long *trace_buf, int grid, hipStream_t stream) {
+static void dump_trace(unsigned long long *trace_buf, int grid, hipStream_t stream, int nmt_dbg = 0) {
     if (!trace_buf || !getenv("GS_GRAM_TRACE_DUMP")) return;
     (void)hipStreamSynchronize(stream);
     static std::vector<unsigned long long> h(16 * 4096);
@@ -444,6 +521,25 @@ static void dump_trace(unsigned long long *trace_buf, int grid, hipStream_t stre
     for (int q = 1; q < 15; ++q)
         if (cnt[q]) fprintf(stderr, " s%d=%.0f(%.0f)", q, sum[q] / cnt[q], mx[q]);
     fprintf(stderr, "\n");
+    if (nmt_dbg > 0) {
+        // mean workgroup duration (start -> slab written) per macro tile and per XCD
+        std::vector<double> ts(nmt_dbg, 0.0), xs(8, 0.0);
+        std::vector<int> tc(nmt_dbg, 0), xc(8, 0);
+        for (int b = 0; b < grid; ++b) {
+            const unsigned long long s0 = h[b * 16], e = h[b * 16 + 14];
+            if (!s0 || e <= s0) continue;
+            const int tile = (b >> 3) % nmt_dbg;
+            ts[tile] += (double)(e - s0);
+            tc[tile]++;
+            xs[b & 7] += (double)(e - s0);
+            xc[b & 7]++;
+        }
+        fprintf(stderr, "[gram trace] per tile:");
+        for (int t = 0; t < nmt_dbg; ++t) fprintf(stderr, " %d:%.0f", t, tc[t] ? ts[t] / tc[t] : 0.0);
+        fprintf(stderr, "  per xcd:");
+        for (int x = 0; x < 8; ++x) fprintf(stderr, " %.0f", xc[x] ? xs[x] / xc[x] : 0.0);
+        fprintf(stderr, "\n");
+    }
 }
 
 static void launch_partial(const GramWorkspace &ws, const GramGeom &g, int buf, const float *Xb, int64_t n,
@@ -472,7 +568,7 @@ static void launch_partial(const GramWorkspace &ws, const GramGeom &g, int buf, 
     if (ws.precision != GS_PREC_F32) {
         (void)launch_gram_bf16(ws.precision, g.grid, nfold, Xb, n, ld, (int)d, shift, ws.partial[buf],
                                ws.colsum_partial[buf], dp, g.nchunks, g.plan, g.nmt, g.T, fj, stream);
-        dump_trace(trace_buf, g.grid, stream);
+        dump_trace(trace_buf, g.grid, stream, g.nmt);
         return;
     }
     const dim3 grid((unsigned)(g.grid + nfold));
@@ -484,7 +580,7 @@ static void launch_partial(const GramWorkspace &ws, const GramGeom &g, int buf, 
         hipLaunchKernelGGL(gram_partial_kernel<false>, grid, dim3(kThreads), 0, stream, Xb, n, ld, (int)d, shift,
                            ws.partial[buf], ws.colsum_partial[buf], dp, g.nchunks, g.plan, g.nmt, g.T, ablate,
                            g.grid, fj);
-    dump_trace(trace_buf, g.grid, stream);
+    dump_trace(trace_buf, g.grid, stream, g.nmt);
 }
 
 static FoldJob pending_job(const GramWorkspace &ws, double *G64, double *S1) {
