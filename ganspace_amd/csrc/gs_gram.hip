@@ -26,6 +26,7 @@
 //     accumulated scatter centred (no catastrophic cancellation for |mean| >> stdev).
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 #include <vector>
 
 #include "gs_common.h"
@@ -68,6 +69,14 @@ __device__ __forceinline__ float4 finish(float4 v, float4 sh, bool row_ok, int c
     v.z = (row_ok && col + 2 < d) ? v.z - sh.z : 0.f;
     v.w = (row_ok && col + 3 < d) ? v.w - sh.w : 0.f;
     return v;
+}
+
+// a - b as two v_pk_add_f32 (neg modifiers) instead of four v_sub_f32
+using f32x2v = __attribute__((ext_vector_type(2))) float;
+__device__ __forceinline__ float4 sub4(float4 a, float4 b) {
+    const f32x2v lo = f32x2v{a.x, a.y} - f32x2v{b.x, b.y};
+    const f32x2v hi = f32x2v{a.z, a.w} - f32x2v{b.z, b.w};
+    return make_float4(lo.x, lo.y, hi.x, hi.y);
 }
 
 struct GramTileCtx {
@@ -154,10 +163,16 @@ __device__ __forceinline__ void mfma_steps(const float *__restrict__ A, const fl
 template <bool M0, bool M1>
 __device__ __forceinline__ void mfma_stage(const float *__restrict__ A, const float *__restrict__ B,
                                            int ksteps, f32x16 &acc0, f32x16 &acc1) {
+    // chunk lengths are multiples of 16 rows (kRowUnit): 8, 16, 24 or 32 k-steps, pipelined; anything else is
+    // the ragged end of the last chunk of a launch
     if (ksteps == kKB / 2) {
         mfma_steps<M0, M1, kKB / 2>(A, B, acc0, acc1);
+    } else if (ksteps == 3 * kKB / 8) {
+        mfma_steps<M0, M1, 3 * kKB / 8>(A, B, acc0, acc1);
     } else if (ksteps == kKB / 4) {
         mfma_steps<M0, M1, kKB / 4>(A, B, acc0, acc1);
+    } else if (ksteps == kKB / 8) {
+        mfma_steps<M0, M1, kKB / 8>(A, B, acc0, acc1);
     } else {
         // ragged stage of a chunk: only the rows that exist (no MFMA time spent on zero padding)
         for (int k = 0; k < 2 * ksteps; k += 2) {
@@ -260,10 +275,10 @@ __device__ __forceinline__ void gram_tile(const GramTileCtx &c, float (*lds)[2][
             float4 la = f.a[i], lb = f.b[i];
             asm volatile("" : "+v"(la.x), "+v"(la.y), "+v"(la.z), "+v"(la.w));
             if (!DIAG) asm volatile("" : "+v"(lb.x), "+v"(lb.y), "+v"(lb.z), "+v"(lb.w));
-            const float4 va = make_float4(la.x - shA.x, la.y - shA.y, la.z - shA.z, la.w - shA.w);
+            const float4 va = sub4(la, shA);
             *reinterpret_cast<float4 *>(&lds[buf][0][rr + 16 * i][c4 * 4]) = va;
             if (!DIAG) {
-                const float4 vb = make_float4(lb.x - shB.x, lb.y - shB.y, lb.z - shB.z, lb.w - shB.w);
+                const float4 vb = sub4(lb, shB);
                 *reinterpret_cast<float4 *>(&lds[buf][1][rr + 16 * i][c4 * 4]) = vb;
             } else {
                 cs.x += va.x;
@@ -298,29 +313,42 @@ __device__ __forceinline__ void gram_tile(const GramTileCtx &c, float (*lds)[2][
     auto opB = [&](int buf) { return &lds[buf][DIAG ? 0 : 1][arow][bcol]; };
 
     FetchRegs f;
-    if (nst > 0) {
-        fetch(f, c.r0, 1);
-        stash(f, 0, c.r0, 1);
-    }
-    __syncthreads();
-    stamp(1);
     int s = 0;
     // general iteration (any stage length): loads of stage s + 1 | MFMA on stage s | store stage s + 1
-    auto general = [&]() {
+    auto general = [&](bool prefetched) {
         const int buf = s & 1;
         const bool more = s + 1 < nst;
-        if (more && !(c.ablate & 2)) fetch(f, stage_row(s + 1), (stage_rows(s + 1) + 15) / 16);
+        const bool next_whole = tile_full && s + 1 <= nfull;      // stage s + 1 may use the mask-free path
+        if (more && !prefetched && !(c.ablate & 2)) {
+            if (next_whole)
+                fetch_fast(f, stage_row(s + 1));
+            else
+                fetch(f, stage_row(s + 1), (stage_rows(s + 1) + 15) / 16);
+        }
         __builtin_amdgcn_sched_barrier(0);
         if ((M0 || M1) && !(c.ablate & 1)) mfma_stage<M0, M1>(opA(buf), opB(buf), (stage_rows(s) + 1) / 2, acc0, acc1);
         __builtin_amdgcn_sched_barrier(0);
-        if (more && !(c.ablate & 16)) stash(f, buf ^ 1, stage_row(s + 1), (stage_rows(s + 1) + 15) / 16);
+        if (more && !(c.ablate & 16)) {
+            if (next_whole)
+                stash_fast(f, buf ^ 1);
+            else
+                stash(f, buf ^ 1, stage_row(s + 1), (stage_rows(s + 1) + 15) / 16);
+        }
         __syncthreads();
         stamp(2 + s);
         ++s;
     };
-    if (nst > 0) general();                                   // stage 0 (and the loads / stores of stage 1)
+    if (nst > 0) {
+        fetch(f, c.r0, 1);
+        stash(f, 0, c.r0, 1);
+        __syncthreads();
+        stamp(1);
+        general(false);                                       // stage 0 (and the loads / stores of stage 1)
+    }
     if (tile_full) {
         // whole stages whose successor is a whole stage too: stages 1 .. nfull - 1
+        // (tried and measured no better: the store phase inside the k-loop at 3/4, or at different places for the
+        //  two waves of a SIMD pair; a second stage of loads in flight)
         while (s < nfull) {
             const int buf = s & 1;
             if (!(c.ablate & 2)) fetch_fast(f, stage_row(s + 1));
@@ -333,7 +361,7 @@ __device__ __forceinline__ void gram_tile(const GramTileCtx &c, float (*lds)[2][
             ++s;
         }
     }
-    while (s < nst) general();                                // last whole stage, ragged stage; partial-column tiles
+    while (s < nst) general(false);                                // last whole stage, ragged stage; partial-column tiles
 
     // ---- epilogue: 32x32 sub-tiles -> this chunk's float32 slab --------------------------------
     if (!(c.ablate & 32) || c.r0 < 0) {
