@@ -91,6 +91,7 @@ int column_sums_f64(const float *X, int64_t rows, int64_t ld, int64_t d, double 
 // ---- top-k subspace eigensolver: gs_subspace.hip ---------------------------------------------------
 struct SubspaceWorkspace {
     int n_cap = 0, p_cap = 0, pp = 0;
+    int warm_mults = 0;            // products the last converged warm-started solve used (schedule hint)
     double *Q = nullptr, *Y = nullptr, *Z = nullptr, *R = nullptr;  // [n][pp]
     double *H = nullptr, *B = nullptr, *U = nullptr;                // [pp][pp]
     double *theta = nullptr;                                        // [3*pp + 16]: Ritz values | residuals | pivot floors | R-diagonal statistics

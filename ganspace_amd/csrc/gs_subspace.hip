@@ -481,7 +481,10 @@ int eigh_topk_subspace(SubspaceWorkspace &ws, const double *A, int n, int64_t ld
     // rho ~ (R_pp / R_kk)^(1/j), hence how many products the residual target needs.  A cold start runs that many
     // before its first (expensive: Jacobi on p x p) Rayleigh-Ritz step instead of probing every few products; a
     // warm start (previous components) projects after 4.  A failed test extrapolates from the measured residual.
-    int mults = 0, interval = 2, next_rr = warm ? 4 : max_mults;
+    // A warm start projects after as many products as the previous warm solve of this workspace needed (4 the first
+    // time; consecutive blocks of the incremental PCA have near-identical spectra), minus a probe step now and
+    // then when the last solve converged with a wide margin.
+    int mults = 0, interval = 2, next_rr = warm ? (ws.warm_mults > 4 ? ws.warm_mults : 4) : max_mults;
     double rho = 0.0;
     *converged = 0;
     std::vector<double> host(k + 8);
@@ -554,6 +557,11 @@ int eigh_topk_subspace(SubspaceWorkspace &ws, const double *A, int n, int64_t ld
         const bool ok = worst <= tol2 * th1 * th1;
         if (ok || mults >= max_mults) {
             *converged = ok ? 1 : 0;
+            if (warm && ok) {
+                // margin of more than 4 digits in the squared residual: try two products fewer next time
+                const bool wide = worst <= 1e-4 * tol2 * th1 * th1;
+                ws.warm_mults = (wide && mults > 4) ? mults - 2 : mults;
+            }
             hipLaunchKernelGGL(emit_rows_kernel, dim3((unsigned)ceil_div(n, 256), (unsigned)k), dim3(256), 0, stream,
                                Z, ld, ws.theta, n, k, Vk, ldv, lam);
             GS_HIP_CHECK(hipGetLastError());
