@@ -14,6 +14,7 @@
 // full Jacobi solver, so robustness never depends on the spectrum.  A warm start (the previous
 // block's components) makes the per-block solve of the sklearn-faithful recurrence converge in
 // a handful of multiplications.
+#include <cstdlib>
 #include <utility>
 #include <vector>
 
@@ -444,7 +445,15 @@ void subspace_workspace_free(SubspaceWorkspace &ws) {
 }
 
 int subspace_dim(int n, int k) {
-    int p = k + (k > 48 ? k : 48);
+    static const int extra_env = []() {
+        const char *e = getenv("GS_SUBSPACE_EXTRA");     // experiment knob: guard columns beyond k
+        return e ? atoi(e) : 0;
+    }();
+    // guard columns: the iteration converges like (lambda_{p+1} / lambda_k)^products, every product / CholeskyQR /
+    // Rayleigh-Ritz step costs ~p, p^2, p^3.  48 .. k/2 guards measured best on the cfg2 spectrum (k = 80:
+    // p = 128 -> 26 products, 3.4 ms; p = 160 -> 18 products, 3.9 ms; p = 112 -> 34 products, 3.6 ms); a flatter
+    // spectrum only costs more products - the residual test, not p, decides when the solve is done.
+    int p = k + (extra_env > 0 ? extra_env : (k / 2 > 48 ? k / 2 : 48));
     p = (int)round_up(p, 16);
     // the subspace must stay well below n for the iteration to pay off
     if (p > 256 || 2 * p > n) return 0;
