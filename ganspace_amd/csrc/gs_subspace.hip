@@ -493,7 +493,7 @@ int eigh_topk_subspace(SubspaceWorkspace &ws, const double *A, int n, int64_t ld
     // A warm start projects after as many products as the previous warm solve of this workspace needed (4 the first
     // time; consecutive blocks of the incremental PCA have near-identical spectra), minus a probe step now and
     // then when the last solve converged with a wide margin.
-    int mults = 0, interval = 2, next_rr = warm ? (ws.warm_mults > 4 ? ws.warm_mults : 4) : max_mults;
+    int mults = 0, interval = 2, orths = 0, next_rr = warm ? (ws.warm_mults > 4 ? ws.warm_mults : 4) : max_mults;
     double rho = 0.0;
     *converged = 0;
     std::vector<double> host(k + 8);
@@ -515,6 +515,13 @@ int eigh_topk_subspace(SubspaceWorkspace &ws, const double *A, int n, int64_t ld
             rc = cholqr(ws, Q, Y, n, p, stream);
             if (rc != GS_OK) return rc;
             std::swap(Q, Y);
+            // the estimates settle after a few factorisations (and each read is a host round trip that idles the
+            // GPU): read R's diagonal for the first four of a cold solve, the first three of a warm solve
+            if (++orths > (warm ? 3 : 4)) {
+                if (!warm && next_rr == max_mults && mults >= 12) next_rr = mults;   // never got an estimate: probe
+                if (mults >= next_rr || mults >= max_mults) break;
+                continue;
+            }
             hipLaunchKernelGGL(rdiag_stats_kernel, dim3(1), dim3(64), 0, stream, ws.Rm, ld, p, k, stats);
             GS_HIP_CHECK(hipMemcpyAsync(host.data(), stats, sizeof(double) * 6, hipMemcpyDeviceToHost, stream));
             GS_HIP_CHECK(hipStreamSynchronize(stream));
