@@ -295,13 +295,16 @@ __device__ __forceinline__ void gram_tile(const GramTileCtx &c, float (*lds)[2][
     stamp(0);
     f32x16 acc0 = {0}, acc1 = {0};
     const int64_t nrows = r1 - c.r0;
-    // Stage 0 is short (16 rows): the matrix pipes start after a 16 KiB fetch per workgroup instead of a 64 KiB
-    // one (the whole grid's first fetch is otherwise ~16 MB before a single MFMA issues).  Then nfull whole
-    // stages of 64 rows, then the rest (< 64 rows).
-    constexpr int kFirst = 16;
-    const int64_t first = nrows < kFirst ? nrows : kFirst;
-    const int nfull = (int)((nrows - first) / kKB);
-    const int rest = (int)(nrows - first - (int64_t)nfull * kKB);
+    // Stage 0 takes the part of the chunk that does not fill whole stages (nrows mod 64; chunk lengths are
+    // multiples of 16 except at the very end of a launch), so every later stage is a whole one and there is no
+    // short stage at the end.  A short first stage also lets the matrix pipes start after a 16-48 KiB fetch per
+    // workgroup instead of a 64 KiB one (the whole grid's first fetch is otherwise ~16 MB before a single MFMA).
+    // (the k-loop consumes rows in pairs, so a stage that is followed by more rows must have an even length: the
+    //  sub-16 tail of a launch's last chunk stays at the end, where the rows past r1 are stored as zeros)
+    const int64_t body = nrows - nrows % kRowUnit;
+    const int64_t first = body == 0 ? nrows : ((body % kKB) ? body % kKB : (body < kKB ? body : kKB));
+    const int nfull = (int)((body - first) / kKB) * (body > 0 ? 1 : 0);
+    const int rest = body == 0 ? 0 : (int)(nrows - body);             // < 16 rows, only at the end of a launch
     const int nst = (nrows > 0 ? 1 : 0) + nfull + (rest > 0 ? 1 : 0);
     const bool tile_full = VEC && (c.I + 1) * kMacroTile <= d && (c.J + 1) * kMacroTile <= d;   // workgroup-uniform
     const int arow = lane >> 5;
@@ -339,8 +342,8 @@ __device__ __forceinline__ void gram_tile(const GramTileCtx &c, float (*lds)[2][
         ++s;
     };
     if (nst > 0) {
-        fetch(f, c.r0, 1);
-        stash(f, 0, c.r0, 1);
+        fetch(f, c.r0, ((int)first + 15) / 16);
+        stash(f, 0, c.r0, ((int)first + 15) / 16);
         __syncthreads();
         stamp(1);
         general(false);                                       // stage 0 (and the loads / stores of stage 1)

@@ -51,6 +51,24 @@ def test_gram_accumulate_matches_float64(dev, rows, d, ld_extra, use_shift):
     np.testing.assert_array_equal(Gh, Gh.T)      # exactly symmetric by construction
 
 
+@pytest.mark.parametrize("d", [384, 100])
+def test_gram_row_count_sweep(dev, d):
+    """Chunk / stage boundaries of the launch geometry: rows are dealt to chunks in 16-row units, the first LDS stage
+    of a chunk takes its length mod 64, the sub-16 tail of the last chunk is masked - every combination must give
+    the same sums (this sweep caught an odd-length first stage double counting a row)."""
+    from ganspace_amd import ops
+    rs = np.random.RandomState(d)
+    for rows in (1, 2, 15, 16, 17, 31, 33, 48, 49, 63, 64, 65, 81, 96, 111, 113, 177, 1023, 1600, 4095, 4097, 6401):
+        Xh = rs.standard_normal((rows, d)).astype(np.float32)
+        X = torch.from_numpy(Xh).to(dev)
+        Gref = Xh.astype(np.float64).T @ Xh.astype(np.float64)
+        for precision in ("f32", "bf16x6"):
+            G, cs = ops.gram_accumulate(X, precision=precision)
+            err = np.abs(G.cpu().numpy() - Gref).max() / max(np.abs(Gref).max(), 1e-30)
+            assert err <= 2e-6, (rows, d, precision, err)
+            np.testing.assert_allclose(cs.cpu().numpy(), Xh.astype(np.float64).sum(0), atol=2e-5 * max(1.0, rows ** 0.5))
+
+
 def test_gram_accumulates_and_is_linear(dev):
     from ganspace_amd import ops
     rs = np.random.RandomState(5)
