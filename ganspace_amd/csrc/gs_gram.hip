@@ -8,22 +8,25 @@
 //
 // Work decomposition (one launch per <= 24 x 1024 rows at d = 512):
 //   * output: upper-triangle 128 x 128 macro tiles of the d x d Gram (symmetry: the lower
-//     triangle is never computed); one workgroup (4 waves) per (macro tile, row chunk);
-//     wave (wi, wj) owns a 64 x 64 tile = 2 x 2 accumulators of v_mfma_f32_32x32x2_f32;
-//     on diagonal macro tiles the strictly-lower wave tile is skipped.
-//   * split-K over row chunks: each chunk's partial tile goes to a float32 slab; a second
-//     kernel folds the slabs in float64 into the persistent accumulator, so float32
-//     fma chains never exceed 1024 rows (417 at the 10 000-row block of the bench).
+//     triangle is never computed); one workgroup (8 waves = 2 per SIMD) per (macro tile, row
+//     chunk); wave (wi, wj) owns a 64 x 32 strip = 2 accumulators of v_mfma_f32_32x32x2_f32;
+//     diagonal macro tiles compute only their 10 upper sub-tiles, dealt 3/3/2/2 to the SIMDs.
+//   * split-K over row chunks (rows dealt in 16-row units, lengths differ by at most one unit):
+//     each chunk's partial tile goes to a float32 slab; the slabs are folded in float64 into
+//     the persistent accumulator (by spare workgroups of the next launch in exact mode), so
+//     float32 fma chains never exceed 1024 rows (416 at the 10 000-row block of the bench).
 //   * X is row-major [rows, d]; for X^T X both MFMA operands are "row k, 32 consecutive
 //     columns" (A[i][k] = X[k][I+i], B[k][j] = X[k][J+j]) so global reads are fully
 //     coalesced 512-B row segments and LDS reads are conflict-free ds_read_b32 without
-//     any transpose or swizzle.  Tiles are register-staged (global_load_dwordx4 ->
-//     subtract shift -> ds_write_b128) and double-buffered in LDS (64 KiB / workgroup).
+//     any transpose or swizzle.  Tiles are register-staged (buffer_load_dwordx4 ->
+//     subtract shift -> ds_write_b128) and double-buffered in LDS (64-row stages, 128 KiB).
 //   * XCD-aware block mapping: block b lands on XCD b % 8, so all macro tiles of a row
 //     chunk are given to the same XCD and the chunk's rows are fetched from HBM once and
 //     re-read from that XCD's L2.
 //   * the shift s (running mean, float32) is subtracted while staging, which keeps the
 //     accumulated scatter centred (no catastrophic cancellation for |mean| >> stdev).
+// Profiling hooks (off by default): GS_GRAM_TRACE / GS_GRAM_TRACE_DUMP (s_memtime stamps per
+// workgroup), GS_GRAM_ABLATE (bit mask, results wrong by design) - see gram_tile().
 #include <cstdio>
 #include <cstdlib>
 #include <type_traits>
