@@ -589,6 +589,9 @@ static void launch_partial(const GramWorkspace &ws, const GramGeom &g, int buf, 
     if (fold.P != nullptr) {
         nfold = 256 - g.grid % 256;
         if (nfold < 8 || nfold > 64) nfold = 16;
+        // the two-plane split kernel needs 80 KiB of LDS: two workgroups fit a CU, so fold workgroups can sit next
+        // to compute workgroups - its launches are short enough for a 16-workgroup fold to become the critical path
+        if (ws.precision == GS_PREC_BF16X3) nfold = 64;
     }
     static unsigned long long *trace_buf = []() -> unsigned long long * {
         if (!getenv("GS_GRAM_TRACE")) return nullptr;
