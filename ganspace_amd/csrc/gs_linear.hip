@@ -13,6 +13,8 @@
 // 64 x 64, K step 32, double-buffered.  Bias, equalised-lr scales, leaky-ReLU and the
 // sqrt(2) gain (fused_leaky_relu of the missing stylegan2 `op/` CUDA extension) are fused
 // into the epilogue.
+#include <utility>
+
 #include "gs_common.h"
 
 namespace gs {
@@ -122,6 +124,190 @@ __global__ __launch_bounds__(256, 2) void linear_act_kernel(
     }
 }
 
+// ---- fast path: whole K steps, whole N tiles, 16-byte aligned rows ---------------------------------------------
+// Same arithmetic order per output element as linear_act_kernel (a k-ordered fma chain), restructured the way the
+// Gram kernel was (gs_gram.hip):
+//   * output tile (32 R) x 128 with R chosen per launch so that the tiles fill the 256 CUs in as few, as full
+//     rounds as possible - the 128 x 128 tiling of the 10 000 x 512 mapping layer gave 316 workgroups, i.e. 1.23
+//     rounds paid as 2 (measured 74 us); R = 5 gives 252 workgroups in one round;
+//   * 8 waves: waves w and w + 4 (same SIMD) own output columns 32 w .. 32 w + 31 and split the R row fragments
+//     (RF + 1 operand reads feed RF MFMAs): one of them has MFMAs in flight while the other stores / restarts;
+//   * the tiles stay K-contiguous in LDS ([row][32 k + 2 pad]: rows 136 B apart make the 64 lanes of a fragment
+//     read - 32 rows x 2 consecutive k - hit 64 different banks), so staging is two ds_write_b64 per float4 instead
+//     of four scalar stores; loads go through buffer resources (row offsets in SGPRs, rows past M read as zeros);
+//   * operand reads run two k-steps ahead of the MFMAs (inline-asm ds_read_b32 with immediate offsets + counted
+//     s_waitcnt); one code path in the K loop.
+constexpr int kFP = kLK + 2;   // padded row length (floats)
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+
+template <int OFF>
+__device__ __forceinline__ float lds_rd(unsigned addr) {
+    float v;
+    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+    return v;
+}
+
+// v[i] = LDS dword at addr + BASE + i * STRIDE (immediate offsets), i = 0 .. R - 1
+template <int R, int BASE, int STRIDE, int I = 0>
+struct ReadFrags {
+    static __device__ __forceinline__ void run(unsigned addr, float (&v)[R]) {
+        v[I] = lds_rd<BASE + I * STRIDE>(addr);
+        ReadFrags<R, BASE, STRIDE, I + 1>::run(addr, v);
+    }
+};
+template <int R, int BASE, int STRIDE>
+struct ReadFrags<R, BASE, STRIDE, R> {
+    static __device__ __forceinline__ void run(unsigned, float (&)[R]) {}
+};
+
+template <int N>
+__device__ __forceinline__ void lgkm_wait() {
+    static_assert(N >= 0 && N <= 15, "lgkmcnt is a 4-bit counter");
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int R, int K, int KS>
+struct LinPipe {
+    // a[] / b: operands of k-step K (issued two steps ago); p[] / pb: step K + 1, still in flight
+    static __device__ __forceinline__ void run(unsigned aaddr, unsigned baddr, const float (&a)[R], float b,
+                                               const float (&p)[R], float pb, f32x16 (&acc)[R]) {
+        constexpr int kFrag = 32 * kFP * 4;   // byte distance between 32-row fragments
+        float q[R], qb = 0.f;
+#pragma unroll
+        for (int r = 0; r < R; ++r) q[r] = 0.f;
+        if (K + 2 < KS) {
+            qb = lds_rd<(K + 2) * 8>(baddr);
+            ReadFrags<R, (K + 2) * 8, kFrag>::run(aaddr, q);
+            lgkm_wait<2 * (R + 1)>();
+        } else if (K + 1 < KS) {
+            lgkm_wait<R + 1>();
+        } else {
+            lgkm_wait<0>();
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[r], b, acc[r], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        LinPipe<R, K + 1, KS>::run(aaddr, baddr, p, pb, q, qb, acc);
+    }
+};
+template <int R, int KS>
+struct LinPipe<R, KS, KS> {
+    static __device__ __forceinline__ void run(unsigned, unsigned, const float (&)[R], float, const float (&)[R], float,
+                                               f32x16 (&)[R]) {}
+};
+
+// K loop of one wave that owns RF row fragments (starting at fragment f0) of column fragment `cw`.  All 512
+// threads stage; the two waves of a SIMD (w and w + 4) share a column fragment and split the row fragments, so that
+// one of them has MFMAs in flight while the other stores the next tile or restarts after the barrier.
+template <int R, int RF>
+__device__ __forceinline__ void linear_fast_body(float (*lds)[32 * R + kLT][kFP], const float *__restrict__ bias,
+                                                 float *__restrict__ Y, int64_t M, int K, int64_t ldy, float wscale,
+                                                 float bscale, float slope, float gain, int act, int64_t m0, int n0,
+                                                 int f0, int cw, const __amdgpu_buffer_rsrc_t &rx,
+                                                 const __amdgpu_buffer_rsrc_t &rw, int64_t ldx) {
+    constexpr int TM = 32 * R;
+    constexpr int PA = (TM + 63) / 64;      // staging passes of 64 rows
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int k4 = tid & 7, r8 = tid >> 3;  // 64 rows per pass
+    const unsigned voffx = (unsigned)((r8 * ldx + k4 * 4) * 4), voffw = (unsigned)((r8 * K + k4 * 4) * 4);
+
+    u32x4 ra[PA], rb[2];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < PA; ++i)
+            if (TM % 64 == 0 || i + 1 < PA || r8 < TM % 64)
+                ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, voffx, (unsigned)(((m0 + 64 * i) * ldx + k0) * 4), 0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            rb[i] = __builtin_amdgcn_raw_buffer_load_b128(rw, voffw, (unsigned)((((int64_t)n0 + 64 * i) * K + k0) * 4), 0);
+    };
+    auto put = [&](float *dst, u32x4 v) {
+        // opaque: keeps the stores (and the wait for the loads) behind the MFMA stream, see gs_gram.hip
+        asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));
+        uint2 *p = reinterpret_cast<uint2 *>(dst);
+        p[0] = make_uint2(v.x, v.y);
+        p[1] = make_uint2(v.z, v.w);
+    };
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < PA; ++i)
+            if (TM % 64 == 0 || i + 1 < PA || r8 < TM % 64) put(&lds[buf][r8 + 64 * i][k4 * 4], ra[i]);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) put(&lds[buf][TM + r8 + 64 * i][k4 * 4], rb[i]);
+    };
+
+    f32x16 acc[RF > 0 ? RF : 1];
+#pragma unroll
+    for (int r = 0; r < (RF > 0 ? RF : 1); ++r) acc[r] = f32x16{0};
+    const int nst = K / kLK;
+    const int frag = ((lane & 31) * kFP + (lane >> 5)) * 4;   // byte offset of this lane inside a 32-row fragment
+    constexpr int kFrag = 32 * kFP * 4;
+
+    fetch(0);
+    stash(0);
+    __syncthreads();
+    for (int s = 0; s < nst; ++s) {
+        const int buf = s & 1;
+        if (s + 1 < nst) fetch((s + 1) * kLK);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (RF > 0) {
+            const unsigned aaddr = (unsigned)(uintptr_t)&lds[buf][32 * f0][0] + frag;
+            const unsigned baddr = (unsigned)(uintptr_t)&lds[buf][TM + cw * 32][0] + frag;
+            float a[RF], p[RF];
+            const float b0 = lds_rd<0>(baddr);
+            ReadFrags<RF, 0, kFrag>::run(aaddr, a);
+            const float pb = lds_rd<8>(baddr);
+            ReadFrags<RF, 8, kFrag>::run(aaddr, p);
+            LinPipe<RF, 0, kLK / 2>::run(aaddr, baddr, a, b0, p, pb, acc);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (s + 1 < nst) stash(buf ^ 1);
+        __syncthreads();
+    }
+
+    if constexpr (RF > 0) {
+        const int col = n0 + cw * 32 + (lane & 31);
+        const float bb = bias ? bias[col] * bscale : 0.f;
+        const int64_t row_base = m0 + 32 * f0 + 4 * (lane >> 5);
+#pragma unroll
+        for (int r = 0; r < RF; ++r)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int64_t row = row_base + 32 * r + (i & 3) + 8 * (i >> 2);
+                if (row < M) {
+                    float v = acc[r][i] * wscale + bb;
+                    if (act) v = gain * (v >= 0.f ? v : v * slope);
+                    Y[row * ldy + col] = v;
+                }
+            }
+    }
+}
+
+template <int R>
+__global__ __launch_bounds__(512, 1) void linear_act_fast_kernel(
+    const float *__restrict__ X, const float *__restrict__ Wt, const float *__restrict__ bias,
+    float *__restrict__ Y, int64_t M, int N, int K, int64_t ldx, int64_t ldy, float wscale, float bscale,
+    float slope, float gain, int act) {
+    constexpr int TM = 32 * R;
+    __shared__ __attribute__((aligned(16))) float lds[2][TM + kLT][kFP];  // [buffer][x rows | W rows][k]
+    const int ntn = N / kLT;
+    const int bid = blockIdx.x;
+    const int64_t m0 = (int64_t)(bid / ntn) * TM;
+    const int n0 = (bid % ntn) * kLT;
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(X), 0,
+                                                                        (unsigned)((uint64_t)M * ldx * 4u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(Wt), 0,
+                                                                        (unsigned)((uint64_t)N * K * 4u), 0x00020000);
+    constexpr int RA = (R + 1) / 2, RB = R / 2;    // row fragments of waves 0-3 / 4-7
+    if (wave < 4)
+        linear_fast_body<R, RA>(lds, bias, Y, M, K, ldy, wscale, bscale, slope, gain, act, m0, n0, 0, wave, rx, rw, ldx);
+    else
+        linear_fast_body<R, RB>(lds, bias, Y, M, K, ldy, wscale, bscale, slope, gain, act, m0, n0, RA, wave - 4, rx, rw,
+                                ldx);
+}
+
 // PixelNorm: y = x * rsqrt(mean(x^2, dim=1) + eps)  (models/stylegan/model.py:138-143)
 __global__ __launch_bounds__(256) void pixelnorm_kernel(const float *__restrict__ X, float *__restrict__ Y,
                                                         int64_t rows, int dim, float eps) {
@@ -152,8 +338,36 @@ static int launch_linear(const float *x, const float *W, const float *b, float *
                          float wscale, float bscale, float slope, float gain, int act, hipStream_t stream) {
     const int64_t ntm = ceil_div(M, kLT), ntn = ceil_div(N, kLT);
     GS_REQUIRE(ntm * ntn < (int64_t)2147483647, GS_EINVAL, "linear: grid too large");
-    hipLaunchKernelGGL(linear_act_kernel, dim3((unsigned)(ntm * ntn)), dim3(256), 0, stream, x, W, b, y, M, N,
-                       K, (int64_t)K, (int64_t)N, wscale, bscale, slope, gain, act);
+    const bool fast = (K % kLK == 0) && (N % kLT == 0) && (uint64_t)M * K * 4u < 0xFFFFFFFFull &&
+                      (uint64_t)N * K * 4u < 0xFFFFFFFFull;      // x / W: 16-byte aligned by contract (checked by the callers)
+    if (fast) {
+        // rows per tile = 32 R: fewest rounds over the 256 CUs, then the least padded work
+        int best = 4;
+        int64_t best_cost = -1;
+        for (int R = 2; R <= 6; ++R) {
+            const int64_t tiles = ceil_div(M, (int64_t)32 * R) * ntn;
+            const int64_t cost = ceil_div(tiles, (int64_t)256) * R * 1000 + (6 - R);   // ties: larger tile
+            if (best_cost < 0 || cost < best_cost) {
+                best_cost = cost;
+                best = R;
+            }
+        }
+        const unsigned grid = (unsigned)(ceil_div(M, (int64_t)32 * best) * ntn);
+#define GS_LAUNCH_FAST(RR)                                                                                         \
+    hipLaunchKernelGGL((linear_act_fast_kernel<RR>), dim3(grid), dim3(512), 0, stream, x, W, b, y, M, N, K, (int64_t)K, \
+                       (int64_t)N, wscale, bscale, slope, gain, act)
+        switch (best) {
+            case 2: GS_LAUNCH_FAST(2); break;
+            case 3: GS_LAUNCH_FAST(3); break;
+            case 4: GS_LAUNCH_FAST(4); break;
+            case 5: GS_LAUNCH_FAST(5); break;
+            default: GS_LAUNCH_FAST(6); break;
+        }
+#undef GS_LAUNCH_FAST
+    } else {
+        hipLaunchKernelGGL(linear_act_kernel, dim3((unsigned)(ntm * ntn)), dim3(256), 0, stream, x, W, b, y, M, N,
+                           K, (int64_t)K, (int64_t)N, wscale, bscale, slope, gain, act);
+    }
     GS_HIP_CHECK(hipGetLastError());
     return GS_OK;
 }
