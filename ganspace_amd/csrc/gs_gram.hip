@@ -321,11 +321,11 @@ __device__ __forceinline__ void gram_tile(const GramTileCtx &c, float (*lds)[2][
     FetchRegs f;
     int s = 0;
     // general iteration (any stage length): loads of stage s + 1 | MFMA on stage s | store stage s + 1
-    auto general = [&](bool prefetched) {
+    auto general = [&]() {
         const int buf = s & 1;
         const bool more = s + 1 < nst;
         const bool next_whole = tile_full && s + 1 <= nfull;      // stage s + 1 may use the mask-free path
-        if (more && !prefetched && !(c.ablate & 2)) {
+        if (more && !(c.ablate & 2)) {
             if (next_whole)
                 fetch_fast(f, stage_row(s + 1));
             else
@@ -349,7 +349,7 @@ __device__ __forceinline__ void gram_tile(const GramTileCtx &c, float (*lds)[2][
         stash(f, 0, c.r0, ((int)first + 15) / 16);
         __syncthreads();
         stamp(1);
-        general(false);                                       // stage 0 (and the loads / stores of stage 1)
+        general();                                       // stage 0 (and the loads / stores of stage 1)
     }
     if (tile_full) {
         // whole stages whose successor is a whole stage too: stages 1 .. nfull - 1
@@ -367,7 +367,7 @@ __device__ __forceinline__ void gram_tile(const GramTileCtx &c, float (*lds)[2][
             ++s;
         }
     }
-    while (s < nst) general(false);                                // last whole stage, ragged stage; partial-column tiles
+    while (s < nst) general();                                // last whole stage, ragged stage; partial-column tiles
 
     // ---- epilogue: 32x32 sub-tiles -> this chunk's float32 slab --------------------------------
     if (!(c.ablate & 32) || c.r0 < 0) {

@@ -192,12 +192,15 @@ __global__ void subspace_seed_kernel(double *__restrict__ Q, int n, int64_t ldq,
 }
 
 // Diagonal block of the blocked Cholesky: factors H[j0:j0+nb, j0:j0+nb] = R_JJ^T R_JJ, stores R_JJ into Rm
-// and its inverse (upper, leading dim kCB) into Dinv.  ONE wave, no LDS, no barriers: lane c keeps column c
+// and its inverse (upper, leading dim kCB) into Dinv.  ONE wave, no LDS, no barriers: lane c < 32 keeps column c
 // of the (identity-padded) 32 x 32 block in registers, every loop is fully unrolled with static register
 // indices, and the values a step needs from other lanes (the pivot, row j of R) travel by v_readlane.
+// Lanes 32..63 carry the columns of an appended identity through the SAME elimination steps (same instructions,
+// same broadcast values), which leaves R_JJ^-T in them: the inverse costs no second substitution pass.
 // A pivot that has lost more than ~13 digits against the column's original squared norm (origdiag, captured
-// at j0 == 0) marks a numerically dependent basis column: it gets R_jj = 1 and a ZERO column in Dinv, so the
-// panel row and the resulting Q column are exactly zero (the subspace shrinks by one) instead of NaN/garbage.
+// at j0 == 0) marks a numerically dependent basis column: it gets a zero row in R (diagonal 1 inside the
+// factorisation, 0 in Rm for rdiag_stats_kernel) and a ZERO row / column in Dinv, so the panel row and the
+// resulting Q column are exactly zero (the subspace shrinks by one) instead of NaN/garbage.
 constexpr int kCB = 32;
 __global__ __launch_bounds__(64) void chol_diag_kernel(const double *__restrict__ H, int64_t ldh, int p, int j0,
                                                        int nb, double *__restrict__ Rm, double *__restrict__ Dinv,
@@ -205,17 +208,17 @@ __global__ __launch_bounds__(64) void chol_diag_kernel(const double *__restrict_
     const int lane = threadIdx.x;
     if (j0 == 0)
         for (int i = lane; i < p; i += 64) origdiag[i] = H[(int64_t)i * ldh + i];
-    const int c = lane & 31;  // lanes 32..63 mirror lanes 0..31 (keeps every cross-lane read in range)
-    double col[kCB];          // col[r] = block(r, c), upper part r <= c
+    const int c = lane & 31;
+    const bool aug = lane >= kCB;   // identity column c
+    double col[kCB];                // col[r] = block(r, c) (upper part r <= c)  |  aug: running row r of L^-1 e_c
 #pragma unroll
     for (int r = 0; r < kCB; ++r) {
         double v = (r == c) ? 1.0 : 0.0;
-        if (r < nb && c < nb) v = (r <= c) ? H[(int64_t)(j0 + r) * ldh + j0 + c] : 0.0;
+        if (!aug && r < nb && c < nb) v = (r <= c) ? H[(int64_t)(j0 + r) * ldh + j0 + c] : 0.0;
         col[r] = v;
     }
     const double ref = (c < nb) ? ((j0 == 0) ? H[(int64_t)c * ldh + c] : origdiag[j0 + c]) : 1.0;
     unsigned dead_mask = 0;
-    double invdiag = 1.0;  // lane j keeps 1 / R[j][j]
 #pragma unroll
     for (int j = 0; j < kCB; ++j) {
         // pivot and its reference live in lane j
@@ -224,34 +227,30 @@ __global__ __launch_bounds__(64) void chol_diag_kernel(const double *__restrict_
         const bool dead = !(d > rf * 1e-13);
         const double inv = dead ? 0.0 : rsqrt_f64(d);
         if (dead) dead_mask |= (1u << j);
-        if (c == j) invdiag = dead ? 1.0 : inv;
-        // row j of R: R[j][c] = block(j, c) / piv  (c > j), R[j][j] = piv (or 1 when dead)
-        const double rjc = (c == j) ? (dead ? 1.0 : d * inv) : ((c > j) ? col[j] * inv : 0.0);
+        // row j of R: R[j][c] = block(j, c) / piv (c > j), R[j][j] = piv (1 when dead); row j of L^-1: scaled alike
+        double rjc = col[j] * inv;
+        if (!aug) rjc = (c == j) ? (dead ? 1.0 : d * inv) : ((c > j) ? rjc : 0.0);
         col[j] = rjc;
         if (!dead) {
 #pragma unroll
             for (int r = j + 1; r < kCB; ++r) {
-                const double rjr = readlane_f64(rjc, r);  // R[j][r], held by lane r
-                if (r <= c) col[r] -= rjr * rjc;
+                const double rjr = readlane_f64(rjc, r);  // R[j][r], held by lane r < 32
+                if (aug || r <= c) col[r] -= rjr * rjc;
             }
         }
     }
-    // inverse X = R^-1: lane c solves column c by back substitution; R[i][t] is lane t's col[i]
-    double x[kCB];
+    const bool dead_c = (dead_mask >> c) & 1u;
+    if (!aug) {
+        // the diagonal block of Rm is only read by rdiag_stats_kernel: a dead pivot shows up there as 0
 #pragma unroll
-    for (int i = kCB - 1; i >= 0; --i) {
-        double sum = (i == c) ? 1.0 : 0.0;
-#pragma unroll
-        for (int t = i + 1; t < kCB; ++t) sum -= readlane_f64(col[i], t) * x[t];
-        x[i] = (i <= c) ? sum * readlane_f64(invdiag, i) : 0.0;
-    }
-    if (lane < kCB) {
-        const bool dead_c = (dead_mask >> c) & 1u;
-#pragma unroll
-        for (int i = 0; i < kCB; ++i) {
-            Dinv[i * kCB + c] = (dead_c || i >= nb || c >= nb) ? 0.0 : x[i];
-            // the diagonal block of Rm is only read by rdiag_stats_kernel: a dead pivot shows up there as 0
+        for (int i = 0; i < kCB; ++i)
             if (i < nb && c < nb) Rm[(int64_t)(j0 + i) * ldh + j0 + c] = (i < c || (i == c && !dead_c)) ? col[i] : 0.0;
+    } else {
+        // lane 32 + c holds column c of R^-T = row c of R^-1
+#pragma unroll
+        for (int t = 0; t < kCB; ++t) {
+            const bool dead_t = (dead_mask >> t) & 1u;
+            Dinv[c * kCB + t] = (dead_t || dead_c || t < c || t >= nb || c >= nb) ? 0.0 : col[t];
         }
     }
 }
