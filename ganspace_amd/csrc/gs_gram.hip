@@ -309,7 +309,9 @@ __device__ __forceinline__ void gram_tile(const GramTileCtx &c, float (*lds)[2][
     const int nfull = (int)((body - first) / kKB) * (body > 0 ? 1 : 0);
     const int rest = body == 0 ? 0 : (int)(nrows - body);             // < 16 rows, only at the end of a launch
     const int nst = (nrows > 0 ? 1 : 0) + nfull + (rest > 0 ? 1 : 0);
-    const bool tile_full = VEC && (c.I + 1) * kMacroTile <= d && (c.J + 1) * kMacroTile <= d;   // workgroup-uniform
+    // workgroup-uniform: all 128 columns of both panels exist, and every byte offset of the launch fits the 32-bit
+    // offsets of the buffer loads (it does for ld <= 8192 * 5; a block that is a narrow slice of a huge row falls back)
+    const bool tile_full = VEC && (c.I + 1) * kMacroTile <= d && (c.J + 1) * kMacroTile <= d && xbytes < 0xFFFFFFFFull;
     const int arow = lane >> 5;
     const int acol = wi * 64 + (lane & 31);
     const int bcol = wj * 32 + (lane & 31);

@@ -528,14 +528,17 @@ int eigh_topk_subspace(SubspaceWorkspace &ws, const double *A, int n, int64_t ld
             const int ndead = (int)host[5];
             if (j > 0 && dmin > 0.0 && dmax > dmin) {
                 const double g = pow(dmax / dmin, 1.0 / j);
-                int it = (int)floor(log(1e6) / log(g));
+                const double itd = log(1e6) / log(g);                  // g -> 1 makes this huge: clamp before the cast
+                int it = !(itd < 4.0) ? 4 : (int)floor(itd);
                 if (ndead > 0 && it >= interval) it = interval - 1;
                 interval = it < 1 ? 1 : (it > 4 ? 4 : it);
             }
             if (j > 0 && rk > 0.0 && rp > 0.0 && rp < rk && r1 >= rk) {
                 rho = pow(rp / rk, 1.0 / j);
                 if (!warm && mults >= 2) {
-                    const double pred = log(tol_rel * pow(r1 / rk, 1.0 / j)) / log(rho);
+                    double pred = log(tol_rel * pow(r1 / rk, 1.0 / j)) / log(rho);
+                    if (!(pred < (double)max_mults)) pred = (double)max_mults;   // rho -> 1 (flat spectrum) / NaN
+                    if (pred < 0.0) pred = 0.0;
                     int target = 2 * (int)floor(pred / 2.0) + 2;
                     if (target < 4) target = 4;
                     next_rr = target > max_mults ? max_mults : target;
@@ -586,7 +589,9 @@ int eigh_topk_subspace(SubspaceWorkspace &ws, const double *A, int n, int64_t ld
         // products still needed: the worst residual shrinks by ~rho per product
         int extra = 4;
         if (rho > 0.0 && rho < 1.0 && th1 > 0.0 && worst > 0.0) {
-            const double need = log(tol_rel * th1 / sqrt(worst)) / log(rho);
+            double need = log(tol_rel * th1 / sqrt(worst)) / log(rho);
+            if (!(need < 16.0)) need = 16.0;
+            if (need < 0.0) need = 0.0;
             extra = (int)ceil(need) + 1;
             if (extra < 2) extra = 2;
             if (extra > 16) extra = 16;

@@ -69,6 +69,23 @@ def test_gram_row_count_sweep(dev, d):
             np.testing.assert_allclose(cs.cpu().numpy(), Xh.astype(np.float64).sum(0), atol=2e-5 * max(1.0, rows ** 0.5))
 
 
+def test_gram_block_is_a_narrow_slice_of_very_wide_rows(dev):
+    """ld >> d with more than 4 GB between the first and the last row: the buffer-resource fast path (32-bit byte
+    offsets) must hand over to the general path."""
+    from ganspace_amd import ops
+    rows, d, ld = 18000, 256, 60000                       # 4.3 GB of float32
+    g = torch.Generator(device=dev).manual_seed(3)
+    big = torch.empty((rows, ld), dtype=torch.float32, device=dev)
+    big[:, :d] = torch.randn((rows, d), generator=g, device=dev)
+    X = big[:, :d]
+    G, cs = ops.gram_accumulate(X)
+    Xd = X.double()
+    Gref = (Xd.T @ Xd)
+    assert float((G - Gref).abs().max() / Gref.abs().max()) <= 2e-6
+    assert float((cs - Xd.sum(0)).abs().max()) <= 1e-2
+    del big
+
+
 def test_gram_accumulates_and_is_linear(dev):
     from ganspace_amd import ops
     rs = np.random.RandomState(5)
