@@ -69,13 +69,21 @@ def generate(kind: str, seeds, n: int, dim: int, truncation: float = 1.0, worker
             p.stdin.write(json.dumps(job).encode())
             p.stdin.close()
             procs.append(p)
+        # flag protocol (one byte per batch): 0 untouched, 2 claimed by a worker, 1 ready in `data`, 3 taken by the
+        # parent.  While the workers are still starting up (python + numpy import, ~1-2 s on a cold box) the parent
+        # generates the batches it needs itself instead of waiting; a worker skips what the parent took.  A lost
+        # race only means a batch is generated twice - the result is a pure function of its seed.
         try:
             for i in range(len(seeds)):
-                while not done[i]:
+                if done[i] == 0:
+                    done[i] = 3
+                    yield _one(kind, seeds[i], n, dim, truncation)
+                    continue
+                while done[i] != 1:
                     if any(p.poll() not in (None, 0) for p in procs):
                         raise RuntimeError("z-generation worker failed")
                     time.sleep(0.0005)
-                yield np.array(data[i])
+                yield data[i]          # a view into the shared map: consume (copy) it before the next batch is requested
         finally:
             for p in procs:
                 if p.poll() is None:
@@ -87,11 +95,14 @@ def _worker_main():
     job = json.loads(sys.stdin.buffer.read().decode())
     data = np.load(job["data"], mmap_mode="r+")
     done = np.load(job["done"], mmap_mode="r+")
+    # No msync: parent and workers map the same file MAP_SHARED, which is coherent without it (and on a multi-GB map
+    # every flush() walked the whole mapping).  The flag is written after the data; x86 keeps the stores in order.
     for i, seed in job["items"]:
+        if done[i] != 0:            # the parent took this batch while we were starting up
+            continue
+        done[i] = 2
         data[i] = _one(job["kind"], seed, job["n"], job["dim"], job["truncation"])
-        data.flush()
         done[i] = 1
-        done.flush()
 
 
 if __name__ == "__main__":

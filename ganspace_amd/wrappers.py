@@ -284,7 +284,9 @@ class StyleGAN2(BaseModel):
     z_spec = ("stylegan", 512)
 
     def latent_from_z(self, z_host):
-        z = torch.from_numpy(z_host).float().to(self.device)
+        """z (host ndarray, or a tensor already on its way to the device) -> the latent the block loop uses."""
+        z = z_host if torch.is_tensor(z_host) else torch.from_numpy(z_host)
+        z = z.float().to(self.device)
         if self.w_primary:
             z = self.model.style(z)
         return z
@@ -477,7 +479,8 @@ class BigGAN(BaseModel):
     z_spec = ("biggan", 128)
 
     def latent_from_z(self, z_host):
-        return torch.from_numpy(z_host).to(self.device)
+        z = z_host if torch.is_tensor(z_host) else torch.from_numpy(z_host)
+        return z.to(self.device)
 
     def get_max_latents(self):
         return len(self.model.config.layers) + 1
