@@ -493,7 +493,7 @@ int eigh_topk_subspace(SubspaceWorkspace &ws, const double *A, int n, int64_t ld
     // time; consecutive blocks of the incremental PCA have near-identical spectra), minus a probe step now and
     // then when the last solve converged with a wide margin.
     int mults = 0, interval = 2, orths = 0, next_rr = warm ? (ws.warm_mults > 4 ? ws.warm_mults : 4) : max_mults;
-    double rho = 0.0;
+    double rho = 0.0, prev_worst = 0.0;
     *converged = 0;
     std::vector<double> host(k + 8);
     double *stats = ws.theta + 3 * ws.pp + 8;     // 6 doubles behind the pivot floors
@@ -585,6 +585,15 @@ int eigh_topk_subspace(SubspaceWorkspace &ws, const double *A, int n, int64_t ld
             GS_HIP_CHECK(hipGetLastError());
             break;
         }
+        // Stalled?  Between two projections the squared residual should shrink by rho^(2 * products); if it has
+        // not even halved the residual, the wanted eigenvalues are (numerically) degenerate with their neighbours
+        // - white-noise blocks, k cutting through a cluster - and more products will not help: hand over to the
+        // full Jacobi solver now instead of after max_mults products and a dozen projections.
+        if (prev_worst > 0.0 && worst > 0.25 * prev_worst) {
+            *converged = 0;
+            break;
+        }
+        prev_worst = worst;
         std::swap(Q, Z);  // continue from the Ritz basis (B stays nearly diagonal: warm Jacobi next time)
         // products still needed: the worst residual shrinks by ~rho per product
         int extra = 4;
