@@ -102,3 +102,18 @@ def test_sample_latent_follows_the_reference_seed_stream(monkeypatch):
     np.testing.assert_array_equal(z1.numpy(), zstream.stylegan_z_batch(seeds[0], 4))
     np.testing.assert_array_equal(z2.numpy(), zstream.stylegan_z_batch(seeds[1], 3))
     np.testing.assert_array_equal(m.sample_latent(2, seed=5).numpy(), zstream.stylegan_z_batch(5, 2))
+
+
+@pytest.mark.parametrize("kind,dim", [("stylegan", 64), ("biggan", 16)])
+def test_parallel_z_generation_is_bit_identical_and_ordered(monkeypatch, kind, dim):
+    """Worker subprocesses + the parent's own share (it generates batches itself while workers start up) must give
+    exactly the batches of the reference's serial protocol, in seed order (oracle/zstream.py)."""
+    from ganspace_amd import _zgen
+    from oracle import zstream
+    monkeypatch.setenv("GANSPACE_ZGEN_WORKERS", "3")
+    seeds = [11, 7, 123456, 42, 7, 99, 2_000_000_000, 5, 31337, 8]
+    got = [np.array(z) for z in _zgen.generate(kind, seeds, 37, dim, 0.8)]
+    assert len(got) == len(seeds)
+    for s, z in zip(seeds, got):
+        want = zstream.stylegan_z_batch(s, 37, dim) if kind == "stylegan" else zstream.biggan_z_batch(s, 37, dim, 0.8)
+        np.testing.assert_array_equal(z, want)
