@@ -39,6 +39,9 @@ SIGNATURES = {
     "gs_gram_accumulate_prec": (_int, [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _int, _vp]),
     "gs_gram_kernel_time": (_int, [_vp, _vp, _i64, _i64, _int, _vp, _vp, _vp]),
     "gs_eigh_sym": (_int, [_vp, _vp, _int, _vp, _vp]),
+    "gs_eigh_topk": (_int, [_vp, _int, _int, _vp, _int, _vp, _vp, _vp, _vp]),
+    "gs_chol_inv": (_int, [_vp, _int, _vp, _vp, _vp]),
+    "gs_jacobi_small": (_int, [_vp, _int, _vp, _vp, _vp, _vp]),
     "gs_mapping_forward": (_int, [_vp, _vp, _vp, _vp, _vp, _int, _int, _f32, _f32, _f32, _f32, _int, _i64, _vp]),
     "gs_linear_forward": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _int, _vp]),
 }

@@ -88,13 +88,32 @@ int rank_columns(const EighWorkspace &ws, int n, hipStream_t stream);
 // column sums of X[rows, ld] accumulated (atomically) into out[d] (float64, caller zeroes it)
 int column_sums_f64(const float *X, int64_t rows, int64_t ld, int64_t d, double *out, hipStream_t stream);
 
-// ---- top-k subspace eigensolver: gs_subspace.hip ---------------------------------------------------
+// ---- float64 GEMM with arbitrary element strides: gs_subspace.hip -------------------------------------
+// C[M x N] (row-major, ldc) = beta C + alpha sum_t A(i,t) B(t,j);  A(i,t) = A[i a_i + t a_t], B(t,j) = B[t b_t + j b_j].
+// With an epilogue:  C = coef[0] (A B) + coef[1] E1 + coef[2] E2  (coef: 3 doubles in DEVICE memory; E1 / E2 laid
+// out like C, may be null).  allow_split lets small outputs with a long K use split-K (atomic epilogue after a
+// zeroing launch).
+struct GemmEpilogue {
+    const double *coef = nullptr;
+    const double *E1 = nullptr;
+    const double *E2 = nullptr;
+};
+void gemm_f64(int M, int N, int K, const double *A, int64_t a_i, int64_t a_t, const double *B, int64_t b_t,
+              int64_t b_j, double *C, int64_t ldc, hipStream_t stream, double alpha = 1.0, double beta = 0.0,
+              const GemmEpilogue &epi = GemmEpilogue(), bool allow_split = true);
+
+// ---- top-k subspace eigensolver: gs_subspace.hip / gs_topk.hip ----------------------------------------
 struct SubspaceWorkspace {
     int n_cap = 0, p_cap = 0, pp = 0;
     int warm_mults = 0;            // products the last converged warm-started solve used (schedule hint)
+    // gs_topk.hip: filter schedule of the last converged warm-started solve (reused without a host round trip)
+    bool plan_valid = false;
+    int plan_p = 0, plan_deg = 1, plan_ncyc = 1;
+    double plan_gain = 0.0;
+    int last_rr_sweeps = 0;        // Jacobi sweeps of the last Rayleigh-Ritz step
     double *Q = nullptr, *Y = nullptr, *Z = nullptr, *R = nullptr;  // [n][pp]
     double *H = nullptr, *B = nullptr, *U = nullptr;                // [pp][pp]
-    double *theta = nullptr;                                        // [3*pp + 16]: Ritz values | residuals | pivot floors | R-diagonal statistics
+    double *theta = nullptr;                                        // [3*pp + 32]: Ritz values | residuals | pivot floors / R diagonal | statistics (8) | filter coefficients (6)
     double *Rm = nullptr;                                           // [pp][pp] Cholesky factor
     double *Dinv = nullptr;                                         // inverses of its 32 x 32 diagonal blocks
     EighWorkspace ews;
@@ -106,6 +125,16 @@ int subspace_dim(int n, int k);
 int eigh_topk_subspace(SubspaceWorkspace &ws, const double *A, int n, int64_t lda, int k, const double *V0, int k0,
                        int64_t ldv0, double *Vk, int64_t ldv, double *lam, int *iters_out, int *converged,
                        hipStream_t stream);
+// single-workgroup building blocks of gs_topk.hip (p <= 128):
+//   chol_inv:      H = R^T R (p x p, symmetric positive semi-definite) -> Rinv = R^-1 (upper, row-major), rdiag = diag(R)
+//   jacobi_small:  symmetric B (p x p, p % 8 == 0) -> theta descending, eigenvectors as COLUMNS of U; info = {sweeps, limit hit}
+int chol_inv_launch(const double *H, int64_t ldh, int p, double *Rinv, int64_t ldr, double *rdiag, hipStream_t stream);
+int jacobi_small_launch(const double *B, int64_t ldb, int p, double *U, int64_t ldu, double *theta, int *info,
+                        hipStream_t stream);
+// same contract, Chebyshev-filtered latency-first version for subspace_dim(n, k) <= 128 (gs_topk.hip)
+int eigh_topk_cheb(SubspaceWorkspace &ws, const double *A, int n, int64_t lda, int k, const double *V0, int k0,
+                   int64_t ldv0, double *Vk, int64_t ldv, double *lam, int *iters_out, int *converged,
+                   hipStream_t stream);
 
 // ---- small-side recurrence for d >> m: gs_smallside.hip -------------------------------------------
 struct SmallSide {

@@ -734,4 +734,68 @@ int gs_eigh_sym(double *A, double *w, int n, int *sweeps_out_host, void *stream_
     return rc;
 }
 
+int gs_chol_inv(const double *H, int p, double *Rinv, double *rdiag, void *stream_) {
+    GS_REQUIRE(H && Rinv && rdiag, GS_EINVAL, "gs_chol_inv: NULL argument");
+    return chol_inv_launch(H, p, p, Rinv, p, rdiag, (hipStream_t)stream_);
+}
+
+int gs_jacobi_small(const double *B, int p, double *U, double *theta, int *info_host, void *stream_) {
+    GS_REQUIRE(B && U && theta, GS_EINVAL, "gs_jacobi_small: NULL argument");
+    hipStream_t stream = (hipStream_t)stream_;
+    int *info = nullptr;
+    GS_HIP_CHECK(hipMalloc(&info, sizeof(int) * 2));
+    int rc = jacobi_small_launch(B, p, p, U, p, theta, info, stream);
+    int host[2] = {0, 0};
+    if (rc == GS_OK && hipMemcpyAsync(host, info, sizeof(int) * 2, hipMemcpyDeviceToHost, stream) != hipSuccess) rc = GS_EHIP;
+    if (hipStreamSynchronize(stream) != hipSuccess) rc = GS_EHIP;
+    (void)hipFree(info);
+    if (info_host) {
+        info_host[0] = host[0];
+        info_host[1] = host[1];
+    }
+    return rc;
+}
+
+int gs_eigh_topk(const double *A, int n, int k, const double *V0, int k0, double *V, double *w, int *info_host,
+                 void *stream_) {
+    GS_REQUIRE(A && V && w && n >= 2 && k >= 1 && k <= n, GS_EINVAL, "gs_eigh_topk: bad argument");
+    GS_REQUIRE(k0 == 0 || (V0 != nullptr && k0 <= k), GS_EINVAL, "gs_eigh_topk: bad warm start");
+    const int p = subspace_dim(n, k);
+    GS_REQUIRE(p > 0, GS_EINVAL, "gs_eigh_topk: subspace too large for n (use gs_eigh_sym)");
+    hipStream_t stream = (hipStream_t)stream_;
+    SubspaceWorkspace ws;
+    int rc = subspace_workspace_alloc(ws, n, p);
+    EighWorkspace ews;
+    double *W = nullptr;
+    int mults = 0, converged = 0, sweeps = 0;
+    if (rc == GS_OK)
+        rc = eigh_topk_subspace(ws, A, n, n, k, V0, k0, n, V, n, w, &mults, &converged, stream);
+    if (rc == GS_OK && !converged) {
+        // fall-back: full Jacobi on a copy, top-k columns by norm
+        rc = eigh_workspace_alloc(ews, n + 2);
+        if (rc == GS_OK && hipMalloc(&W, sizeof(double) * (size_t)n * n) != hipSuccess) rc = GS_ENOMEM;
+        if (rc == GS_OK) {
+            (void)hipMemcpyAsync(W, A, sizeof(double) * (size_t)n * n, hipMemcpyDeviceToDevice, stream);
+            rc = eigh_jacobi(ews, W, n, n, &sweeps, stream);
+        }
+        if (rc == GS_OK) rc = rank_columns(ews, n, stream);
+        if (rc == GS_OK) {
+            hipLaunchKernelGGL(select_topk_kernel, dim3((unsigned)ceil_div(n, 4)), dim3(256), 0, stream, W, ews.norms,
+                               ews.rank, V, w, n, (int64_t)n, n, k);
+            if (hipGetLastError() != hipSuccess) rc = GS_EHIP;
+        }
+    }
+    if (hipStreamSynchronize(stream) != hipSuccess && rc == GS_OK) rc = GS_EHIP;
+    if (info_host) {
+        info_host[0] = mults;
+        info_host[1] = converged;
+        info_host[2] = converged ? ws.last_rr_sweeps : sweeps;
+        info_host[3] = p;
+    }
+    subspace_workspace_free(ws);
+    eigh_workspace_free(ews);
+    if (W) (void)hipFree(W);
+    return rc;
+}
+
 }  // extern "C"

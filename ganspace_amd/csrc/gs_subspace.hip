@@ -49,7 +49,8 @@ template <int TM, int TN>
 __global__ __launch_bounds__(256) void gemm_f64_kernel(int M, int N, int K, const double *__restrict__ A,
                                                        int64_t a_i, int64_t a_t, const double *__restrict__ B,
                                                        int64_t b_t, int64_t b_j, double *__restrict__ C,
-                                                       int64_t ldc, double alpha, double beta, int kchunk) {
+                                                       int64_t ldc, double alpha, double beta, int kchunk,
+                                                       GemmEpilogue epi) {
     constexpr int RM = TM / 16, RN = TN / 16;            // micro-tile
     constexpr int EA = TM * kTK / 256, EB = TN * kTK / 256;  // elements staged per thread
     __shared__ double As[kTK][TM + 1];
@@ -128,7 +129,13 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(int M, int N, int K, cons
             const int gj = j0 + tx + 16 * c;
             if (gj < N) {
                 double *dst = C + (int64_t)gi * ldc + gj;
-                if (split)
+                if (epi.coef != nullptr) {
+                    // C = coef[0] A B + coef[1] E1 + coef[2] E2 (coefficients live on the device; never split)
+                    double v = epi.coef[0] * acc[r][c];
+                    if (epi.E1) v += epi.coef[1] * epi.E1[(int64_t)gi * ldc + gj];
+                    if (epi.E2) v += epi.coef[2] * epi.E2[(int64_t)gi * ldc + gj];
+                    *dst = v;
+                } else if (split)
                     atomicAdd(dst, alpha * acc[r][c]);
                 else
                     *dst = (beta == 0.0) ? alpha * acc[r][c] : beta * *dst + alpha * acc[r][c];
@@ -142,15 +149,16 @@ __global__ void zero_rows_kernel(double *__restrict__ C, int M, int N, int64_t l
     if (j < N) C[(int64_t)blockIdx.y * ldc + j] = 0.0;
 }
 
-static void gemm_f64(int M, int N, int K, const double *A, int64_t a_i, int64_t a_t, const double *B, int64_t b_t,
-                     int64_t b_j, double *C, int64_t ldc, hipStream_t stream, double alpha = 1.0, double beta = 0.0) {
+void gemm_f64(int M, int N, int K, const double *A, int64_t a_i, int64_t a_t, const double *B, int64_t b_t,
+              int64_t b_j, double *C, int64_t ldc, hipStream_t stream, double alpha, double beta,
+              const GemmEpilogue &epi, bool allow_split) {
     if (M <= 0 || N <= 0) return;
     const bool small_tiles = ceil_div(M, 64) * ceil_div(N, 64) < 64;
     const int TMv = small_tiles ? 32 : 64;
     const int64_t tiles = ceil_div(M, TMv) * ceil_div(N, TMv);
     // split K (atomic epilogue) when the output alone cannot cover the chip and K is long enough
     int splits = 1;
-    if (beta == 0.0 && tiles < 128 && K >= 256) {
+    if (allow_split && epi.coef == nullptr && beta == 0.0 && tiles < 128 && K >= 256) {
         splits = (int)ceil_div(160, tiles);
         if (splits > K / 64) splits = K / 64;
         if (splits < 1) splits = 1;
@@ -163,10 +171,10 @@ static void gemm_f64(int M, int N, int K, const double *A, int64_t a_i, int64_t 
     dim3 grid((unsigned)ceil_div(N, TMv), (unsigned)ceil_div(M, TMv), (unsigned)splits);
     if (small_tiles)
         hipLaunchKernelGGL((gemm_f64_kernel<32, 32>), grid, dim3(256), 0, stream, M, N, K, A, a_i, a_t, B, b_t, b_j, C,
-                           ldc, alpha, beta, kchunk);
+                           ldc, alpha, beta, kchunk, epi);
     else
         hipLaunchKernelGGL((gemm_f64_kernel<64, 64>), grid, dim3(256), 0, stream, M, N, K, A, a_i, a_t, B, b_t, b_j, C,
-                           ldc, alpha, beta, kchunk);
+                           ldc, alpha, beta, kchunk, epi);
 }
 
 // deterministic pseudo-random start: Q[i][j] in (-1, 1)
@@ -427,7 +435,7 @@ int subspace_workspace_alloc(SubspaceWorkspace &ws, int n, int p) {
     if (rc == GS_OK) rc = alloc(&ws.H, ppp);
     if (rc == GS_OK) rc = alloc(&ws.B, ppp);
     if (rc == GS_OK) rc = alloc(&ws.U, ppp);
-    if (rc == GS_OK) rc = alloc(&ws.theta, 3 * (size_t)ws.pp + 16);
+    if (rc == GS_OK) rc = alloc(&ws.theta, 3 * (size_t)ws.pp + 32);
     if (rc == GS_OK) rc = alloc(&ws.Rm, ppp);
     if (rc == GS_OK) rc = alloc(&ws.Dinv, (size_t)(ws.pp / 16 + 1) * kCB * kCB);
     if (rc == GS_OK && hipMemset(ws.Rm, 0, sizeof(double) * ppp) != hipSuccess) rc = GS_EHIP;
@@ -467,6 +475,9 @@ int eigh_topk_subspace(SubspaceWorkspace &ws, const double *A, int n, int64_t ld
                        hipStream_t stream) {
     const int p = subspace_dim(n, k);
     GS_REQUIRE(p > 0 && n <= ws.n_cap && p <= ws.p_cap, GS_EINVAL, "eigh_topk_subspace: bad sizes");
+    static const bool legacy = getenv("GS_SUBSPACE_LEGACY") != nullptr;
+    if (p <= 128 && !legacy)
+        return eigh_topk_cheb(ws, A, n, lda, k, V0, k0, ldv0, Vk, ldv, lam, iters_out, converged, stream);
     const int64_t ld = ws.pp;
     double *Q = ws.Q, *Y = ws.Y, *Z = ws.Z;
     const dim3 gnp((unsigned)ceil_div(p, 64), (unsigned)n), b64(64);

@@ -89,3 +89,55 @@ def linear_forward(x, weight, bias=None):
     _lib.check(lib.gs_linear_forward(_p(x), _p(weight), _p(bias), _p(y), x.shape[0], in_f, out_f,
                                      _lib.current_stream_ptr()))
     return y
+
+
+def eigh_topk(A, k, V0=None):
+    """Leading ``k`` eigenpairs of a symmetric PSD float64 matrix (Chebyshev-filtered subspace iteration):
+    returns ``(w [k] descending, V [k, n] eigenvectors as rows, info)`` with
+    ``info = dict(products, converged, sweeps, subspace)``."""
+    import torch
+    lib = _lib.load()
+    _need_cuda(A, V0)
+    assert A.dtype == torch.float64 and A.dim() == 2 and A.shape[0] == A.shape[1]
+    A = A.contiguous()
+    n = A.shape[0]
+    V = torch.empty((k, n), dtype=torch.float64, device=A.device)
+    w = torch.empty(k, dtype=torch.float64, device=A.device)
+    k0 = 0
+    if V0 is not None:
+        V0 = V0.to(torch.float64).contiguous()
+        k0 = V0.shape[0]
+    info = (C.c_int * 4)()
+    _lib.check(lib.gs_eigh_topk(_p(A), n, k, _p(V0), k0, _p(V), _p(w), C.cast(info, C.c_void_p),
+                                _lib.current_stream_ptr()))
+    return w, V, dict(products=info[0], converged=bool(info[1]), sweeps=info[2], subspace=info[3])
+
+
+def chol_inv(H):
+    """Single-workgroup Cholesky + inverse of a Gram matrix ``H = R^T R`` (p <= 128): ``(Rinv, rdiag)``."""
+    import torch
+    lib = _lib.load()
+    _need_cuda(H)
+    assert H.dtype == torch.float64 and H.dim() == 2 and H.shape[0] == H.shape[1]
+    H = H.contiguous()
+    p = H.shape[0]
+    Rinv = torch.empty_like(H)
+    rdiag = torch.empty(p, dtype=torch.float64, device=H.device)
+    _lib.check(lib.gs_chol_inv(_p(H), p, _p(Rinv), _p(rdiag), _lib.current_stream_ptr()))
+    return Rinv, rdiag
+
+
+def jacobi_small(B):
+    """Single-workgroup eigensolver for a symmetric ``p x p`` float64 matrix (p % 8 == 0, p <= 128):
+    ``(theta [p] descending, U [p, p] eigenvectors as columns, sweeps, limit_hit)``."""
+    import torch
+    lib = _lib.load()
+    _need_cuda(B)
+    assert B.dtype == torch.float64 and B.dim() == 2 and B.shape[0] == B.shape[1]
+    B = B.contiguous()
+    p = B.shape[0]
+    U = torch.empty_like(B)
+    theta = torch.empty(p, dtype=torch.float64, device=B.device)
+    info = (C.c_int * 2)()
+    _lib.check(lib.gs_jacobi_small(_p(B), p, _p(U), _p(theta), C.cast(info, C.c_void_p), _lib.current_stream_ptr()))
+    return theta, U, info[0], bool(info[1])

@@ -148,6 +148,23 @@ int gs_gram_kernel_time(gs_ipca_t *h, const float *X, int64_t rows, int64_t ld, 
  * as |lambda|.  sweeps_out (host, optional) receives the number of sweeps used.         */
 int gs_eigh_sym(double *A, double *w, int n, int *sweeps_out_host, void *stream);
 
+/* Leading k eigenpairs of a symmetric positive semi-definite float64 matrix A [n*n] (the d x d / r x r matrix whose
+ * decomposition stands in for LAPACK gesdd, sklearn _incremental_pca.py:362): Chebyshev-filtered subspace
+ * iteration (gs_topk.hip) with the full Jacobi solver as fall-back.  V [k*n]: unit eigenvectors as ROWS (sign
+ * arbitrary), w [k] descending.  V0 (device, k0 rows of n, may be NULL with k0 = 0) warm-starts the subspace.
+ * info_host (optional, 4 ints): {products by A, 1 = subspace solve converged / 0 = fall-back ran, Jacobi sweeps of
+ * the projection step, subspace dimension}.  Needs 2 * subspace_dim <= n (otherwise use gs_eigh_sym).               */
+int gs_eigh_topk(const double *A, int n, int k, const double *V0, int k0, double *V, double *w, int *info_host,
+                 void *stream);
+
+/* Single-workgroup building blocks of that solver, exposed for unit tests (p <= 128):
+ * gs_chol_inv:     H [p*p] = R^T R  ->  Rinv [p*p] = R^-1 (upper triangular, row-major), rdiag [p] = diag(R);
+ *                  numerically dependent columns get a zero row / column (rdiag = 0).
+ * gs_jacobi_small: symmetric B [p*p], p % 8 == 0 -> theta [p] descending, eigenvectors as COLUMNS of U [p*p];
+ *                  info_host (2 ints) = {sweeps, 1 if the sweep limit was hit}.                                       */
+int gs_chol_inv(const double *H, int p, double *Rinv, double *rdiag, void *stream);
+int gs_jacobi_small(const double *B, int p, double *U, double *theta, int *info_host, void *stream);
+
 /* z -> w: the StyleGAN2 mapping network `Generator.style` called from
  * models/wrappers.py:177,200 (PixelNorm + L x EqualLinear(dim, dim, lr_mul,
  * activation='fused_lrelu')); in-tree analogue models/stylegan/model.py:190-216.

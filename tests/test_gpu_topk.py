@@ -1,0 +1,159 @@
+"""GPU tests of the latency-first top-k eigensolver (gs_topk.hip) and its single-workgroup building blocks,
+against NumPy/LAPACK float64 on the same matrices.  The solver stands in for LAPACK gesdd inside
+``IncrementalPCA.partial_fit`` (sklearn/decomposition/_incremental_pca.py:362); end-to-end parity with the
+reference is covered by test_gpu_parity.py / test_gpu_decomposition.py."""
+import numpy as np
+import pytest
+
+import inputs as gin
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a HIP device; the product path has no CPU fallback")
+    from ganspace_amd import _lib
+    _lib.load()
+    return torch.device("cuda", 0)
+
+
+def _spd(p, seed, cond=1e3):
+    rs = np.random.RandomState(seed)
+    Q, _ = np.linalg.qr(rs.standard_normal((p, p)))
+    ev = np.logspace(0, -np.log10(cond), p)
+    return (Q * ev) @ Q.T
+
+
+@pytest.mark.parametrize("p,cond", [(128, 1e3), (128, 1e10), (96, 1e6), (80, 1e2), (37, 1e4), (5, 10.0), (1, 1.0)])
+def test_chol_inv_matches_lapack(dev, p, cond):
+    from ganspace_amd import ops
+    H = _spd(p, 100 + p, cond)
+    Rinv, rdiag = ops.chol_inv(torch.from_numpy(H).to(dev))
+    Rinv, rdiag = Rinv.cpu().numpy(), rdiag.cpu().numpy()
+    R = np.linalg.cholesky(H).T
+    np.testing.assert_allclose(rdiag, np.diag(R), rtol=1e-9 * max(1.0, cond ** 0.5))
+    assert np.abs(np.tril(Rinv, -1)).max() == 0.0                     # upper triangular
+    # Q = Y R^-1 must be orthonormal:  R^-T H R^-1 = I
+    err = np.abs(Rinv.T @ H @ Rinv - np.eye(p)).max()
+    assert err <= 1e-15 * cond + 1e-12, err
+
+
+def test_chol_inv_zeroes_dependent_columns(dev):
+    """A numerically dependent basis column (pivot lost > 13 digits) gets a zero row/column of R^-1, so the
+    corresponding column of Y R^-1 is exactly zero instead of noise (the subspace shrinks)."""
+    from ganspace_amd import ops
+    rs = np.random.RandomState(3)
+    Y = rs.standard_normal((300, 64))
+    Y[:, 40] = Y[:, 3] * 2.0 - Y[:, 17]          # exact linear dependence
+    Y[:, 63] = Y[:, 62]
+    H = Y.T @ Y
+    Rinv, rdiag = ops.chol_inv(torch.from_numpy(H).to(dev))
+    Rinv, rdiag = Rinv.cpu().numpy(), rdiag.cpu().numpy()
+    assert rdiag[40] == 0.0 and rdiag[63] == 0.0 and (np.delete(rdiag, [40, 63]) > 0).all()
+    assert np.abs(Rinv[40]).max() == 0.0 and np.abs(Rinv[:, 40]).max() == 0.0
+    Q = Y @ Rinv
+    live = np.delete(np.arange(64), [40, 63])
+    assert np.abs(Q[:, [40, 63]]).max() == 0.0
+    assert np.abs(Q[:, live].T @ Q[:, live] - np.eye(62)).max() < 1e-10
+
+
+@pytest.mark.parametrize("p,kind", [(128, "dense"), (128, "neardiag"), (128, "clustered"), (112, "dense"),
+                                    (96, "dense"), (80, "dense"), (64, "lowrank"), (16, "dense"), (8, "dense")])
+def test_jacobi_small_matches_lapack(dev, p, kind):
+    from ganspace_amd import ops
+    rs = np.random.RandomState(p + len(kind))
+    if kind == "dense":
+        B = _spd(p, p, 1e4)
+    elif kind == "neardiag":
+        B = np.diag(np.logspace(0, -3, p)) + 1e-6 * rs.standard_normal((p, p))
+        B = (B + B.T) / 2
+    elif kind == "clustered":
+        Q, _ = np.linalg.qr(rs.standard_normal((p, p)))
+        ev = np.repeat(np.logspace(0, -2, p // 4), 4) * (1 + 1e-9 * rs.standard_normal(p))
+        B = (Q * ev) @ Q.T
+    else:
+        A = rs.standard_normal((p // 4, p))
+        B = A.T @ A
+    theta, U, sweeps, limit = ops.jacobi_small(torch.from_numpy(B).to(dev))
+    theta, U = theta.cpu().numpy(), U.cpu().numpy()
+    assert not limit and 1 <= sweeps <= 12
+    ref = np.sort(np.abs(np.linalg.eigvalsh(B)))[::-1]
+    scale = ref[0]
+    np.testing.assert_allclose(theta, ref, atol=1e-11 * scale)
+    live = theta > 1e-9 * scale
+    Ul = U[:, live]
+    assert np.abs(Ul.T @ Ul - np.eye(live.sum())).max() < 1e-10       # orthonormal eigenvectors (as columns)
+    assert np.abs(B @ Ul - Ul * theta[live]).max() < 1e-10 * scale       # B u = theta u
+
+
+def _cfg2_like_cov(n_rows=40000, seed=0):
+    """Covariance of the random-init mapping network's W vectors (the spectrum BASELINE cfg2 solves)."""
+    from oracle import synth
+    rs = np.random.RandomState(seed)
+    W = (rs.standard_normal((8, 512, 512)) / 0.01).astype(np.float32)
+    b = np.zeros((8, 512), np.float32)
+    z = rs.standard_normal((n_rows, 512)).astype(np.float32)
+    w = synth.mapping_network(z, W, b, dtype=np.float32).astype(np.float64)
+    wc = w - w.mean(0)
+    return wc.T @ wc
+
+
+def _check_topk(dev, A, k, expect_converged=True, V0=None, ncheck=None, tol=1e-8):
+    from ganspace_amd import ops
+    ev, EV = np.linalg.eigh(A)
+    ev, EV = ev[::-1], EV[:, ::-1]
+    w, V, info = ops.eigh_topk(torch.from_numpy(A).to(dev), k, None if V0 is None else torch.from_numpy(V0).to(dev))
+    w, V = w.cpu().numpy(), V.cpu().numpy()
+    assert info["converged"] == expect_converged, info
+    np.testing.assert_allclose(w, ev[:k], atol=tol * ev[0])
+    ncheck = ncheck or k
+    res = np.linalg.norm(A @ V[:ncheck].T - V[:ncheck].T * w[:ncheck], axis=0).max() / ev[0]
+    assert res < 10 * tol, res
+    assert np.abs(V @ V.T - np.eye(k)).max() < 1e-8
+    return info
+
+
+def test_eigh_topk_cfg2_spectrum(dev):
+    A = _cfg2_like_cov()
+    info = _check_topk(dev, A, 80)
+    assert info["subspace"] == 128 and info["products"] <= 20, info        # round 1 needed 26 products
+
+
+def test_eigh_topk_warm_start(dev):
+    """Faithful-mode situation: previous components seed the subspace of a slightly perturbed matrix."""
+    A = _cfg2_like_cov()
+    ev, EV = np.linalg.eigh(A)
+    V0 = EV[:, ::-1][:, :80].T.copy()
+    rs = np.random.RandomState(9)
+    X = rs.standard_normal((2000, 512)) * 0.3
+    A2 = A + X.T @ X
+    info = _check_topk(dev, A2, 80, V0=V0)
+    assert info["products"] <= 14, info
+
+
+@pytest.mark.parametrize("name", ["d512_k20", "d512_k80_nb10000"])
+def test_eigh_topk_fixture_spectra(dev, name):
+    """Steep spectra (lambda_1 / lambda_p ~ 1e6) sitting on a flat noise floor."""
+    case = gin.IPCA_CASES[name]
+    X = np.concatenate(list(gin.ipca_blocks(case))).astype(np.float64)
+    Xc = X - X.mean(0)
+    _check_topk(dev, Xc.T @ Xc, case["k"], ncheck=case["ncheck"])
+
+
+def test_eigh_topk_rank_deficient(dev):
+    rs = np.random.RandomState(5)
+    A_ = rs.standard_normal((100, 512)) * (1.1 ** -np.arange(100))[:, None]
+    X = rs.standard_normal((3000, 100)) @ A_
+    _check_topk(dev, X.T @ X, 80, expect_converged=True, ncheck=60, tol=1e-7)
+
+
+def test_eigh_topk_white_noise_falls_back(dev):
+    """No gap after the k-th eigenvalue: the filter cannot converge; the full Jacobi solver must take over and
+    still deliver the exact leading pairs."""
+    rs = np.random.RandomState(5)
+    X = rs.standard_normal((4000, 512))
+    _check_topk(dev, X.T @ X, 80, expect_converged=False, ncheck=1)
