@@ -1,23 +1,28 @@
 #!/usr/bin/env python3
 """Headline benchmark: latent samples/s into the PCA (BASELINE.json metric).
 
-Workload = BASELINE config 2: StyleGAN2-ffhq W-space, -n=1_000_000 -b=10_000 -c=80 on one
-MI355X with a random-init mapping network.  A *step* is one IPCA block (NB = 10 000 rows x
-512 features, float32, already resident in HBM) pushed through ``fit_partial``; after the K
-timed steps the job is completed inside the timed region (multi-GPU: the RCCL all-reduce of
-the sufficient statistics; then the eigensolve and the device->host copy of the components),
-so ``value`` is whole-job throughput.  Default K = 100 is exactly n = 1e6 samples per GPU.
+Workload = BASELINE config 2: StyleGAN2-ffhq W-space, -n=1_000_000 -b=10_000 -c=80 on one MI355X with a
+random-init mapping network, fed by the reference's z stream (per-batch-seeded NumPy MT19937,
+models/wrappers.py:167-174, seed list drawn after np.random.seed(1), decomposition.py:226-227) through the HIP
+mapping-network kernel - i.e. through the product's own ``decomposition._presample``.
+
+A *step* is FIVE IPCA blocks (5 x NB = 50 000 rows x 512 features, float32, already resident in HBM) pushed through
+``fit_partial``; the driver's ``--steps 20`` is therefore exactly n = 1e6 samples per GPU.  After the K timed steps
+the job is completed inside the timed region (multi-GPU: the RCCL all-reduce of the sufficient statistics; then
+the eigensolve and the device->host copy of the components), so ``value`` is whole-job throughput and
+``ms_per_step * steps`` is the timed region.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--mode exact|faithful]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-Rank 0 prints ONE JSON line (plus human-readable notes on stderr).
+With N ranks the job is the 8-GPU config in miniature (BASELINE cfg4 layout): ONE z stream for n = N x K x 50 000
+samples, rank r owns the contiguous block range ``distributed.shard_range`` gives it and generates only those z
+batches (weak scaling: the per-GPU work is fixed).  Rank 0 prints ONE JSON line (plus notes on stderr).
 """
 import argparse
 import ctypes as C
 import json
-import math
 import os
 import sys
 import time
@@ -30,6 +35,7 @@ import numpy as np
 import torch
 
 D, NB, K_COMP = 512, 10_000, 80
+BLOCKS_PER_STEP = 5
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_HBM_GBS = 8000.0             # HBM3E spec
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # dense bf16 MFMA peak (the 2:1-sparsity headline figure is not used)
@@ -39,35 +45,46 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def make_mapping_weights(dev):
-    """Random-init StyleGAN2 mapping network: weight = randn(out,in)/lr_mul, bias 0."""
-    g = torch.Generator(device="cpu").manual_seed(0)
-    W = torch.randn(8, D, D, generator=g) / 0.01
-    return W.to(dev), torch.zeros(8, D, device=dev)
-
-
-def make_latents(n_blocks, dev, rank):
-    """W-space latents [n_blocks*NB, 512] float32 in HBM: z ~ N(0,1) -> style(z) (HIP kernel)."""
-    from ganspace_amd import ops
-    W, b = make_mapping_weights(dev)
-    g = torch.Generator(device=dev).manual_seed(1234 + rank)
-    out = torch.empty((n_blocks * NB, D), dtype=torch.float32, device=dev)
-    for i in range(n_blocks):
-        z = torch.randn((NB, D), generator=g, device=dev, dtype=torch.float32)
-        out[i * NB:(i + 1) * NB] = ops.mapping_forward(z, W, b)
+def make_blocks(n_blocks, dev, rank=0, world=1):
+    """The W-space rows the "Fitting batches" loop of cfg2 reads (decomposition.py:245-267), for this rank's share of
+    an n = world x n_blocks x NB job: product path end to end (seed protocol -> parallel z generation -> pinned
+    H2D -> PixelNorm + 8-layer mapping kernel), resident in HBM.  Returns (list of [NB, 512] blocks, seconds)."""
+    from ganspace_amd import decomposition as dec
+    from ganspace_amd.wrappers import get_model
+    t0 = time.perf_counter()
+    model = get_model("StyleGAN2", "ffhq", dev)
+    model.use_w()
+    plan = dec._Plan.make(world * n_blocks * NB, NB, K_COMP)
+    assert plan.NB == NB and len(list(plan.block_starts)) == world * n_blocks
+    starts = plan.shard_blocks(rank, world)
+    b_lo, b_hi = plan.batch_span(starts)
+    latent_shape = model.get_latent_shape()          # (draws from the global stream: before the seeding, as in compute())
+    torch.manual_seed(dec.SEED_SAMPLING)
+    np.random.seed(dec.SEED_SAMPLING)
+    latents, row0 = dec._presample(model, plan, latent_shape, dev, b_lo, b_hi)
     torch.cuda.synchronize()
-    return out
+    blocks = [latents[g - row0:g - row0 + NB].reshape(NB, -1) for g in starts]
+    return blocks, time.perf_counter() - t0
+
+
+def gram_kernel_us(lib, _lib, est, block, iters=50):
+    ms, rows = C.c_float(0), C.c_int64(0)
+    _lib.check(lib.gs_gram_kernel_time(est.transformer._h, C.c_void_p(block.data_ptr()), block.shape[0], block.stride(0),
+                                       iters, C.cast(C.byref(ms), C.c_void_p), C.cast(C.byref(rows), C.c_void_p),
+                                       _lib.current_stream_ptr()))
+    return ms.value * 1e3, rows.value
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--mode", default="exact", choices=["exact", "faithful"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-blocks", type=int, default=16)
     ap.add_argument("--no-wide", action="store_true", help="skip the cfg3/cfg5-shape small-side timings")
+    ap.add_argument("--no-extras", action="store_true", help="headline + roofline only (profiling runs)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -89,11 +106,9 @@ def main():
     lib = _lib.load()
 
     K, Wm = args.steps, args.warmup
-    n_blocks = max(K, Wm, 1)
-    t0 = time.perf_counter()
-    lat = make_latents(n_blocks, dev, rank)
-    t_sample = time.perf_counter() - t0
-    blocks = [lat[i * NB:(i + 1) * NB] for i in range(n_blocks)]
+    n_blocks = K * BLOCKS_PER_STEP
+    blocks, t_sample = make_blocks(n_blocks, dev, rank, world)
+    log(f"rank {rank}: {len(blocks)} blocks of {NB} W-space rows resident ({t_sample:.1f} s: z stream + mapping network)")
 
     def barrier():
         if dist is not None:
@@ -101,12 +116,12 @@ def main():
         torch.cuda.synchronize()
 
     def run(est, nsteps, finish=True):
-        for i in range(nsteps):
+        for i in range(nsteps * BLOCKS_PER_STEP):
             ok = est.fit_partial(blocks[i % n_blocks])
             assert ok
         if finish:
             if dist is not None and args.mode == "exact":
-                gdist.allreduce_estimator(est)
+                gdist.allreduce_estimator(est, d=D)
             est.get_components()           # eigensolve (exact mode) + D2H of the results
 
     # ---- warm-up (untimed) ------------------------------------------------------------------
@@ -126,7 +141,7 @@ def main():
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
-    samples = K * NB * world
+    samples = K * BLOCKS_PER_STEP * NB * world
     value = samples / dt
 
     # ---- split of the job: update loop vs finalize ----------------------------------------------
@@ -142,19 +157,15 @@ def main():
     torch.cuda.synchronize()
     t_final = time.perf_counter() - t0
 
-    # ---- roofline of the dominant kernel (partial X^T X MFMA kernel), HIP events on its stream ---
-    avg_ms = C.c_float(0)
-    rows_timed = C.c_int64(0)
-    _lib.check(lib.gs_gram_kernel_time(est2.transformer._h, C.c_void_p(blocks[0].data_ptr()), NB, D, 50,
-                                       C.cast(C.byref(avg_ms), C.c_void_p),
-                                       C.cast(C.byref(rows_timed), C.c_void_p), _lib.current_stream_ptr()))
-    rows_l = rows_timed.value
+    # ---- roofline of the dominant kernel of the timed region (the partial X^T X MFMA kernel: one launch per
+    #      block, K x 5 launches), HIP events on its stream ----------------------------------------------------
+    us, rows_l = gram_kernel_us(lib, _lib, est2, blocks[0])
     flops = rows_l * D * (D + 1)           # algorithmic: upper triangle incl. diagonal, 2 flop/MAC
     bytes_ = rows_l * D * 4                # algorithmic: one read of the [rows, d] f32 block
-    ach_tf = flops / (avg_ms.value * 1e-3) / 1e12
-    ach_gbs = bytes_ / (avg_ms.value * 1e-3) / 1e9
-    # HBM traffic of that kernel from the committed rocprofv3 PMC passes (bench.py cannot run the
-    # profiler on itself): FETCH_SIZE, x2-corrected as MI355X_MICROARCH.md prescribes, per launch
+    ach_tf = flops / (us * 1e-6) / 1e12
+    ach_gbs = bytes_ / (us * 1e-6) / 1e9
+    # HBM traffic of that kernel from the committed rocprofv3 PMC passes (bench.py cannot run the profiler on
+    # itself): FETCH_SIZE x2-corrected as MI355X_MICROARCH.md prescribes + WRITE_SIZE, per launch
     traffic = None
     traffic_note = None
     try:
@@ -165,11 +176,13 @@ def main():
             traffic_note = pmc.get("traffic_breakdown")
     except Exception:
         pass
+    frac_of_region = (n_blocks * us * 1e-6) / (t_updates + t_final) if (t_updates + t_final) > 0 else None
     roofline = {"bound": "mfma", "kernel": "gram_partial_kernel<true>", "achieved": round(ach_tf, 2),
                 "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach_tf / PEAK_F32_MFMA_TFLOPS, 4),
                 "traffic": traffic, "traffic_source": "profiles/gram_pmc_latest.json (rocprofv3 --pmc FETCH_SIZE, x2)",
                 "traffic_note": traffic_note,
-                "avg_launch_us": round(avg_ms.value * 1e3, 2), "rows_per_launch": rows_l,
+                "avg_launch_us": round(us, 2), "rows_per_launch": rows_l, "launches_in_timed_region": n_blocks,
+                "share_of_timed_region": None if frac_of_region is None else round(frac_of_region, 3),
                 "algorithmic_flops_per_launch": flops, "algorithmic_bytes_per_launch": bytes_,
                 "hbm_achieved_GBs": round(ach_gbs, 1), "hbm_frac_of_8TBs": round(ach_gbs / PEAK_HBM_GBS, 4),
                 "clock_note": "peak = 2.4 GHz x 256 CU x 4 SIMD x 64 flop/clk; the s_memtime traces of this kernel "
@@ -180,18 +193,22 @@ def main():
         "value": round(value, 1), "unit": "samples/s", "n_gpus": world, "steps": K, "warmup": Wm,
         "ms_per_step": round(dt / K * 1e3, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "cfg2: StyleGAN2-ffhq W-space PCA, -n=%d -b=10_000 -c=80 per GPU, "
-                               "random-init mapping network, activations resident in HBM" % (K * NB),
-                   "mode": args.mode, "feat_dim": D, "block_rows": NB, "components": K_COMP,
-                   "parallelism": f"dp{world} (rows sharded, one RCCL all-reduce of n/mean/scatter)"},
+        "config": {"workload": "cfg2: StyleGAN2-ffhq W-space PCA, -n=%d -b=10_000 -c=80 per GPU (%d in total), "
+                               "random-init mapping network, reference z stream (MT19937 per-batch seeds), "
+                               "activations resident in HBM" % (K * BLOCKS_PER_STEP * NB, samples),
+                   "mode": args.mode, "feat_dim": D, "block_rows": NB, "blocks_per_step": BLOCKS_PER_STEP,
+                   "components": K_COMP,
+                   "parallelism": f"dp{world} (blocks of one z stream sharded, one RCCL all-reduce of n/mean/scatter)"},
         "roofline": roofline,
         "breakdown": {"update_loop_s": round(t_updates, 5), "finalize_eigensolve_s": round(t_final, 5),
                       "sampling_zgen_plus_mapping_s": round(t_sample, 4),
+                      "eigh_products": int(lib.gs_ipca_last_mults(est2.transformer._h)),
                       "eigh_sweeps": int(lib.gs_ipca_last_sweeps(est2.transformer._h))},
     }
 
+    extras = rank == 0 and world == 1 and not args.no_extras
     # ---- CPU baseline + cos-sim on a bounded sample (rank 0, N=1 only) -----------------------------
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if extras and not args.no_cpu_baseline:
         from oracle import reference_cpu
         from oracle.ipca import signed_cosines
         nb = min(args.cpu_blocks, n_blocks)
@@ -200,7 +217,7 @@ def main():
         cores = reference_cpu.host_threads()
         out["cpu_baseline"] = {"value": round(n_cpu / t_cpu, 1), "unit": "samples/s", "cores": cores,
                                "kind": "reference",
-                               "sample": f"first {nb} of the {K} blocks ({n_cpu} samples, {t_cpu:.1f} s): "
+                               "sample": f"first {nb} of the {n_blocks} blocks ({n_cpu} samples, {t_cpu:.1f} s): "
                                          "sklearn IncrementalPCA.partial_fit configured as "
                                          "estimators.py:59 (the arithmetic the reference executes), "
                                          f"host cpu_count={os.cpu_count()}"}
@@ -244,13 +261,12 @@ def main():
                 run(e2, K)
                 torch.cuda.synchronize()
                 job = time.perf_counter() - t0
-                ms = C.c_float(0)
-                rt = C.c_int64(0)
-                _lib.check(lib.gs_gram_kernel_time(e2.transformer._h, C.c_void_p(blocks[0].data_ptr()), NB, D, 50,
-                                                   C.cast(C.byref(ms), C.c_void_p), C.cast(C.byref(rt), C.c_void_p),
-                                                   _lib.current_stream_ptr()))
-                mfma_tf = nprod * rt.value * D * (D + 1) / (ms.value * 1e-3) / 1e12
-                split[prec] = {"samples_per_s": round(K * NB / job, 1), "gram_launch_us": round(ms.value * 1e3, 2),
+                us_p, rt = gram_kernel_us(lib, _lib, e2, blocks[0])
+                mfma_tf = nprod * rt * D * (D + 1) / (us_p * 1e-6) / 1e12
+                gbs = rt * D * 4 / (us_p * 1e-6) / 1e9
+                split[prec] = {"samples_per_s": round(n_blocks * NB / job, 1), "gram_launch_us": round(us_p, 2),
+                               "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS,
+                                            "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4)},
                                "bf16_mfma_TFLOPs_executed": round(mfma_tf, 1),
                                "frac_of_bf16_dense_peak": round(mfma_tf / PEAK_BF16_MFMA_TFLOPS, 4),
                                "top20_min_signed_cos": round(float(c[:20].min()), 7),
@@ -259,7 +275,7 @@ def main():
 
     # ---- the wide-feature BASELINE shapes (cfg3 d = 32 768, cfg5 d = 131 072; NB = 2 000, k = 80): PCA-only
     #      throughput of the small-side recurrence on synthetic low-rank-plus-noise device buffers -----------
-    if rank == 0 and world == 1 and not args.no_wide:
+    if extras and not args.no_wide:
         wide = {}
         for name, dd in (("cfg3_shape_d32768", 32768), ("cfg5_shape_d131072", 131072)):
             g = torch.Generator(device=dev).manual_seed(7)

@@ -11,7 +11,7 @@ import os
 
 from . import _build
 
-GS_OK, GS_EINVAL, GS_EHIP, GS_ENOMEM, GS_ESTATE, GS_ENOTIMPL = 0, -1, -2, -3, -4, -5
+GS_OK, GS_EINVAL, GS_EHIP, GS_ENOMEM, GS_ESTATE, GS_ENOTIMPL, GS_ENOCONV = 0, -1, -2, -3, -4, -5, -6
 GS_MODE_EXACT, GS_MODE_FAITHFUL, GS_MODE_SMALLSIDE = 0, 1, 2
 GS_PREC_F32, GS_PREC_BF16X3, GS_PREC_BF16X6 = 0, 1, 2
 PRECISIONS = {"f32": GS_PREC_F32, "bf16x3": GS_PREC_BF16X3, "bf16x6": GS_PREC_BF16X6}
@@ -40,7 +40,7 @@ SIGNATURES = {
     "gs_gram_kernel_time": (_int, [_vp, _vp, _i64, _i64, _int, _vp, _vp, _vp]),
     "gs_eigh_sym": (_int, [_vp, _vp, _int, _vp, _vp]),
     "gs_eigh_topk": (_int, [_vp, _int, _int, _vp, _int, _vp, _vp, _vp, _vp]),
-    "gs_chol_inv": (_int, [_vp, _int, _vp, _vp, _vp]),
+    "gs_cholqr": (_int, [_vp, _int, _int, _vp, _vp, _vp]),
     "gs_jacobi_small": (_int, [_vp, _int, _vp, _vp, _vp, _vp]),
     "gs_mapping_forward": (_int, [_vp, _vp, _vp, _vp, _vp, _int, _int, _f32, _f32, _f32, _f32, _int, _i64, _vp]),
     "gs_linear_forward": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _int, _vp]),

@@ -126,11 +126,18 @@ int eigh_topk_subspace(SubspaceWorkspace &ws, const double *A, int n, int64_t ld
                        int64_t ldv0, double *Vk, int64_t ldv, double *lam, int *iters_out, int *converged,
                        hipStream_t stream);
 // single-workgroup building blocks of gs_topk.hip (p <= 128):
-//   chol_inv:      H = R^T R (p x p, symmetric positive semi-definite) -> Rinv = R^-1 (upper, row-major), rdiag = diag(R)
+//   chol_blocked:  H = R^T R (p x p Gram matrix) -> Rm = R (upper, row-major), Dinv = inverses of its 32 x 32
+//                  diagonal blocks, rdiag = diag(R) (0 marks a numerically dependent column)
 //   jacobi_small:  symmetric B (p x p, p % 8 == 0) -> theta descending, eigenvectors as COLUMNS of U; info = {sweeps, limit hit}
-int chol_inv_launch(const double *H, int64_t ldh, int p, double *Rinv, int64_t ldr, double *rdiag, hipStream_t stream);
+//   orth_fast:     Qout = orth(Y) (CholeskyQR: Gram GEMM, chol_blocked, row-parallel triangular solve), Y: n x p, ld = ws.pp
+int chol_blocked_launch(const double *H, int64_t ldh, int p, double *Rm, int64_t ldr, double *Dinv, double *rdiag,
+                        hipStream_t stream);
 int jacobi_small_launch(const double *B, int64_t ldb, int p, double *U, int64_t ldu, double *theta, int *info,
                         hipStream_t stream);
+int orth_fast(SubspaceWorkspace &ws, const double *Y, double *Qout, int n, int p, hipStream_t stream);
+// Qout = Y R^-1 from the blocked factor (gs_subspace.hip)
+int trsm_rows_launch(const double *Y, double *Qout, int64_t ld, int n, int p, const double *Rm, const double *Dinv,
+                     hipStream_t stream);
 // same contract, Chebyshev-filtered latency-first version for subspace_dim(n, k) <= 128 (gs_topk.hip)
 int eigh_topk_cheb(SubspaceWorkspace &ws, const double *A, int n, int64_t lda, int k, const double *V0, int k0,
                    int64_t ldv0, double *Vk, int64_t ldv, double *lam, int *iters_out, int *converged,

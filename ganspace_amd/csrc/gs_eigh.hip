@@ -294,6 +294,10 @@ static int launch_block_sweeps(const EighWorkspace &ws, double *W, int n, int64_
         if (host_done[0]) break;
     }
     if (sweeps_out) *sweeps_out = host_done[1];
+    if (!host_done[0]) {
+        set_error("eigh_jacobi: block Jacobi did not converge within the sweep limit");
+        return GS_ENOCONV;
+    }
     return GS_OK;
 }
 
@@ -386,6 +390,10 @@ int eigh_jacobi(const EighWorkspace &ws, double *W, int n, int64_t ldw, int *swe
             GS_HIP_CHECK(hipMemcpyAsync(&off_host, offmax, sizeof(double), hipMemcpyDeviceToHost, stream));
             GS_HIP_CHECK(hipStreamSynchronize(stream));
             if (off_host <= kJacobiTol) break;
+            if (sweeps >= kMaxSweeps) {
+                set_error("eigh_jacobi: Jacobi did not converge within the sweep limit");
+                return GS_ENOCONV;
+            }
         }
     }
     hipLaunchKernelGGL(colnorm_kernel, grid_cols, blk, 0, stream, W, n, ldw, ws.norms, (double *)nullptr);

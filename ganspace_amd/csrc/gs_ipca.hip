@@ -326,7 +326,7 @@ int solve_topk(gs_ipca *h, bool warm, const double *total_src, int total_len, hi
             hipLaunchKernelGGL(signfix_rows_kernel, dim3((unsigned)ceil_div(k, 4)), dim3(256), 0, stream, h->Vk, n, dp,
                                k);
             h->last_mults = mults;
-            h->last_sweeps = 0;
+            h->last_sweeps = h->sws.last_rr_sweeps;   // Jacobi sweeps of the projection step
             done = true;
         }
     }
@@ -734,9 +734,29 @@ int gs_eigh_sym(double *A, double *w, int n, int *sweeps_out_host, void *stream_
     return rc;
 }
 
-int gs_chol_inv(const double *H, int p, double *Rinv, double *rdiag, void *stream_) {
-    GS_REQUIRE(H && Rinv && rdiag, GS_EINVAL, "gs_chol_inv: NULL argument");
-    return chol_inv_launch(H, p, p, Rinv, p, rdiag, (hipStream_t)stream_);
+int gs_cholqr(const double *Y, int n, int p, double *Q, double *rdiag, void *stream_) {
+    GS_REQUIRE(Y && Q && rdiag && n >= 1 && p >= 1 && p <= 128, GS_EINVAL, "gs_cholqr: bad argument (p <= 128)");
+    hipStream_t stream = (hipStream_t)stream_;
+    SubspaceWorkspace ws;
+    int rc = subspace_workspace_alloc(ws, n, p);
+    if (rc == GS_OK) {
+        // the workspace rows are ws.pp wide
+        const int64_t ld = ws.pp;
+        if (hipMemsetAsync(ws.Y, 0, sizeof(double) * (size_t)n * ld, stream) != hipSuccess ||
+            hipMemcpy2DAsync(ws.Y, sizeof(double) * ld, Y, sizeof(double) * p, sizeof(double) * p, n,
+                             hipMemcpyDeviceToDevice, stream) != hipSuccess)
+            rc = GS_EHIP;
+        if (rc == GS_OK) rc = orth_fast(ws, ws.Y, ws.Q, n, p, stream);
+        if (rc == GS_OK &&
+            (hipMemcpy2DAsync(Q, sizeof(double) * p, ws.Q, sizeof(double) * ld, sizeof(double) * p, n,
+                              hipMemcpyDeviceToDevice, stream) != hipSuccess ||
+             hipMemcpyAsync(rdiag, ws.theta + 2 * ws.pp, sizeof(double) * p, hipMemcpyDeviceToDevice, stream) !=
+                 hipSuccess))
+            rc = GS_EHIP;
+    }
+    if (hipStreamSynchronize(stream) != hipSuccess && rc == GS_OK) rc = GS_EHIP;
+    subspace_workspace_free(ws);
+    return rc;
 }
 
 int gs_jacobi_small(const double *B, int p, double *U, double *theta, int *info_host, void *stream_) {

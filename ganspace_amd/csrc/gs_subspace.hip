@@ -302,6 +302,15 @@ __global__ __launch_bounds__(512) void trsm_rows_kernel(const double *__restrict
     }
 }
 
+int trsm_rows_launch(const double *Y, double *Qout, int64_t ld, int n, int p, const double *Rm, const double *Dinv,
+                     hipStream_t stream) {
+    GS_REQUIRE(p >= 1 && p <= 256, GS_EINVAL, "trsm_rows: p must be in [1, 256]");
+    hipLaunchKernelGGL(trsm_rows_kernel, dim3((unsigned)ceil_div(n, 16)), dim3(512), 0, stream, Y, Qout, ld, n, p, Rm,
+                       Dinv);
+    GS_HIP_CHECK(hipGetLastError());
+    return GS_OK;
+}
+
 // Diagonal of the last Cholesky factor, for the iteration schedule: out = {R_11, R_kk, R_pp*, max, min, #dead}
 // over the live (non-zero) pivots; R_pp* = the last live pivot.  After j products from an orthonormal basis whose
 // columns are roughly ordered, R_ii ~ lambda_i^j.

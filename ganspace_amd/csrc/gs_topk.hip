@@ -15,8 +15,8 @@
 //              ~150x on the W-space covariance of BASELINE cfg2 where three plain products gain ~14x
 //              (13-16 products and 6 orthonormalisations instead of 26 and 13).  The degree is capped so that
 //              T_m(x_1) <= 3e7 (CholeskyQR needs cond(Y)^2 < 1/eps); steep spectra get m = 1.
-//   orth       CholeskyQR: H = Y^T Y (GEMM), R^-1 by chol_inv_kernel (one workgroup, registers), Q = Y R^-1
-//              (GEMM): three launches instead of sixteen.
+//   orth       CholeskyQR: H = Y^T Y (GEMM), blocked Cholesky by chol_blocked_kernel (one workgroup, matrix in
+//              LDS), Q = Y R^-1 row-parallel: three launches instead of sixteen.
 //   project    B = Q^T A Q, eigenvectors by jacobi_lds_kernel (one workgroup, all sweeps, sorted output),
 //              residual test, emit.
 #include <cmath>
@@ -57,148 +57,185 @@ __device__ __forceinline__ double sum8(double v) {
 }  // namespace
 
 // =====================================================================================================
-// Cholesky factor + inverse of a p x p Gram matrix (p <= 128), ONE workgroup of 1024 threads.
+// Cholesky factor of a p x p Gram matrix (p <= 128) in ONE workgroup of 1024 threads, blocked 32 wide, with the
+// matrix resident in LDS (128 x 129 doubles).
 //
-// Row-operation form on the augmented matrix [H | I] -> [R | R^-T]: step j scales row j by 1/sqrt(pivot) and
-// subtracts multiples of it from the rows below.  The 128 x 256 augmented matrix lives in registers: thread
-// (ty, tx) = (tid >> 5, tid & 31) owns rows ty + 32 a (a < 4) and columns tx + 32 b (b < 8; b >= 4 is the
-// identity half), 32 doubles.  Row j is published through a double-buffered LDS row, so a step costs one
-// barrier.  The trailing matrix stays symmetric, hence the multiplier of row r is the pivot row's entry at
-// column r and nothing but the pivot row has to be communicated.  Column blocks that are already final
-// (left of the pivot in H, right of it in the identity half) are skipped with wave-uniform tests.
+// Per block step J:  (a) the 32 x 32 diagonal block is factored together with an appended identity, one element
+// of each per thread: step j publishes row j through a double-buffered LDS row (one barrier per step, ~25
+// instructions per wave - the factorisation is a latency chain of 32 such steps, not throughput);  the trailing
+// block stays symmetric, so the multiplier of row r is the pivot row's entry at column r.  That leaves R_JJ and
+// R_JJ^-T.  (b) panel  R[J, rest] = R_JJ^-T H[J, rest]  and  (c) trailing update
+// H[rest, rest] -= R[J, rest]^T R[J, rest]  are small dense products out of LDS, all threads busy.
 //
 // A pivot that lost more than ~13 digits against the column's original squared norm marks a numerically
-// dependent column: its row of R and its row / column of R^-1 are zero, so the corresponding column of Y R^-1
-// is exactly zero (the subspace shrinks by one) instead of noise.
+// dependent column: its row of R and its row / column of R_JJ^-1 are zero, so the corresponding column of
+// Y R^-1 is exactly zero (the subspace shrinks by one) instead of noise.
 //
-// Outputs: Rinv[t * ldr + c] = (R^-1)[t][c] (upper triangular, full p x p written), rdiag[j] = R_jj (0 = dead).
+// Outputs for trsm_rows_kernel (gs_subspace.hip): Rm (upper factor, row-major, ld = ldr), Dinv[J] = R_JJ^-1
+// (32 x 32 row-major blocks), rdiag[j] = R_jj (0 = dead).
 constexpr int kCholP = 128;
-__global__ __launch_bounds__(1024) void chol_inv_kernel(const double *__restrict__ H, int64_t ldh, int p,
-                                                         double *__restrict__ Rinv, int64_t ldr,
-                                                         double *__restrict__ rdiag) {
-    __shared__ double rowbuf[2][2 * kCholP];
-    __shared__ double refd[kCholP];
-    const int tid = threadIdx.x, tx = tid & 31, ty = tid >> 5;
-    double M[4][8];
-#pragma unroll
-    for (int a = 0; a < 4; ++a) {
-        const int r = ty + 32 * a;
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            const int c = tx + 32 * b;
-            M[a][b] = (r < p && c < p) ? H[(int64_t)r * ldh + c] : (r == c ? 1.0 : 0.0);
-            M[a][4 + b] = (r == c) ? 1.0 : 0.0;
-        }
+constexpr int kCholLd = 129;
+constexpr size_t kCholLdsBytes = sizeof(double) * ((size_t)kCholP * kCholLd + 32 * 33 + 64 + 64 + kCholP);
+__global__ __launch_bounds__(1024) void chol_blocked_kernel(const double *__restrict__ H, int64_t ldh, int p,
+                                                             double *__restrict__ Rm, int64_t ldr,
+                                                             double *__restrict__ Dinv, double *__restrict__ rdiag) {
+    extern __shared__ __attribute__((aligned(16))) double csm[];
+    double *Hs = csm;                            // [128][129]
+    double *Es = Hs + kCholP * kCholLd;          // [32][33]   R_JJ^-T of the current block (lower triangular)
+    double *rowL = Es + 32 * 33;                 // [2][32]    published pivot row, matrix half
+    double *rowE = rowL + 64;                    // [2][32]    ... identity half
+    double *refd = rowE + 64;                    // [128]      original diagonal
+    const int tid = threadIdx.x, r = tid >> 5, c = tid & 31;
+    const int nblk = (p + 31) >> 5, pend = nblk * 32;
+    for (int e = tid; e < pend * pend; e += 1024) {
+        const int i = e / pend, j = e - i * pend;
+        Hs[i * kCholLd + j] = (i < p && j < p) ? H[(int64_t)i * ldh + j] : (i == j ? 1.0 : 0.0);
     }
     if (tid < kCholP) refd[tid] = (tid < p) ? H[(int64_t)tid * ldh + tid] : 1.0;
     __syncthreads();
-    for (int j = 0; j < p; ++j) {
-        const int aj = j >> 5;
-        double *rb = rowbuf[j & 1];
-        // publish row j (its owner threads: ty == j mod 32, register row j / 32 - four static cases, so that M
-        // is never indexed dynamically and stays in registers)
+    for (int J = 0; J < nblk; ++J) {
+        const int j0 = 32 * J, j1 = j0 + 32, rem = pend - j1;
+        // ---- (a) diagonal block with appended identity ----
+        double h = (r <= c) ? Hs[(j0 + r) * kCholLd + j0 + c] : Hs[(j0 + c) * kCholLd + j0 + r];
+        double e = (r == c) ? 1.0 : 0.0;
+        for (int j = 0; j < 32; ++j) {
+            double *rl = rowL + (j & 1) * 32, *re = rowE + (j & 1) * 32;
+            if (r == j) {
+                rl[c] = h;
+                re[c] = e;
+            }
+            __syncthreads();
+            const double d = rl[j];
+            const bool dead = !(d > refd[j0 + j] * 1e-13);
+            const double inv = dead ? 0.0 : rsqrt64(d);
+            if (r > j) {
+                const double f = rl[r] * (inv * inv);
+                h -= f * rl[c];
+                e -= f * re[c];
+            } else if (r == j) {
+                h *= inv;
+                e *= inv;
+            }
+        }
+        {
+            const double rv = (r <= c) ? h : 0.0;
+            const double ev = (c <= r) ? e : 0.0;             // (R^-T)[r][c] = (R^-1)[c][r]
+            Hs[(j0 + r) * kCholLd + j0 + c] = rv;
+            Es[r * 33 + c] = ev;
+            if (j0 + r < p && j0 + c < p) Rm[(int64_t)(j0 + r) * ldr + j0 + c] = rv;
+            Dinv[(size_t)J * 1024 + c * 32 + r] = ev;
+            if (r == c && j0 + r < p) rdiag[j0 + r] = h;
+        }
+        __syncthreads();
+        if (rem <= 0) break;
+        // ---- (b) panel: P[i][c2] = sum_{t <= i} Es[i][t] H[j0 + t][c2] ----
+        double acc[3];
+        const int npanel = 32 * rem;
 #pragma unroll
-        for (int a = 0; a < 4; ++a) {
-            if (ty + 32 * a == j) {
-#pragma unroll
-                for (int b = 0; b < 8; ++b) rb[tx + 32 * b] = M[a][b];
+        for (int w = 0; w < 3; ++w) {
+            const int idx = tid + 1024 * w;
+            acc[w] = 0.0;
+            if (idx < npanel) {
+                const int i = idx / rem, c2 = j1 + (idx - i * rem);
+                double a0 = 0.0, a1 = 0.0;
+#pragma unroll 8
+                for (int t = 0; t < 32; t += 2) {
+                    a0 += Es[i * 33 + t] * Hs[(j0 + t) * kCholLd + c2];
+                    a1 += Es[i * 33 + t + 1] * Hs[(j0 + t + 1) * kCholLd + c2];
+                }
+                acc[w] = a0 + a1;
             }
         }
         __syncthreads();
-        const double d = rb[j];
-        const bool dead = !(d > refd[j] * 1e-13);
-        const double inv = dead ? 0.0 : rsqrt64(d);
-        const double inv2 = inv * inv;
-        double rc[8];
 #pragma unroll
-        for (int b = 0; b < 8; ++b) {
-            // left half: columns >= 32 aj can still change; identity half: columns <= j are populated
-            const bool live = (b < 4) ? (b >= aj) : (b - 4 <= aj);
-            rc[b] = live ? rb[tx + 32 * b] * inv2 : 0.0;
-        }
-#pragma unroll
-        for (int a = 0; a < 4; ++a) {
-            const int r = ty + 32 * a;
-            if (a >= aj) {                        // rows above the pivot block are final (wave-uniform test)
-                const double f = (r > j) ? rb[r] : 0.0;
-#pragma unroll
-                for (int b = 0; b < 8; ++b) {
-                    const bool live = (b < 4) ? (b >= aj) : (b - 4 <= aj);
-                    if (live) M[a][b] -= f * rc[b];
-                }
-                if (r == j) {
-#pragma unroll
-                    for (int b = 0; b < 8; ++b) M[a][b] *= inv;   // row j of R and of R^-T (all zero when dead)
-                }
+        for (int w = 0; w < 3; ++w) {
+            const int idx = tid + 1024 * w;
+            if (idx < npanel) {
+                const int i = idx / rem, c2 = j1 + (idx - i * rem);
+                Hs[(j0 + i) * kCholLd + c2] = acc[w];
+                if (j0 + i < p && c2 < p) Rm[(int64_t)(j0 + i) * ldr + c2] = acc[w];
             }
         }
-        if (tid == 0) rdiag[j] = dead ? 0.0 : d * inv;
-    }
-    // identity half holds R^-T: thread element (r, c') = (R^-1)[c'][r]
-#pragma unroll
-    for (int a = 0; a < 4; ++a) {
-        const int r = ty + 32 * a;
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            const int c = tx + 32 * b;
-            if (r < p && c < p) Rinv[(int64_t)c * ldr + r] = (c <= r) ? M[a][4 + b] : 0.0;
+        __syncthreads();
+        // ---- (c) trailing update, upper part: H[r2][c2] -= sum_t R[j0 + t][r2] R[j0 + t][c2] ----
+        const int ntrail = rem * rem;
+        for (int idx = tid; idx < ntrail; idx += 1024) {
+            const int i = idx / rem, r2 = j1 + i, c2 = j1 + (idx - i * rem);
+            if (c2 >= r2) {
+                double a0 = 0.0, a1 = 0.0;
+#pragma unroll 8
+                for (int t = 0; t < 32; t += 2) {
+                    a0 += Hs[(j0 + t) * kCholLd + r2] * Hs[(j0 + t) * kCholLd + c2];
+                    a1 += Hs[(j0 + t + 1) * kCholLd + r2] * Hs[(j0 + t + 1) * kCholLd + c2];
+                }
+                Hs[r2 * kCholLd + c2] -= a0 + a1;
+            }
         }
+        __syncthreads();
     }
 }
 
 // =====================================================================================================
-// Symmetric eigensolver for the p x p Rayleigh-Ritz matrix (p <= 128, even), ONE workgroup, all sweeps in
+// Symmetric eigensolver for the p x p Rayleigh-Ritz matrix (p <= 128, p % 8 == 0), ONE workgroup, all sweeps in
 // one launch: one-sided (Hestenes) Jacobi on W = B, columns in LDS (column stride 128 doubles).
 //
-// A column pair is handled by 8 lanes (p/8 <= 16 elements per lane and column), p/2 pairs per round in p/2
-// lane groups (4 p threads).  Round-robin "circle" ordering; group g handles pair (g - R) mod h in round R,
-// which makes the first column of its pair the SAME column in consecutive rounds: that column stays in
-// registers, only the partner column travels through LDS (half the LDS traffic of re-reading both).  The
-// group whose pair index wraps swaps its resident column.  Rotation angles from two reciprocal square roots.
+// A column pair is handled by 8 lanes (NT = p/8 rounded up to a multiple of 4 elements per lane and column,
+// compile-time so that the element loops carry no predicates), p/2 pairs per round in p/2 lane groups (4 p
+// threads).  Round-robin "circle" ordering; group g handles pair (g - R) mod h in round R, which makes the first
+// column of its pair the SAME column in consecutive rounds: that column stays in registers, only the partner
+// column travels through LDS (half the LDS traffic of re-reading both).  The group whose pair index wraps swaps
+// its resident column.  The squared column norms are carried along (a rotation changes them by -/+ t gamma
+// exactly) and refreshed from the data in the first round of every sweep, so a round computes ONE dot product
+// per pair instead of three.  Rotation angles from two reciprocal square roots.
 //
 // A sweep whose largest rotation was below ~3e-6 (relative off-diagonal) ends the iteration: Jacobi converges
 // quadratically, the remaining off-diagonal part is ~1e-11.  Output: eigenvalues theta[rank] descending and
 // the eigenvectors as COLUMNS of U (U[t * ldu + rank]); info[0] = sweeps, info[1] = 1 if the sweep limit was hit.
 constexpr int kJacLd = 128;
-constexpr int kJacMaxSweeps = 24;
+constexpr int kJacMaxSweeps = 30;
+template <int NT>
 __global__ __launch_bounds__(512) void jacobi_lds_kernel(const double *__restrict__ B, int64_t ldb, int p,
                                                           double *__restrict__ U, int64_t ldu,
                                                           double *__restrict__ theta, int *__restrict__ info) {
     extern __shared__ __attribute__((aligned(16))) double jsm[];
     double *W = jsm;                                         // [p][kJacLd]
-    double *nrm = jsm + (size_t)kJacLd * kJacLd;             // [128]
+    double *nrm = jsm + (size_t)kJacLd * kJacLd;             // [128] squared column norms
     int *irank = reinterpret_cast<int *>(nrm + kJacLd);      // [128]
     unsigned long long *umax = reinterpret_cast<unsigned long long *>(irank + kJacLd);   // [1]
-    int *flag = reinterpret_cast<int *>(umax + 1);           // [2]: big rotation seen / any rotation seen
+    int *flag = reinterpret_cast<int *>(umax + 1);           // [1]: a big rotation was seen in this sweep
     const int tid = threadIdx.x, nthr = blockDim.x;
     const int h = p >> 1, m1 = p - 1;
     const int g = tid >> 3, q = tid & 7;
-    const int nt = p >> 3;                                   // elements per lane per column (p multiple of 8)
-    const int ntp = (nt + 3) & ~3;                           // the bank swizzle permutes blocks of 4: zero padded
-    const int swz = g & 3;
-    // ---- load (B symmetric: row j = column j); rows p .. 8 ntp of every column are zero padding ----
-    const int pl = 8 * ntp;
-    for (int e = tid; e < p * pl; e += nthr) {
-        const int j = e / pl, t = e - j * pl;
+    const int swz = g & 3;                                   // bank swizzle: permutes blocks of 4 element slots
+    const bool act = g < h;
+    // ---- load (B symmetric: row j = column j); rows p .. 8 NT of every column are zero padding ----
+    constexpr int PL = 8 * NT;
+    for (int e = tid; e < p * PL; e += nthr) {
+        const int j = e / PL, t = e - j * PL;
         W[j * kJacLd + t] = (t < p) ? B[(int64_t)j * ldb + t] : 0.0;
     }
     if (tid == 0) {
         umax[0] = 0ull;
         flag[0] = 0;
-        flag[1] = 0;
     }
     __syncthreads();
-    // largest squared column norm -> floor below which a column counts as numerically zero
-    if (g < h) {
+    // squared column norms; the largest one sets the floor below which a column counts as numerically zero
+    if (act) {
+#pragma unroll
         for (int cc = 0; cc < 2; ++cc) {
-            const double *col = W + (g + cc * h) * kJacLd;
+            const int j = g + cc * h;
+            const double *col = W + j * kJacLd;
             double s = 0.0;
-            for (int t = 0; t < nt; ++t) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
                 const double v = col[q + 8 * t];
                 s += v * v;
             }
             s = sum8(s);
-            if (q == 0) atomicMax(umax, (unsigned long long)__double_as_longlong(s));
+            if (q == 0) {
+                nrm[j] = s;
+                atomicMax(umax, (unsigned long long)__double_as_longlong(s));
+            }
         }
     }
     __syncthreads();
@@ -207,41 +244,52 @@ __global__ __launch_bounds__(512) void jacobi_lds_kernel(const double *__restric
     constexpr double kTolRot2 = 1e-28;     // rotate while |gamma| > 1e-14 sqrt(alpha beta)
     constexpr double kTolBig2 = 1e-11;     // (3e-6)^2: a sweep without such a rotation is the last one
 
-    double x[16], y[16];
-    int sweeps = 0, R = 0;
+    double x[NT], y[NT];
+    int sweeps = 0;
     bool limit = false;
     int cur_a = -1;
+    int r = 0, i = act ? g : 0;            // round within the sweep / this group's pair index: i = (g - R) mod h
     while (true) {
-        for (int rr = 0; rr < m1; ++rr, ++R) {
-            const int r = R % m1;
-            int a = 0, b = 0, i = 0;
-            if (g < h) {
-                i = ((g - R) % h + h) % h;
+        for (int rr = 0; rr < m1; ++rr) {
+            if (act) {
+                int a, b;
                 if (i == 0) {
                     a = r;
                     b = m1;
                 } else {
-                    a = (r + i) % m1;
-                    b = (r - i + m1) % m1;
+                    a = r + i;
+                    a = a >= m1 ? a - m1 : a;
+                    b = r - i;
+                    b = b < 0 ? b + m1 : b;
                 }
-                const double *ca = W + a * kJacLd, *cb = W + b * kJacLd;
+                double *ca = W + a * kJacLd, *cb = W + b * kJacLd;
                 if (a != cur_a) {
 #pragma unroll
-                    for (int t = 0; t < 16; ++t)
-                        if (t < ntp) x[t] = ca[q + 8 * (t ^ swz)];
+                    for (int t = 0; t < NT; ++t) x[t] = ca[q + 8 * (t ^ swz)];
                     cur_a = a;
                 }
-                double alpha = 0.0, beta = 0.0, gamma = 0.0;
+                double alpha, beta;
+                double gq[4] = {0.0, 0.0, 0.0, 0.0};      // four partial sums: short dependent FMA chains
 #pragma unroll
-                for (int t = 0; t < 16; ++t)
-                    if (t < ntp) {
-                        y[t] = cb[q + 8 * (t ^ swz)];
-                        alpha += x[t] * x[t];
-                        beta += y[t] * y[t];
-                        gamma += x[t] * y[t];
+                for (int t = 0; t < NT; ++t) {
+                    y[t] = cb[q + 8 * (t ^ swz)];
+                    gq[t & 3] += x[t] * y[t];
+                }
+                double gamma = (gq[0] + gq[1]) + (gq[2] + gq[3]);
+                if (rr == 0) {
+                    // first round of a sweep: every column is in exactly one pair - refresh its norm from the data
+                    double sa[4] = {0.0, 0.0, 0.0, 0.0}, sb[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        sa[t & 3] += x[t] * x[t];
+                        sb[t & 3] += y[t] * y[t];
                     }
-                alpha = sum8(alpha);
-                beta = sum8(beta);
+                    alpha = sum8((sa[0] + sa[1]) + (sa[2] + sa[3]));
+                    beta = sum8((sb[0] + sb[1]) + (sb[2] + sb[3]));
+                } else {
+                    alpha = nrm[a];
+                    beta = nrm[b];
+                }
                 gamma = sum8(gamma);
                 const double ab = alpha * beta, g2 = gamma * gamma;
                 const bool rot = (alpha > floor2) && (beta > floor2) && (g2 > kTolRot2 * ab);
@@ -252,26 +300,31 @@ __global__ __launch_bounds__(512) void jacobi_lds_kernel(const double *__restric
                     const double c2 = 0.5 + 0.5 * fabs(da) * ir;
                     const double ic = rsqrt64(c2);
                     const double c = c2 * ic;
-                    double s = 0.5 * fabs(db) * ir * ic;
-                    s = ((da < 0.0) != (db < 0.0)) ? -s : s;
-                    double *cbw = W + b * kJacLd;
+                    double sn = 0.5 * fabs(db) * ir * ic;
+                    sn = ((da < 0.0) != (db < 0.0)) ? -sn : sn;
 #pragma unroll
-                    for (int t = 0; t < 16; ++t)
-                        if (t < ntp) {
-                            const double xv = x[t], yv = y[t];
-                            x[t] = c * xv - s * yv;
-                            cbw[q + 8 * (t ^ swz)] = s * xv + c * yv;
-                        }
+                    for (int t = 0; t < NT; ++t) {
+                        const double xv = x[t], yv = y[t];
+                        x[t] = c * xv - sn * yv;
+                        cb[q + 8 * (t ^ swz)] = sn * xv + c * yv;
+                    }
+                    const double tg = sn * ic * gamma;               // t gamma,  t = s / c,  ic = 1 / c
+                    alpha -= tg;
+                    beta += tg;
+                }
+                if (q == 0 && (rot || rr == 0)) {
+                    nrm[a] = alpha;
+                    nrm[b] = beta;
                 }
                 if (i == 0) {
                     // this group's resident column leaves (it is the partner column of pair 1 next round)
-                    double *caw = W + a * kJacLd;
 #pragma unroll
-                    for (int t = 0; t < 16; ++t)
-                        if (t < ntp) caw[q + 8 * (t ^ swz)] = x[t];
+                    for (int t = 0; t < NT; ++t) ca[q + 8 * (t ^ swz)] = x[t];
                     cur_a = -1;
                 }
+                i = (i == 0) ? h - 1 : i - 1;
             }
+            r = (r + 1 == m1) ? 0 : r + 1;
             __syncthreads();
         }
         ++sweeps;
@@ -286,20 +339,21 @@ __global__ __launch_bounds__(512) void jacobi_lds_kernel(const double *__restric
         __syncthreads();
     }
     // flush the resident columns
-    if (g < h && cur_a >= 0) {
+    if (act && cur_a >= 0) {
         double *caw = W + cur_a * kJacLd;
 #pragma unroll
-        for (int t = 0; t < 16; ++t)
-            if (t < ntp) caw[q + 8 * (t ^ swz)] = x[t];
+        for (int t = 0; t < NT; ++t) caw[q + 8 * (t ^ swz)] = x[t];
     }
     __syncthreads();
-    // ---- column norms -> eigenvalues, rank by decreasing value, normalised eigenvectors ----
-    if (g < h) {
+    // ---- exact column norms -> eigenvalues, rank by decreasing value, normalised eigenvectors ----
+    if (act) {
+#pragma unroll
         for (int cc = 0; cc < 2; ++cc) {
             const int j = g + cc * h;
             const double *col = W + j * kJacLd;
             double s = 0.0;
-            for (int t = 0; t < nt; ++t) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
                 const double v = col[q + 8 * t];
                 s += v * v;
             }
@@ -453,9 +507,32 @@ static size_t jacobi_lds_bytes() {
     return sizeof(double) * ((size_t)kJacLd * kJacLd + kJacLd) + sizeof(int) * kJacLd + 32;
 }
 
-int chol_inv_launch(const double *H, int64_t ldh, int p, double *Rinv, int64_t ldr, double *rdiag, hipStream_t stream) {
-    GS_REQUIRE(p >= 1 && p <= kCholP, GS_EINVAL, "chol_inv: p must be in [1, 128]");
-    hipLaunchKernelGGL(chol_inv_kernel, dim3(1), dim3(1024), 0, stream, H, ldh, p, Rinv, ldr, rdiag);
+int chol_blocked_launch(const double *H, int64_t ldh, int p, double *Rm, int64_t ldr, double *Dinv, double *rdiag,
+                        hipStream_t stream) {
+    GS_REQUIRE(p >= 1 && p <= kCholP, GS_EINVAL, "chol_blocked: p must be in [1, 128]");
+    static bool attr_set = false;
+    if (!attr_set) {
+        GS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(chol_blocked_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)kCholLdsBytes));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(chol_blocked_kernel, dim3(1), dim3(1024), kCholLdsBytes, stream, H, ldh, p, Rm, ldr, Dinv,
+                       rdiag);
+    GS_HIP_CHECK(hipGetLastError());
+    return GS_OK;
+}
+
+template <int NT>
+static int jacobi_launch_nt(const double *B, int64_t ldb, int p, double *U, int64_t ldu, double *theta, int *info,
+                            hipStream_t stream) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        GS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(jacobi_lds_kernel<NT>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)jacobi_lds_bytes()));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(jacobi_lds_kernel<NT>, dim3(1), dim3(4 * p), jacobi_lds_bytes(), stream, B, ldb, p, U, ldu,
+                       theta, info);
     GS_HIP_CHECK(hipGetLastError());
     return GS_OK;
 }
@@ -463,28 +540,22 @@ int chol_inv_launch(const double *H, int64_t ldh, int p, double *Rinv, int64_t l
 int jacobi_small_launch(const double *B, int64_t ldb, int p, double *U, int64_t ldu, double *theta, int *info,
                         hipStream_t stream) {
     GS_REQUIRE(p >= 8 && p <= kJacLd && (p % 8) == 0, GS_EINVAL, "jacobi_small: p must be a multiple of 8 in [8, 128]");
-    static bool attr_set = false;
-    if (!attr_set) {
-        GS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(jacobi_lds_kernel),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)jacobi_lds_bytes()));
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(jacobi_lds_kernel, dim3(1), dim3(4 * p), jacobi_lds_bytes(), stream, B, ldb, p, U, ldu, theta,
-                       info);
-    GS_HIP_CHECK(hipGetLastError());
-    return GS_OK;
+    const int nt = ((p >> 3) + 3) & ~3;
+    if (nt == 4) return jacobi_launch_nt<4>(B, ldb, p, U, ldu, theta, info, stream);
+    if (nt == 8) return jacobi_launch_nt<8>(B, ldb, p, U, ldu, theta, info, stream);
+    if (nt == 12) return jacobi_launch_nt<12>(B, ldb, p, U, ldu, theta, info, stream);
+    return jacobi_launch_nt<16>(B, ldb, p, U, ldu, theta, info, stream);
 }
 
-// Q_out = orth(Y): three launches.  rdiag lands in ws.theta + 2 pp.
-static int orth_fast(SubspaceWorkspace &ws, const double *Y, double *Qout, int n, int p, hipStream_t stream) {
+// Q_out = orth(Y) by CholeskyQR in three launches: H = Y^T Y (GEMM), blocked Cholesky in one workgroup,
+// Q = Y R^-1 row-parallel (trsm_rows_kernel).  rdiag lands in ws.theta + 2 pp.
+int orth_fast(SubspaceWorkspace &ws, const double *Y, double *Qout, int n, int p, hipStream_t stream) {
     const int64_t ld = ws.pp;
     GemmEpilogue none;
     gemm_f64(p, p, n, Y, 1, ld, Y, ld, 1, ws.H, ld, stream, 1.0, 0.0, none, /*allow_split=*/n > 1024);
-    int rc = chol_inv_launch(ws.H, ld, p, ws.Rm, ld, ws.theta + 2 * ws.pp, stream);
+    int rc = chol_blocked_launch(ws.H, ld, p, ws.Rm, ld, ws.Dinv, ws.theta + 2 * ws.pp, stream);
     if (rc != GS_OK) return rc;
-    gemm_f64(n, p, p, Y, ld, 1, ws.Rm, ld, 1, Qout, ld, stream, 1.0, 0.0, none, false);
-    GS_HIP_CHECK(hipGetLastError());
-    return GS_OK;
+    return trsm_rows_launch(Y, Qout, ld, n, p, ws.Rm, ws.Dinv, stream);
 }
 
 static double cheb_T(int m, double x) { return x <= 1.0 ? 1.0 : std::cosh((double)m * std::acosh(x)); }

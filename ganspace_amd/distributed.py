@@ -9,9 +9,11 @@ ONE exchange step before the eigensolve:
 
     all-reduce [ n | n*mean ]            (d+1 float64: latency-bound)
     re-centre the local scatter about the global mean (Chan et al. pairwise merge)
-    all-reduce C                         (d*d float64: 2 MiB at d=512)
+    all-reduce the packed upper triangle of C   (d(d+1)/2 float64: 1 MiB at d=512)
 
-No collective sits on the data path itself.
+No collective sits on the data path itself.  A rank that owns no block (more ranks than blocks) contributes an
+all-zero state instead of stalling the others.  No N > 1 RCCL run has been measured in the build environment
+(``gpurun`` exposes one GPU); the logic is covered by world_size-2 gloo tests and a 1-rank RCCL test.
 """
 from __future__ import annotations
 
@@ -31,6 +33,9 @@ def shard_range(n_items: int, rank: int, world: int):
 def _recenter(state, d, new_mean):
     """``C += n (mean-new)(mean-new)^T ; mean = new`` in place on a state vector."""
     import torch
+    if float(state[0]) <= 0:
+        state[1:1 + d] = new_mean.to(state.dtype)       # an empty state has no scatter to move
+        return state
     if state.is_cuda:
         lib = _lib.load()
         new_mean = new_mean.to(device=state.device, dtype=torch.float64).contiguous()
@@ -58,25 +63,63 @@ def merge_states(states, d):
     return out
 
 
+PACK_MAX_FEATURES = 4096     # beyond this the index tensors of the packing cost more than the bytes they save
+
+
+def pack_upper(scatter, d):
+    """Row-major upper triangle (diagonal included) of a symmetric ``d x d`` matrix stored flat: d(d+1)/2 values."""
+    import torch
+    iu = torch.triu_indices(d, d, device=scatter.device)
+    return scatter.view(d, d)[iu[0], iu[1]].contiguous()
+
+
+def unpack_upper(packed, d, out):
+    """Inverse of :func:`pack_upper` into the flat ``d*d`` buffer ``out`` (both triangles filled)."""
+    import torch
+    iu = torch.triu_indices(d, d, device=packed.device)
+    m = out.view(d, d)
+    m.zero_()
+    m[iu[0], iu[1]] = packed
+    diag = m.diagonal().clone()
+    m.add_(m.T.clone())
+    m.diagonal().copy_(diag)
+    return out
+
+
 def allreduce_state(state, d, group=None):
-    """In-place global merge of every rank's exported state (two sum all-reduces)."""
+    """In-place global merge of every rank's exported state: a sum all-reduce of ``[n | n mean]``, the Chan
+    re-centring about the global mean, then a sum all-reduce of the (packed) centred scatter."""
     import torch
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()):
         return state
     hdr = torch.cat([state[:1], state[0] * state[1:1 + d]])
     dist.all_reduce(hdr, op=dist.ReduceOp.SUM, group=group)
+    total = float(hdr[0])
+    if total <= 0:
+        return state                              # nobody has seen a sample
     mean = hdr[1:] / hdr[0]
     _recenter(state, d, mean)
     scatter = state[1 + d:]
-    dist.all_reduce(scatter, op=dist.ReduceOp.SUM, group=group)
+    if d <= PACK_MAX_FEATURES:
+        packed = pack_upper(scatter, d)
+        dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=group)
+        unpack_upper(packed, d, scatter)
+    else:
+        dist.all_reduce(scatter, op=dist.ReduceOp.SUM, group=group)
     state[0] = hdr[0]
     return state
 
 
-def allreduce_estimator(estimator, group=None):
-    """Merge the EXACT-mode state of ``estimator`` across all ranks, in place."""
+def allreduce_estimator(estimator, group=None, d=None):
+    """Merge the EXACT-mode state of ``estimator`` across all ranks, in place.  ``d`` (the feature count every
+    rank agrees on) lets a rank that fitted nothing create its handle and contribute zeros."""
     t = estimator.transformer
+    if t._h is None:
+        if d is None:
+            raise RuntimeError("allreduce_estimator: this rank fitted no block; pass d= so that it can join with "
+                               "an empty state")
+        t._ensure(int(d))
     st = allreduce_state(t.export_state(), t._d, group)
     t.import_state(st, t._d)
     return estimator

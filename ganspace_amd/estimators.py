@@ -14,13 +14,22 @@ attribute names (``mean_``, ``components_``, ``explained_variance_`` ...), which
                   leading components match to ~1e-6 cosine, trailing ones are the *exact*
                   PCA instead of IPCA's truncated approximation; cache key ``ipca-exact_c{k}``.
 
-There is no CPU fallback: constructing an estimator loads the HIP library and fails
-loudly if it is missing.  The non-batch estimators of the reference (pca / fbpca / ica /
-spca, estimators.py:18-52,84-204) are whole-matrix CPU fits outside this hot path.
+``'pca'``         the reference's whole-matrix ``PCAEstimator`` (estimators.py:84-118) on the device:
+                  the same Gram kernel over all rows, one eigensolve; cache key ``pca-full_c{k}``.
+``'fbpca'``       the reference's ``FacebookPCAEstimator`` (estimators.py:124-160: randomized PCA of the
+                  *uncentred* matrix, ``raw=True``) as its n_iter -> infinity limit: the leading right singular
+                  vectors of X from the uncentred Gram; cache key ``fbpca_c{k}_it2_l{2k}``.
+``'ica'`` / ``'spca'``  are not batch estimators and not PCA; ``get_estimator`` hands them to the CPU
+                  pass-through in ``ganspace_amd/cpu_estimators.py`` (scikit-learn, the reference's own
+                  arithmetic) so that every name the reference accepts still works.
+
+There is no CPU fallback on the hot path: constructing any of the four PCA estimators loads the HIP
+library and fails loudly if it is missing.
 """
 from __future__ import annotations
 
 import ctypes as C
+from types import SimpleNamespace
 
 import numpy as np
 
@@ -240,17 +249,108 @@ class IPCAEstimator:
         return t.components_, stdev, t.explained_variance_ratio_
 
 
-_OUT_OF_SCOPE = ("pca", "fbpca", "ica", "spca")
+class _WholeMatrixPCA:
+    """Shared body of the two non-batch PCA estimators: ONE pass of the Gram kernel over the whole
+    ``[N, d]`` matrix (EXACT-mode handle, fed in launches of <= 24 576 rows), one top-k eigensolve, then the
+    reference's post-processing (estimators.py:96-118 / :137-157): projected standard deviations (ddof = 0),
+    components sorted by them, ``total_var = X.var(axis=0).sum()``, ``mean_ = X.mean(axis=0)``.
+
+    ``centre=True``  -> eigenvectors of the centred scatter  (sklearn ``PCA(svd_solver='full')``)
+    ``centre=False`` -> eigenvectors of ``X^T X``            (fbpca ``pca(raw=True)``)
+    The projected variance of a unit vector v is ``v^T S v / N`` with S the centred scatter in both cases, so no
+    second pass over X is needed: it is evaluated from the accumulated statistics in float64.
+    """
+
+    ROWS_PER_LAUNCH = 24576
+
+    def __init__(self, n_components, centre, device=None):
+        self.n_components = int(n_components)
+        self.batch_support = False
+        self._centre = centre
+        self._device = device
+        self.transformer = SimpleNamespace()
+        self.stdev = np.zeros((self.n_components,))
+        self.total_var = 0.0
+
+    def fit(self, X):
+        torch = _torch()
+        inc = _DeviceIncrementalPCA(self.n_components, _lib.GS_MODE_EXACT, self._device)
+        Xd = inc._as_device_rows(X)
+        n, d = Xd.shape
+        if d > inc.GRAM_SIDE_MAX_FEATURES:
+            raise RuntimeError(
+                f"whole-matrix PCA on the device handles feat_dim <= {inc.GRAM_SIDE_MAX_FEATURES} (got {d}); "
+                "use the batch estimator 'ipca', which switches to the small-side recurrence for wide layers")
+        k = self.n_components
+        for lo in range(0, n, self.ROWS_PER_LAUNCH):
+            inc.partial_fit(Xd[lo:lo + self.ROWS_PER_LAUNCH])
+        state = inc.export_state().cpu().numpy()            # [n | mean | centred scatter], float64
+        mean, S = state[1:1 + d], state[1 + d:].reshape(d, d)
+        if self._centre:
+            comp = np.array(inc.components_, dtype=np.float64)
+        else:
+            # uncentred second moment  X^T X = S + n mean mean^T  -> same eigensolver through a second handle
+            raw = _DeviceIncrementalPCA(k, _lib.GS_MODE_EXACT, self._device)
+            raw._ensure(d)
+            st = state.copy()
+            st[1 + d:] = (S + n * np.outer(mean, mean)).ravel()
+            st[1:1 + d] = 0.0
+            raw.import_state(torch.from_numpy(st).to(Xd.device), d)
+            comp = np.array(raw.components_, dtype=np.float64)
+            raw.close()
+        inc.close()
+        var = np.einsum("kd,de,ke->k", comp, S, comp) / n   # np.dot(components_, X.T).std(axis=1) ** 2
+        self.stdev = np.sqrt(np.maximum(var, 0.0))
+        order = np.argsort(self.stdev)[::-1]                   # estimators.py:103-106
+        self.stdev = self.stdev[order]
+        self.transformer.components_ = comp[order].astype(np.float32)
+        self.total_var = float(np.trace(S) / n)                # X.var(axis=0).sum()
+        self.transformer.mean_ = mean[None, :].astype(np.float32)
+        gram = self.transformer.components_.astype(np.float64) @ self.transformer.components_.astype(np.float64).T
+        off = np.abs(gram - np.diag(np.diag(gram))).max() if k > 1 else 0.0
+        if off > 1e-4:
+            print("PCA components not orthogonal, max dot", off)
+
+    def get_components(self):
+        var_ratio = self.stdev ** 2 / self.total_var
+        return self.transformer.components_, self.stdev, var_ratio
+
+
+class PCAEstimator(_WholeMatrixPCA):
+    """Drop-in for the reference ``PCAEstimator`` (estimators.py:84-118)."""
+
+    def __init__(self, n_components, device=None):
+        super().__init__(n_components, centre=True, device=device)
+        self.solver = "full"
+
+    def get_param_str(self):
+        return f"pca-{self.solver}_c{self.n_components}"
+
+
+class FacebookPCAEstimator(_WholeMatrixPCA):
+    """Drop-in for the reference ``FacebookPCAEstimator`` (estimators.py:124-160)."""
+
+    def __init__(self, n_components, device=None):
+        super().__init__(n_components, centre=False, device=device)
+        self.n_iter = 2
+        self.l = 2 * self.n_components
+
+    def get_param_str(self):
+        return "fbpca_c{}_it{}_l{}".format(self.n_components, self.n_iter, self.l)
 
 
 def get_estimator(name, n_components, alpha=1.0):
     """Factory with the reference's names and error behaviour (estimators.py:206-218)."""
+    if name == "pca":
+        return PCAEstimator(n_components)
     if name == "ipca":
         return IPCAEstimator(n_components, "faithful")
     if name == "ipca-exact":
         return IPCAEstimator(n_components, "exact")
-    if name in _OUT_OF_SCOPE:
-        raise NotImplementedError(
-            f"estimator '{name}' is a whole-matrix CPU fit of the reference and is outside the "
-            "MI355X batch hot path; use 'ipca' or 'ipca-exact'")
+    if name == "fbpca":
+        return FacebookPCAEstimator(n_components)
+    if name in ("ica", "spca"):
+        # not PCA, not batchable, not on the accelerated path: the reference's own scikit-learn arithmetic
+        from . import cpu_estimators
+        return cpu_estimators.make(name, n_components, alpha)
     raise RuntimeError("Unknown estimator")

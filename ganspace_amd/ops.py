@@ -113,18 +113,19 @@ def eigh_topk(A, k, V0=None):
     return w, V, dict(products=info[0], converged=bool(info[1]), sweeps=info[2], subspace=info[3])
 
 
-def chol_inv(H):
-    """Single-workgroup Cholesky + inverse of a Gram matrix ``H = R^T R`` (p <= 128): ``(Rinv, rdiag)``."""
+def cholqr(Y):
+    """``Q = orth(Y)`` by CholeskyQR on the device (``Y``: ``[n, p]`` float64, p <= 128): ``(Q, rdiag)`` with
+    ``rdiag`` the diagonal of the Cholesky factor of ``Y^T Y`` (0 marks a numerically dependent column)."""
     import torch
     lib = _lib.load()
-    _need_cuda(H)
-    assert H.dtype == torch.float64 and H.dim() == 2 and H.shape[0] == H.shape[1]
-    H = H.contiguous()
-    p = H.shape[0]
-    Rinv = torch.empty_like(H)
-    rdiag = torch.empty(p, dtype=torch.float64, device=H.device)
-    _lib.check(lib.gs_chol_inv(_p(H), p, _p(Rinv), _p(rdiag), _lib.current_stream_ptr()))
-    return Rinv, rdiag
+    _need_cuda(Y)
+    assert Y.dtype == torch.float64 and Y.dim() == 2
+    Y = Y.contiguous()
+    n, p = Y.shape
+    Q = torch.empty_like(Y)
+    rdiag = torch.empty(p, dtype=torch.float64, device=Y.device)
+    _lib.check(lib.gs_cholqr(_p(Y), n, p, _p(Q), _p(rdiag), _lib.current_stream_ptr()))
+    return Q, rdiag
 
 
 def jacobi_small(B):

@@ -37,7 +37,8 @@ enum {
     GS_EHIP = -2,     /* a HIP runtime call failed                                    */
     GS_ENOMEM = -3,
     GS_ESTATE = -4,   /* call order / mode mismatch                                   */
-    GS_ENOTIMPL = -5
+    GS_ENOTIMPL = -5,
+    GS_ENOCONV = -6   /* an eigensolver hit its sweep limit without converging (results not usable) */
 };
 
 /* PCA mode of a handle.
@@ -157,12 +158,13 @@ int gs_eigh_sym(double *A, double *w, int n, int *sweeps_out_host, void *stream)
 int gs_eigh_topk(const double *A, int n, int k, const double *V0, int k0, double *V, double *w, int *info_host,
                  void *stream);
 
-/* Single-workgroup building blocks of that solver, exposed for unit tests (p <= 128):
- * gs_chol_inv:     H [p*p] = R^T R  ->  Rinv [p*p] = R^-1 (upper triangular, row-major), rdiag [p] = diag(R);
- *                  numerically dependent columns get a zero row / column (rdiag = 0).
+/* Building blocks of that solver, exposed for unit tests (p <= 128):
+ * gs_cholqr:       Q [n*p] = orth(Y [n*p]) by CholeskyQR (Gram GEMM, single-workgroup blocked Cholesky, row-parallel
+ *                  triangular solve); rdiag [p] = diagonal of the Cholesky factor R of Y^T Y.  Numerically dependent
+ *                  columns of Y give an all-zero column of Q and rdiag = 0.
  * gs_jacobi_small: symmetric B [p*p], p % 8 == 0 -> theta [p] descending, eigenvectors as COLUMNS of U [p*p];
  *                  info_host (2 ints) = {sweeps, 1 if the sweep limit was hit}.                                       */
-int gs_chol_inv(const double *H, int p, double *Rinv, double *rdiag, void *stream);
+int gs_cholqr(const double *Y, int n, int p, double *Q, double *rdiag, void *stream);
 int gs_jacobi_small(const double *B, int p, double *U, double *theta, int *info_host, void *stream);
 
 /* z -> w: the StyleGAN2 mapping network `Generator.style` called from

@@ -60,8 +60,14 @@ def test_estimator_factory_names():
     assert get_estimator("ipca", 80, 1.0).batch_support is True
     with pytest.raises(RuntimeError, match="Unknown estimator"):
         get_estimator("bogus", 3, 1.0)
-    with pytest.raises(NotImplementedError):
-        get_estimator("pca", 3, 1.0)
+    # every name the reference's factory accepts (estimators.py:206-218) resolves, with the reference's cache keys
+    # (estimators.py:28-29, 62-63, 91-92, 132-133, 178-179)
+    assert get_estimator("pca", 3, 1.0).get_param_str() == "pca-full_c3"
+    assert get_estimator("fbpca", 3, 1.0).get_param_str() == "fbpca_c3_it2_l6"
+    assert get_estimator("ica", 3, 1.0).get_param_str() == "ica_c3_w"
+    assert get_estimator("spca", 3, 2.5).get_param_str() == "spca_c3_a2.5"
+    for name in ("pca", "fbpca", "ica", "spca"):
+        assert get_estimator(name, 3, 1.0).batch_support is False
 
 
 def test_product_package_never_imports_the_oracle():
@@ -71,6 +77,12 @@ def test_product_package_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), f
-                # no CPU linear algebra in the product (scipy.stats.truncnorm for BigGAN z parity is fine)
+                # no CPU linear algebra in the product (scipy.stats.truncnorm for BigGAN z parity is fine).  The one
+                # exception is the separate pass-through module for the reference's non-PCA estimators ('ica',
+                # 'spca': scikit-learn fits that SURVEY.md 2 keeps on the CPU), which only get_estimator() reaches.
+                if f == "cpu_estimators.py":
+                    continue
                 assert not re.search(r"^\s*(from|import)\s+(sklearn|scipy\.linalg|scipy\.sparse)\b", txt,
                                      flags=re.M), f
+                if f != "estimators.py":
+                    assert "cpu_estimators" not in txt, f

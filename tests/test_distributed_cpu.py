@@ -84,3 +84,79 @@ def test_allreduce_with_one_rank_is_a_fixed_point(tmp_path):
 def test_allreduce_is_identity_without_process_group():
     st = _state_of(_data([50])[0])
     assert D.allreduce_state(st.clone(), 24).equal(st)
+
+
+def test_pack_unpack_upper_roundtrip():
+    rs = np.random.RandomState(1)
+    for d in (1, 5, 24, 129):
+        A = rs.standard_normal((d, d))
+        S = torch.from_numpy(A + A.T).reshape(-1).clone()
+        packed = D.pack_upper(S, d)
+        assert packed.numel() == d * (d + 1) // 2
+        out = torch.empty_like(S)
+        D.unpack_upper(packed, d, out)
+        assert out.equal(S)
+
+
+def _worker_empty_rank(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # more ranks than blocks: rank 1 saw nothing and contributes an all-zero state
+    st = _state_of(_data([700], seed=5)[0]) if rank == 0 else torch.zeros(1 + 24 + 24 * 24, dtype=torch.float64)
+    D.allreduce_state(st, 24)
+    np.save(os.path.join(out_dir, f"rank{rank}.npy"), st.numpy())
+    dist.destroy_process_group()
+
+
+def test_allreduce_with_an_empty_rank(tmp_path):
+    mp.spawn(_worker_empty_rank, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    full = _state_of(_data([700], seed=5)[0]).numpy()
+    for r in range(2):
+        np.testing.assert_allclose(np.load(tmp_path / f"rank{r}.npy"), full, rtol=1e-10, atol=1e-9)
+
+
+# ---- the rank-sharded compute() plan: same blocks, same z rows as the single-process run -----------------------------
+
+@pytest.mark.parametrize("n,batch,k,world", [(1_000_000, 10_000, 80, 8), (8_000_000, 10_000, 80, 8), (10_000, 512, 20, 2),
+                                             (12_000, 1000, 10, 3), (4000, 500, 10, 5), (2100, 100, 8, 4)])
+def test_shard_plan_union_is_the_single_rank_block_list(n, batch, k, world):
+    from ganspace_amd.decomposition import _Plan
+    plan = _Plan.make(n, batch, k)
+    single = list(plan.block_starts)
+    shards = [plan.shard_blocks(r, world) for r in range(world)]
+    assert sum(shards, []) == single                          # contiguous shares, in order, nothing lost
+    assert max(map(len, shards)) - min(map(len, shards)) <= 1
+    per_block = -(-plan.NB // plan.B) * plan.B
+    for starts in shards:
+        lo, hi = plan.batch_span(starts)
+        if not starts:
+            assert (lo, hi) == (0, 0)
+            continue
+        # every row a block of this share reads lies inside the generated batches, and inside n_lat
+        assert lo * plan.B <= starts[0] and starts[-1] + per_block <= hi * plan.B <= plan.n_lat
+
+
+def test_sharded_presample_reads_the_same_z_rows():
+    """Every rank draws the whole seed list (models/wrappers.py:168-169) and generates only its batches: the rows it
+    holds are bit-identical to the single-process array and the global stream ends in the same state."""
+    from ganspace_amd.decomposition import SEED_SAMPLING, _Plan, _presample
+    from ganspace_amd.wrappers import StyleGAN2
+    cpu = torch.device("cpu")
+    model = StyleGAN2(cpu, "cat")                 # Z space: latent_from_z is the identity, nothing touches the GPU
+    shape = (1, 512)
+    plan = _Plan.make(6000, 250, 10)              # NB = 2000, 3 blocks, 8 batches per block
+    np.random.seed(SEED_SAMPLING)
+    full, row0 = _presample(model, plan, shape, cpu)
+    assert row0 == 0 and full.shape[0] == plan.n_lat
+    state_after = np.random.get_state()[1].copy()
+    world = 2
+    for rank in range(world):
+        starts = plan.shard_blocks(rank, world)
+        lo, hi = plan.batch_span(starts)
+        np.random.seed(SEED_SAMPLING)
+        part, r0 = _presample(model, plan, shape, cpu, lo, hi)
+        assert r0 == lo * plan.B and part.shape[0] == (min(hi, plan.n_lat // plan.B) - lo) * plan.B
+        assert torch.equal(part, full[r0:r0 + part.shape[0]])
+        for gi in starts:                         # the rows block gi consumes (decomposition.py:246-247)
+            assert torch.equal(part[gi - r0:gi - r0 + plan.NB], full[gi:gi + plan.NB])
+        np.testing.assert_array_equal(np.random.get_state()[1], state_after)

