@@ -111,6 +111,12 @@ struct SubspaceWorkspace {
     int plan_p = 0, plan_deg = 1, plan_ncyc = 1;
     double plan_gain = 0.0;
     int last_rr_sweeps = 0;        // Jacobi sweeps of the last Rayleigh-Ritz step
+    // warm starts of a SEQUENCE of related matrices (faithful mode: one per block) may take the guard columns
+    // k .. p-1 from the previous solve's Ritz basis instead of random vectors (set by the owner of the workspace)
+    bool reuse_guards = false;
+    bool guards_valid = false;
+    int guards_n = 0, guards_p = 0;
+    double *G = nullptr;           // [n][pp] Ritz basis of the last converged solve
     double *Q = nullptr, *Y = nullptr, *Z = nullptr, *R = nullptr;  // [n][pp]
     double *H = nullptr, *B = nullptr, *U = nullptr;                // [pp][pp]
     double *theta = nullptr;                                        // [3*pp + 32]: Ritz values | residuals | pivot floors / R diagonal | statistics (8) | filter coefficients (6)

@@ -434,6 +434,9 @@ int gs_ipca_create(int64_t d, int k, int mode, int precision, int device, gs_ipc
     h->gws.precision = precision;
     if (rc == GS_OK) rc = eigh_workspace_alloc(h->ews, (int)d + 2);
     if (rc == GS_OK && subspace_dim((int)d, k) > 0) rc = subspace_workspace_alloc(h->sws, (int)d, subspace_dim((int)d, k));
+    // consecutive blocks of the faithful recurrence have near-identical leading AND trailing spectra: the guard
+    // columns of one block's solve are good guards for the next
+    h->sws.reuse_guards = (mode == GS_MODE_FAITHFUL);
     h->dp = h->gws.dp;
     const int64_t dp = h->dp;
     alloc((void **)&h->shift, sizeof(float) * dp);
@@ -478,6 +481,8 @@ int gs_ipca_reset(gs_ipca_t *h) {
     h->blocks = 0;
     h->finalized = false;
     h->gws.pend_valid = false;
+    h->sws.guards_valid = false;
+    h->sws.plan_valid = false;
     return GS_OK;
 }
 

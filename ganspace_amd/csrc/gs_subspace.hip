@@ -130,11 +130,17 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(int M, int N, int K, cons
             if (gj < N) {
                 double *dst = C + (int64_t)gi * ldc + gj;
                 if (epi.coef != nullptr) {
-                    // C = coef[0] A B + coef[1] E1 + coef[2] E2 (coefficients live on the device; never split)
+                    // C = coef[0] A B + coef[1] E1 + coef[2] E2 (coefficients live on the device); with split-K the
+                    // first K slice carries the E terms
                     double v = epi.coef[0] * acc[r][c];
-                    if (epi.E1) v += epi.coef[1] * epi.E1[(int64_t)gi * ldc + gj];
-                    if (epi.E2) v += epi.coef[2] * epi.E2[(int64_t)gi * ldc + gj];
-                    *dst = v;
+                    if (!split || blockIdx.z == 0) {
+                        if (epi.E1) v += epi.coef[1] * epi.E1[(int64_t)gi * ldc + gj];
+                        if (epi.E2) v += epi.coef[2] * epi.E2[(int64_t)gi * ldc + gj];
+                    }
+                    if (split)
+                        atomicAdd(dst, v);
+                    else
+                        *dst = v;
                 } else if (split)
                     atomicAdd(dst, alpha * acc[r][c]);
                 else
@@ -158,7 +164,7 @@ void gemm_f64(int M, int N, int K, const double *A, int64_t a_i, int64_t a_t, co
     const int64_t tiles = ceil_div(M, TMv) * ceil_div(N, TMv);
     // split K (atomic epilogue) when the output alone cannot cover the chip and K is long enough
     int splits = 1;
-    if (allow_split && epi.coef == nullptr && beta == 0.0 && tiles < 128 && K >= 256) {
+    if (allow_split && beta == 0.0 && tiles < 128 && K >= 256) {
         splits = (int)ceil_div(160, tiles);
         if (splits > K / 64) splits = K / 64;
         if (splits < 1) splits = 1;
@@ -441,6 +447,7 @@ int subspace_workspace_alloc(SubspaceWorkspace &ws, int n, int p) {
     if (rc == GS_OK) rc = alloc(&ws.Y, np);
     if (rc == GS_OK) rc = alloc(&ws.Z, np);
     if (rc == GS_OK) rc = alloc(&ws.R, np);
+    if (rc == GS_OK) rc = alloc(&ws.G, np);
     if (rc == GS_OK) rc = alloc(&ws.H, ppp);
     if (rc == GS_OK) rc = alloc(&ws.B, ppp);
     if (rc == GS_OK) rc = alloc(&ws.U, ppp);
@@ -453,7 +460,7 @@ int subspace_workspace_alloc(SubspaceWorkspace &ws, int n, int p) {
 }
 
 void subspace_workspace_free(SubspaceWorkspace &ws) {
-    double *ptrs[] = {ws.Q, ws.Y, ws.Z, ws.R, ws.H, ws.B, ws.U, ws.theta, ws.Rm, ws.Dinv};
+    double *ptrs[] = {ws.Q, ws.Y, ws.Z, ws.R, ws.G, ws.H, ws.B, ws.U, ws.theta, ws.Rm, ws.Dinv};
     for (double *p : ptrs)
         if (p) (void)hipFree(p);
     eigh_workspace_free(ws.ews);

@@ -13,8 +13,8 @@
 //   filter     a few cycles of  Y = T_m((2 A - b I) / b) Q ; Q = orth(Y)  with b ~ lambda_p: the Chebyshev
 //              polynomial is bounded on [0, b] and grows like cosh(m acosh x) above it, so a degree-3 cycle gains
 //              ~150x on the W-space covariance of BASELINE cfg2 where three plain products gain ~14x
-//              (13-16 products and 6 orthonormalisations instead of 26 and 13).  The degree is capped so that
-//              T_m(x_1) <= 3e7 (CholeskyQR needs cond(Y)^2 < 1/eps); steep spectra get m = 1.
+//              (14 products and 5 orthonormalisations instead of 26 and 13).  The degree is capped so that
+//              T_m(x_1) <= 1e9; steep spectra get m = 1.
 //   orth       CholeskyQR: H = Y^T Y (GEMM), blocked Cholesky by chol_blocked_kernel (one workgroup, matrix in
 //              LDS), Q = Y R^-1 row-parallel: three launches instead of sixteen.
 //   project    B = Q^T A Q, eigenvectors by jacobi_lds_kernel (one workgroup, all sweeps, sorted output),
@@ -36,6 +36,12 @@ __device__ __forceinline__ double rsqrt64(double x) {
     y = y * (1.5 - hx * y * y);
     y = y * (1.5 - hx * y * y);
     return y;
+}
+
+// one Newton step on the hardware seed (~2^-26): ~1e-15 relative, enough for rotation angles
+__device__ __forceinline__ double rsqrt64_1(double x) {
+    double y = __builtin_amdgcn_rsq(x);
+    return y * (1.5 - 0.5 * x * y * y);
 }
 
 template <int CTRL>
@@ -60,9 +66,9 @@ __device__ __forceinline__ double sum8(double v) {
 // Cholesky factor of a p x p Gram matrix (p <= 128) in ONE workgroup of 1024 threads, blocked 32 wide, with the
 // matrix resident in LDS (128 x 129 doubles).
 //
-// Per block step J:  (a) the 32 x 32 diagonal block is factored together with an appended identity, one element
-// of each per thread: step j publishes row j through a double-buffered LDS row (one barrier per step, ~25
-// instructions per wave - the factorisation is a latency chain of 32 such steps, not throughput);  the trailing
+// Per block step J:  (a) the 32 x 32 diagonal block is factored together with an appended identity by four of the
+// sixteen waves (4 + 4 elements per thread): step j publishes row j through a double-buffered LDS row (one barrier
+// per step - the factorisation is a latency chain of 32 such steps, not throughput);  the trailing
 // block stays symmetric, so the multiplier of row r is the pivot row's entry at column r.  That leaves R_JJ and
 // R_JJ^-T.  (b) panel  R[J, rest] = R_JJ^-T H[J, rest]  and  (c) trailing update
 // H[rest, rest] -= R[J, rest]^T R[J, rest]  are small dense products out of LDS, all threads busy.
@@ -95,36 +101,62 @@ __global__ __launch_bounds__(1024) void chol_blocked_kernel(const double *__rest
     __syncthreads();
     for (int J = 0; J < nblk; ++J) {
         const int j0 = 32 * J, j1 = j0 + 32, rem = pend - j1;
-        // ---- (a) diagonal block with appended identity ----
-        double h = (r <= c) ? Hs[(j0 + r) * kCholLd + j0 + c] : Hs[(j0 + c) * kCholLd + j0 + r];
-        double e = (r == c) ? 1.0 : 0.0;
+        // ---- (a) diagonal block with appended identity: waves 0-3 work (thread (ry, c): rows ry + 8 i, column c), the
+        //      other twelve only keep the barriers company - a step is a latency chain, four waves (one per SIMD)
+        //      run it without competing for issue slots ----
+        const bool leaf = tid < 256;
+        const int ry = r & 7;
+        double h[4], e[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int rw = ry + 8 * i;
+            h[i] = (rw <= c) ? Hs[(j0 + rw) * kCholLd + j0 + c] : Hs[(j0 + c) * kCholLd + j0 + rw];
+            e[i] = (rw == c) ? 1.0 : 0.0;
+        }
         for (int j = 0; j < 32; ++j) {
             double *rl = rowL + (j & 1) * 32, *re = rowE + (j & 1) * 32;
-            if (r == j) {
-                rl[c] = h;
-                re[c] = e;
+            if (leaf && ry == (j & 7)) {
+                const int ij = j >> 3;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (i == ij) {
+                        rl[c] = h[i];
+                        re[c] = e[i];
+                    }
             }
             __syncthreads();
-            const double d = rl[j];
-            const bool dead = !(d > refd[j0 + j] * 1e-13);
-            const double inv = dead ? 0.0 : rsqrt64(d);
-            if (r > j) {
-                const double f = rl[r] * (inv * inv);
-                h -= f * rl[c];
-                e -= f * re[c];
-            } else if (r == j) {
-                h *= inv;
-                e *= inv;
+            if (leaf) {
+                const double d = rl[j];
+                const bool dead = !(d > refd[j0 + j] * 1e-13);
+                const double inv = dead ? 0.0 : rsqrt64(d);
+                const double inv2 = inv * inv;
+                const double hc = rl[c], ec = re[c];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int rw = ry + 8 * i;
+                    if (rw > j) {
+                        const double f = rl[rw] * inv2;
+                        h[i] -= f * hc;
+                        e[i] -= f * ec;
+                    } else if (rw == j) {
+                        h[i] *= inv;
+                        e[i] *= inv;
+                    }
+                }
             }
         }
-        {
-            const double rv = (r <= c) ? h : 0.0;
-            const double ev = (c <= r) ? e : 0.0;             // (R^-T)[r][c] = (R^-1)[c][r]
-            Hs[(j0 + r) * kCholLd + j0 + c] = rv;
-            Es[r * 33 + c] = ev;
-            if (j0 + r < p && j0 + c < p) Rm[(int64_t)(j0 + r) * ldr + j0 + c] = rv;
-            Dinv[(size_t)J * 1024 + c * 32 + r] = ev;
-            if (r == c && j0 + r < p) rdiag[j0 + r] = h;
+        if (leaf) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int rw = ry + 8 * i;
+                const double rv = (rw <= c) ? h[i] : 0.0;
+                const double ev = (c <= rw) ? e[i] : 0.0;          // (R^-T)[rw][c] = (R^-1)[c][rw]
+                Hs[(j0 + rw) * kCholLd + j0 + c] = rv;
+                Es[rw * 33 + c] = ev;
+                if (j0 + rw < p && j0 + c < p) Rm[(int64_t)(j0 + rw) * ldr + j0 + c] = rv;
+                Dinv[(size_t)J * 1024 + c * 32 + rw] = ev;
+                if (rw == c && j0 + rw < p) rdiag[j0 + rw] = h[i];
+            }
         }
         __syncthreads();
         if (rem <= 0) break;
@@ -244,6 +276,10 @@ __global__ __launch_bounds__(512) void jacobi_lds_kernel(const double *__restric
     constexpr double kTolRot2 = 1e-28;     // rotate while |gamma| > 1e-14 sqrt(alpha beta)
     constexpr double kTolBig2 = 1e-11;     // (3e-6)^2: a sweep without such a rotation is the last one
 
+    // element t of a column sits at  q + 8 (t ^ swz) = (q + 8 ((t & 3) ^ swz)) + 32 (t >> 2): four per-thread
+    // offsets, the rest is an immediate of the LDS instruction
+    const int eo0 = q + 8 * (0 ^ swz), eo1 = q + 8 * (1 ^ swz), eo2 = q + 8 * (2 ^ swz), eo3 = q + 8 * (3 ^ swz);
+#define GS_JAC_AT(col, t) ((col)[(((t) & 3) == 0 ? eo0 : ((t) & 3) == 1 ? eo1 : ((t) & 3) == 2 ? eo2 : eo3) + 32 * ((t) >> 2)])
     double x[NT], y[NT];
     int sweeps = 0;
     bool limit = false;
@@ -265,14 +301,14 @@ __global__ __launch_bounds__(512) void jacobi_lds_kernel(const double *__restric
                 double *ca = W + a * kJacLd, *cb = W + b * kJacLd;
                 if (a != cur_a) {
 #pragma unroll
-                    for (int t = 0; t < NT; ++t) x[t] = ca[q + 8 * (t ^ swz)];
+                    for (int t = 0; t < NT; ++t) x[t] = GS_JAC_AT(ca, t);
                     cur_a = a;
                 }
                 double alpha, beta;
                 double gq[4] = {0.0, 0.0, 0.0, 0.0};      // four partial sums: short dependent FMA chains
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
-                    y[t] = cb[q + 8 * (t ^ swz)];
+                    y[t] = GS_JAC_AT(cb, t);
                     gq[t & 3] += x[t] * y[t];
                 }
                 double gamma = (gq[0] + gq[1]) + (gq[2] + gq[3]);
@@ -296,9 +332,9 @@ __global__ __launch_bounds__(512) void jacobi_lds_kernel(const double *__restric
                 if (rot) {
                     if (q == 0 && g2 > kTolBig2 * ab) flag[0] = 1;
                     const double da = beta - alpha, db = 2.0 * gamma;
-                    const double ir = rsqrt64(da * da + db * db);
+                    const double ir = rsqrt64_1(da * da + db * db);
                     const double c2 = 0.5 + 0.5 * fabs(da) * ir;
-                    const double ic = rsqrt64(c2);
+                    const double ic = rsqrt64_1(c2);
                     const double c = c2 * ic;
                     double sn = 0.5 * fabs(db) * ir * ic;
                     sn = ((da < 0.0) != (db < 0.0)) ? -sn : sn;
@@ -306,7 +342,7 @@ __global__ __launch_bounds__(512) void jacobi_lds_kernel(const double *__restric
                     for (int t = 0; t < NT; ++t) {
                         const double xv = x[t], yv = y[t];
                         x[t] = c * xv - sn * yv;
-                        cb[q + 8 * (t ^ swz)] = sn * xv + c * yv;
+                        GS_JAC_AT(cb, t) = sn * xv + c * yv;
                     }
                     const double tg = sn * ic * gamma;               // t gamma,  t = s / c,  ic = 1 / c
                     alpha -= tg;
@@ -319,7 +355,7 @@ __global__ __launch_bounds__(512) void jacobi_lds_kernel(const double *__restric
                 if (i == 0) {
                     // this group's resident column leaves (it is the partner column of pair 1 next round)
 #pragma unroll
-                    for (int t = 0; t < NT; ++t) ca[q + 8 * (t ^ swz)] = x[t];
+                    for (int t = 0; t < NT; ++t) GS_JAC_AT(ca, t) = x[t];
                     cur_a = -1;
                 }
                 i = (i == 0) ? h - 1 : i - 1;
@@ -342,8 +378,9 @@ __global__ __launch_bounds__(512) void jacobi_lds_kernel(const double *__restric
     if (act && cur_a >= 0) {
         double *caw = W + cur_a * kJacLd;
 #pragma unroll
-        for (int t = 0; t < NT; ++t) caw[q + 8 * (t ^ swz)] = x[t];
+        for (int t = 0; t < NT; ++t) GS_JAC_AT(caw, t) = x[t];
     }
+#undef GS_JAC_AT
     __syncthreads();
     // ---- exact column norms -> eigenvalues, rank by decreasing value, normalised eigenvectors ----
     if (act) {
@@ -496,6 +533,14 @@ __global__ void topk_init_kernel(double *__restrict__ Q, int n, int p, int64_t l
     Q[(int64_t)i * ldq + j] = (double)(x >> 11) * (2.0 / 9007199254740992.0) - 1.0;
 }
 
+// dst[:, c0:c1] = src[:, c0:c1]
+__global__ void topk_copycols_kernel(double *__restrict__ dst, const double *__restrict__ src, int64_t ld, int c0,
+                                     int c1) {
+    const int j = c0 + blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = blockIdx.y;
+    if (j < c1) dst[(int64_t)i * ld + j] = src[(int64_t)i * ld + j];
+}
+
 __global__ void topk_seed_kernel(double *__restrict__ Q, int n, int64_t ldq, const double *__restrict__ V0, int k0,
                                  int64_t ldv) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
@@ -552,7 +597,7 @@ int jacobi_small_launch(const double *B, int64_t ldb, int p, double *U, int64_t 
 int orth_fast(SubspaceWorkspace &ws, const double *Y, double *Qout, int n, int p, hipStream_t stream) {
     const int64_t ld = ws.pp;
     GemmEpilogue none;
-    gemm_f64(p, p, n, Y, 1, ld, Y, ld, 1, ws.H, ld, stream, 1.0, 0.0, none, /*allow_split=*/n > 1024);
+    gemm_f64(p, p, n, Y, 1, ld, Y, ld, 1, ws.H, ld, stream, 1.0, 0.0, none, true);
     int rc = chol_blocked_launch(ws.H, ld, p, ws.Rm, ld, ws.Dinv, ws.theta + 2 * ws.pp, stream);
     if (rc != GS_OK) return rc;
     return trsm_rows_launch(Y, Qout, ld, n, p, ws.Rm, ws.Dinv, stream);
@@ -584,6 +629,9 @@ int eigh_topk_cheb(SubspaceWorkspace &ws, const double *A, int n, int64_t lda, i
     if (warm) {
         hipLaunchKernelGGL(topk_seed_kernel, dim3((unsigned)ceil_div(k0, 64), (unsigned)n), b64, 0, stream, buf[1], n, ld,
                            V0, k0, ldv0);
+        if (ws.reuse_guards && ws.guards_valid && ws.guards_n == n && ws.guards_p == p && k0 < p)
+            hipLaunchKernelGGL(topk_copycols_kernel, dim3((unsigned)ceil_div(p - k0, 64), (unsigned)n), b64, 0, stream,
+                               buf[1], ws.G, ld, k0, p);
         int rc = orth_fast(ws, buf[1], buf[0], n, p, stream);
         if (rc != GS_OK) return rc;
         q = 0;
@@ -594,7 +642,7 @@ int eigh_topk_cheb(SubspaceWorkspace &ws, const double *A, int n, int64_t lda, i
     const int est_cycles = warm ? 1 : 2;
     for (int c = 0; c < est_cycles; ++c) {
         const int y = (q + 1) & 3, o = (q + 2) & 3;
-        gemm_f64(n, p, n, A, lda, 1, buf[q], ld, 1, buf[y], ld, stream, 1.0, 0.0, none, n > 1024);
+        gemm_f64(n, p, n, A, lda, 1, buf[q], ld, 1, buf[y], ld, stream, 1.0, 0.0, none, true);
         ++mults;
         int rc = orth_fast(ws, buf[y], buf[o], n, p, stream);
         if (rc != GS_OK) return rc;
@@ -627,9 +675,12 @@ int eigh_topk_cheb(SubspaceWorkspace &ws, const double *A, int n, int64_t lda, i
                 if (iters_out) *iters_out = mults;
                 return GS_OK;
             }
+            // CholeskyQR is invariant under column scaling, and the filtered block is the (roughly Ritz-ordered)
+            // previous basis times diag(T_m(x_i)): amplification up to ~1e11 leaves it orthonormal to rounding
+            // on the spectra tried; 1e9 keeps two digits of margin to the first dead pivot
             deg = 1;
-            for (int m = 4; m >= 2; --m)
-                if (cheb_T(m, x1) <= 3e7) {
+            for (int m = 6; m >= 2; --m)
+                if (cheb_T(m, x1) <= 1e9) {
                     deg = m;
                     break;
                 }
@@ -657,7 +708,7 @@ int eigh_topk_cheb(SubspaceWorkspace &ws, const double *A, int n, int64_t lda, i
             GemmEpilogue e1;
             e1.coef = coef;
             e1.E1 = buf[t0];
-            gemm_f64(n, p, n, A, lda, 1, buf[t0], ld, 1, buf[t1], ld, stream, 1.0, 0.0, e1, false);
+            gemm_f64(n, p, n, A, lda, 1, buf[t0], ld, 1, buf[t1], ld, stream, 1.0, 0.0, e1, true);
             ++mults;
             int prev = t0, cur = t1;
             int freeb[2] = {t2, t3};
@@ -668,7 +719,7 @@ int eigh_topk_cheb(SubspaceWorkspace &ws, const double *A, int n, int64_t lda, i
                 e2.E1 = buf[cur];
                 e2.E2 = buf[prev];
                 const int nxt = freeb[fi];
-                gemm_f64(n, p, n, A, lda, 1, buf[cur], ld, 1, buf[nxt], ld, stream, 1.0, 0.0, e2, false);
+                gemm_f64(n, p, n, A, lda, 1, buf[cur], ld, 1, buf[nxt], ld, stream, 1.0, 0.0, e2, true);
                 ++mults;
                 // `prev` becomes free - except Q itself in the first step, which nothing needs any more either
                 freeb[fi] = prev;
@@ -682,17 +733,12 @@ int eigh_topk_cheb(SubspaceWorkspace &ws, const double *A, int n, int64_t lda, i
             if (rc != GS_OK) return rc;
             q = o;
         }
-        // second CholeskyQR pass before projecting
-        {
-            const int o = (q + 1) & 3;
-            int rc = orth_fast(ws, buf[q], buf[o], n, p, stream);
-            if (rc != GS_OK) return rc;
-            q = o;
-        }
+        // (no second CholeskyQR pass: a single pass leaves the filtered basis orthonormal to ~1e-14 - see the degree
+        //  cap above; whatever is left shows up in the residuals below, which are computed from the emitted vectors)
         // ---- Rayleigh-Ritz -------------------------------------------------------------------------------
         const int y = (q + 1) & 3, z = (q + 2) & 3, w = (q + 3) & 3;
-        gemm_f64(n, p, n, A, lda, 1, buf[q], ld, 1, buf[y], ld, stream, 1.0, 0.0, none, n > 1024);   // Y = A Q
-        gemm_f64(p, p, n, buf[q], 1, ld, buf[y], ld, 1, ws.B, ld, stream, 1.0, 0.0, none, n > 1024);  // B = Q^T Y
+        gemm_f64(n, p, n, A, lda, 1, buf[q], ld, 1, buf[y], ld, stream, 1.0, 0.0, none, true);   // Y = A Q
+        gemm_f64(p, p, n, buf[q], 1, ld, buf[y], ld, 1, ws.B, ld, stream, 1.0, 0.0, none, true);  // B = Q^T Y
         {
             int rcj = jacobi_small_launch(ws.B, ld, p, ws.U, ld, ws.theta, jinfo, stream);
             if (rcj != GS_OK) return rcj;
@@ -720,6 +766,12 @@ int eigh_topk_cheb(SubspaceWorkspace &ws, const double *A, int n, int64_t lda, i
             hipLaunchKernelGGL(topk_emit_kernel, dim3((unsigned)ceil_div(n, 256), (unsigned)k), dim3(256), 0, stream,
                                buf[z], ld, ws.theta, n, k, Vk, ldv, lam);
             GS_HIP_CHECK(hipGetLastError());
+            if (ws.reuse_guards) {
+                GS_HIP_CHECK(hipMemcpyAsync(ws.G, buf[z], sizeof(double) * (size_t)n * ld, hipMemcpyDeviceToDevice, stream));
+                ws.guards_valid = true;
+                ws.guards_n = n;
+                ws.guards_p = p;
+            }
             if (warm) {
                 // remember the schedule: consecutive blocks of the incremental PCA have near-identical spectra.
                 // A wide margin (> 3 digits in the residual) tries one cycle fewer next time.
