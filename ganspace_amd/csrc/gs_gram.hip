@@ -6,15 +6,16 @@
 // the d x d scatter  sum_r (x_r - s)(x_r - s)^T  and the column sums  sum_r (x_r - s)
 // of the [rows, d] float32 activation block are accumulated on the matrix cores.
 //
-// Work decomposition (one launch per <= 24 x 1024 rows at d = 512):
+// Work decomposition (one launch per <= 2^20 rows):
 //   * output: upper-triangle 128 x 128 macro tiles of the d x d Gram (symmetry: the lower
 //     triangle is never computed); one workgroup (8 waves = 2 per SIMD) per (macro tile, row
 //     chunk); wave (wi, wj) owns a 64 x 32 strip = 2 accumulators of v_mfma_f32_32x32x2_f32;
 //     diagonal macro tiles compute only their 10 upper sub-tiles, dealt 3/3/2/2 to the SIMDs.
 //   * split-K over row chunks (rows dealt in 16-row units, lengths differ by at most one unit):
 //     each chunk's partial tile goes to a float32 slab; the slabs are folded in float64 into
-//     the persistent accumulator (by spare workgroups of the next launch in exact mode), so
-//     float32 fma chains never exceed 1024 rows (416 at the 10 000-row block of the bench).
+//     the persistent accumulator (by spare workgroups of the next launch in exact mode); chunks longer than
+//     1024 rows (multi-block launches) carry their float32 accumulators into float64 registers every 16 stages,
+//     so float32 fma chains never exceed 1024 rows (416 at the 10 000-row block of the reference loop).
 //   * X is row-major [rows, d]; for X^T X both MFMA operands are "row k, 32 consecutive
 //     columns" (A[i][k] = X[k][I+i], B[k][j] = X[k][J+j]) so global reads are fully
 //     coalesced 512-B row segments and LDS reads are conflict-free ds_read_b32 without
@@ -42,7 +43,8 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 constexpr int kKB = 64;        // rows per LDS stage (2 x 2 x 64 x 128 f32 = 128 KiB of LDS per workgroup)
 constexpr int kLoadIters = kKB / 16;
 constexpr int kThreads = 512;   // 8 waves: two per SIMD
-constexpr int kMaxChunkRows = 1024;  // longest float32 fma chain before the float64 fold
+constexpr int kMaxChunkRows = 1024;  // longest float32 fma chain before the float64 carry
+constexpr int64_t kMaxLaunchRows = (int64_t)1 << 20;   // rows of one partial-Gram launch (32-bit unit counts, event timing)
 
 // Raw (un-shifted) float4 of X at a CLAMPED address: never out of bounds, never branches, and
 // nothing depends on the loaded value until `finish` runs - so all loads of a stage stay in
@@ -205,7 +207,7 @@ using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
 // branches once per wave) - whose accumulators never leave their registers, loads through a buffer resource
 // (row offsets in SGPRs: no per-load VALU, rows past the end of X read as 0) and stores without masks; the short
 // first stage, the chunk's ragged last stage and tiles that straddle column d use the general code outside.
-template <bool VEC, bool DIAG, bool M0, bool M1>
+template <bool VEC, bool LONG, bool DIAG, bool M0, bool M1>
 __device__ __forceinline__ void gram_tile(const GramTileCtx &c, float (*lds)[2][kKB][kMacroTile], int wi, int wj) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int c4 = tid & 31, rr = tid >> 5;  // 16 row groups x 32 float4 columns
@@ -297,6 +299,31 @@ __device__ __forceinline__ void gram_tile(const GramTileCtx &c, float (*lds)[2][
     };
     stamp(0);
     f32x16 acc0 = {0}, acc1 = {0};
+    // float64 carry of the float32 accumulators: a chunk longer than kMaxChunkRows (multi-block launches) is folded
+    // in registers every 16 stages, so no float32 fma chain exceeds 1024 rows whatever the chunk length
+    // (LONG is a launch-time template switch: the code of the ordinary launches is untouched)
+    double car0[LONG ? 16 : 1], car1[LONG ? 16 : 1];
+#pragma unroll
+    for (int r = 0; r < (LONG ? 16 : 1); ++r) {
+        car0[r] = 0.0;
+        car1[r] = 0.0;
+    }
+    int since_fold = 0;
+    auto carry = [&]() {
+        if (!LONG) return;
+        if (++since_fold < kMaxChunkRows / kKB) return;
+        since_fold = 0;
+        if (M0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) car0[LONG ? r : 0] += (double)acc0[r];
+            acc0 = f32x16{0};
+        }
+        if (M1) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) car1[LONG ? r : 0] += (double)acc1[r];
+            acc1 = f32x16{0};
+        }
+    };
     const int64_t nrows = r1 - c.r0;
     // Stage 0 takes the part of the chunk that does not fill whole stages (nrows mod 64; chunk lengths are
     // multiples of 16 except at the very end of a launch), so every later stage is a whole one and there is no
@@ -345,6 +372,7 @@ __device__ __forceinline__ void gram_tile(const GramTileCtx &c, float (*lds)[2][
         __syncthreads();
         stamp(2 + s);
         ++s;
+        carry();
     };
     if (nst > 0) {
         fetch(f, c.r0, ((int)first + 15) / 16);
@@ -367,6 +395,7 @@ __device__ __forceinline__ void gram_tile(const GramTileCtx &c, float (*lds)[2][
             __syncthreads();
             stamp(2 + s);
             ++s;
+            carry();
         }
     }
     while (s < nst) general();                                // last whole stage, ragged stage; partial-column tiles
@@ -380,12 +409,12 @@ __device__ __forceinline__ void gram_tile(const GramTileCtx &c, float (*lds)[2][
         if (M0) {
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-                Pc[(int64_t)(row_base + (r & 3) + 8 * (r >> 2)) * dp + col] = acc0[r];
+                Pc[(int64_t)(row_base + (r & 3) + 8 * (r >> 2)) * dp + col] = LONG ? (float)(car0[LONG ? r : 0] + (double)acc0[r]) : acc0[r];
         }
         if (M1) {
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-                Pc[(int64_t)(row_base + 32 + (r & 3) + 8 * (r >> 2)) * dp + col] = acc1[r];
+                Pc[(int64_t)(row_base + 32 + (r & 3) + 8 * (r >> 2)) * dp + col] = LONG ? (float)(car1[LONG ? r : 0] + (double)acc1[r]) : acc1[r];
         }
     }
     stamp(14);
@@ -409,11 +438,11 @@ __device__ __forceinline__ void gram_tile(const GramTileCtx &c, float (*lds)[2][
 // strip assignment of the 8 waves.  Off-diagonal tiles: wave w -> (w >> 2, w & 3), both sub-tiles.  Diagonal
 // tiles: only the 10 sub-tiles on / above the diagonal are computed, dealt to the waves so that the two waves
 // sharing a SIMD (w and w + 4) issue 3, 3, 2, 2 MFMAs per k-step.
-template <bool VEC>
+template <bool VEC, bool LONG>
 __device__ __forceinline__ void gram_tile_dispatch(const GramTileCtx &c, float (*lds)[2][kKB][kMacroTile]) {
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     if (c.I != c.J) {
-        gram_tile<VEC, false, true, true>(c, lds, wave >> 2, wave & 3);
+        gram_tile<VEC, LONG, false, true, true>(c, lds, wave >> 2, wave & 3);
         return;
     }
     const int tab_i[8] = {0, 1, 0, 1, 0, 0, 0, 0};
@@ -421,14 +450,14 @@ __device__ __forceinline__ void gram_tile_dispatch(const GramTileCtx &c, float (
     const int tab_m[8] = {1, 1, 3, 3, 3, 3, 0, 0};  // bit0: sub-tile a=0, bit1: a=1
     const int wi = tab_i[wave], wj = tab_j[wave], m = tab_m[wave];
     if (m == 3)
-        gram_tile<VEC, true, true, true>(c, lds, wi, wj);
+        gram_tile<VEC, LONG, true, true, true>(c, lds, wi, wj);
     else if (m == 1)
-        gram_tile<VEC, true, true, false>(c, lds, wi, wj);
+        gram_tile<VEC, LONG, true, true, false>(c, lds, wi, wj);
     else
-        gram_tile<VEC, true, false, false>(c, lds, wi, wj);
+        gram_tile<VEC, LONG, true, false, false>(c, lds, wi, wj);
 }
 
-template <bool VEC>
+template <bool VEC, bool LONG>
 __global__ __launch_bounds__(kThreads, 1) void gram_partial_kernel(
     const float *__restrict__ X, int64_t rows, int64_t ld, int d, const float *__restrict__ shift,
     float *__restrict__ P, float *__restrict__ CS, int dp, int nchunks, ChunkPlan plan, int nmt,
@@ -458,7 +487,7 @@ __global__ __launch_bounds__(kThreads, 1) void gram_partial_kernel(
     c.trace = fold.trace;
     chunk_range(plan, c.chunk, rows, c.r0, c.r1);
     c.rows_total = rows;
-    gram_tile_dispatch<VEC>(c, lds);
+    gram_tile_dispatch<VEC, LONG>(c, lds);
 }
 
 // Stand-alone fold (faithful mode needs the block's Gram immediately; also the final flush).
@@ -515,7 +544,9 @@ static GramGeom gram_geometry(const GramWorkspace &ws, int64_t n) {
     g.want = (target_wgs / g.nmt) / 8 * 8;
     if (g.want < 8) g.want = 8;
     if (g.want > ws.max_chunks) g.want = ws.max_chunks;
-    g.rows_per_launch = (int64_t)g.want * kMaxChunkRows;
+    // chunks of any length (the kernel carries its float32 accumulators into float64 registers every 1024 rows);
+    // one launch takes up to kMaxLaunchRows rows
+    g.rows_per_launch = ws.precision == GS_PREC_F32 ? kMaxLaunchRows : (int64_t)g.want * kMaxChunkRows;
     if (n > g.rows_per_launch) n = g.rows_per_launch;
     // deal the rows out in units of kRowUnit, at least 64 rows per chunk
     const int64_t units = ceil_div(n, (int64_t)kRowUnit);
@@ -611,14 +642,20 @@ static void launch_partial(const GramWorkspace &ws, const GramGeom &g, int buf, 
         return;
     }
     const dim3 grid((unsigned)(g.grid + nfold));
-    if (vec)
-        hipLaunchKernelGGL(gram_partial_kernel<true>, grid, dim3(kThreads), 0, stream, Xb, n, ld, (int)d, shift,
-                           ws.partial[buf], ws.colsum_partial[buf], dp, g.nchunks, g.plan, g.nmt, g.T, ablate,
-                           g.grid, fj);
+    // chunks longer than one float32 accumulation span use the variant that carries into float64 registers
+    const bool lng = ((int64_t)g.plan.q + (g.plan.rem ? 1 : 0)) * kRowUnit > kMaxChunkRows;
+#define GS_GRAM_LAUNCH(V, L)                                                                                        \
+    hipLaunchKernelGGL((gram_partial_kernel<V, L>), grid, dim3(kThreads), 0, stream, Xb, n, ld, (int)d, shift,     \
+                       ws.partial[buf], ws.colsum_partial[buf], dp, g.nchunks, g.plan, g.nmt, g.T, ablate, g.grid, fj)
+    if (vec && lng)
+        GS_GRAM_LAUNCH(true, true);
+    else if (vec)
+        GS_GRAM_LAUNCH(true, false);
+    else if (lng)
+        GS_GRAM_LAUNCH(false, true);
     else
-        hipLaunchKernelGGL(gram_partial_kernel<false>, grid, dim3(kThreads), 0, stream, Xb, n, ld, (int)d, shift,
-                           ws.partial[buf], ws.colsum_partial[buf], dp, g.nchunks, g.plan, g.nmt, g.T, ablate,
-                           g.grid, fj);
+        GS_GRAM_LAUNCH(false, false);
+#undef GS_GRAM_LAUNCH
     dump_trace(trace_buf, g.grid, stream, g.nmt);
 }
 

@@ -703,7 +703,7 @@ int gs_gram_kernel_time(gs_ipca_t *h, const float *X, int64_t rows, int64_t ld, 
                         int64_t *rows_timed_host, void *stream_) {
     GS_REQUIRE(h && X && avg_ms_host && iters >= 1 && rows >= 1 && ld >= h->d, GS_EINVAL,
                "gs_gram_kernel_time: bad argument");
-    const int64_t cap = (int64_t)24 * 1024;
+    const int64_t cap = (int64_t)1 << 20;
     if (rows_timed_host) *rows_timed_host = rows < cap ? rows : cap;
     return gram_partial_time(h->gws, X, rows < cap ? rows : cap, ld, h->d, h->shift, iters, avg_ms_host,
                              (hipStream_t)stream_);

@@ -20,6 +20,7 @@
 //   project    B = Q^T A Q, eigenvectors by jacobi_lds_kernel (one workgroup, all sweeps, sorted output),
 //              residual test, emit.
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <utility>
 #include <vector>
@@ -84,8 +85,11 @@ constexpr int kCholLd = 129;
 constexpr size_t kCholLdsBytes = sizeof(double) * ((size_t)kCholP * kCholLd + 32 * 33 + 64 + 64 + kCholP);
 __global__ __launch_bounds__(1024) void chol_blocked_kernel(const double *__restrict__ H, int64_t ldh, int p,
                                                              double *__restrict__ Rm, int64_t ldr,
-                                                             double *__restrict__ Dinv, double *__restrict__ rdiag) {
+                                                             double *__restrict__ Dinv, double *__restrict__ rdiag,
+                                                             int debug) {
     extern __shared__ __attribute__((aligned(16))) double csm[];
+    const long long dbg_c0 = debug ? clock64() : 0, dbg_w0 = debug ? wall_clock64() : 0;
+    long long dbg_leaf = 0, dbg_panel = 0, dbg_trail = 0;
     double *Hs = csm;                            // [128][129]
     double *Es = Hs + kCholP * kCholLd;          // [32][33]   R_JJ^-T of the current block (lower triangular)
     double *rowL = Es + 32 * 33;                 // [2][32]    published pivot row, matrix half
@@ -104,6 +108,7 @@ __global__ __launch_bounds__(1024) void chol_blocked_kernel(const double *__rest
         // ---- (a) diagonal block with appended identity: waves 0-3 work (thread (ry, c): rows ry + 8 i, column c), the
         //      other twelve only keep the barriers company - a step is a latency chain, four waves (one per SIMD)
         //      run it without competing for issue slots ----
+        long long dbg_t = debug ? clock64() : 0;
         const bool leaf = tid < 256;
         const int ry = r & 7;
         double h[4], e[4];
@@ -159,6 +164,11 @@ __global__ __launch_bounds__(1024) void chol_blocked_kernel(const double *__rest
             }
         }
         __syncthreads();
+        if (debug) {
+            const long long t = clock64();
+            dbg_leaf += t - dbg_t;
+            dbg_t = t;
+        }
         if (rem <= 0) break;
         // ---- (b) panel: P[i][c2] = sum_{t <= i} Es[i][t] H[j0 + t][c2] ----
         double acc[3];
@@ -189,6 +199,11 @@ __global__ __launch_bounds__(1024) void chol_blocked_kernel(const double *__rest
             }
         }
         __syncthreads();
+        if (debug) {
+            const long long t = clock64();
+            dbg_panel += t - dbg_t;
+            dbg_t = t;
+        }
         // ---- (c) trailing update, upper part: H[r2][c2] -= sum_t R[j0 + t][r2] R[j0 + t][c2] ----
         const int ntrail = rem * rem;
         for (int idx = tid; idx < ntrail; idx += 1024) {
@@ -204,6 +219,12 @@ __global__ __launch_bounds__(1024) void chol_blocked_kernel(const double *__rest
             }
         }
         __syncthreads();
+        if (debug) dbg_trail += clock64() - dbg_t;
+    }
+    if (debug && tid == 0) {
+        const long long c3 = clock64(), w3 = wall_clock64();
+        printf("[chol p=%d] leaf %lld clk, panel %lld, trailing %lld; total %lld clk in %lld x10ns -> %.0f MHz\n", p, dbg_leaf,
+               dbg_panel, dbg_trail, c3 - dbg_c0, w3 - dbg_w0, (double)(c3 - dbg_c0) / ((double)(w3 - dbg_w0) * 0.01));
     }
 }
 
@@ -228,7 +249,8 @@ constexpr int kJacMaxSweeps = 30;
 template <int NT>
 __global__ __launch_bounds__(512) void jacobi_lds_kernel(const double *__restrict__ B, int64_t ldb, int p,
                                                           double *__restrict__ U, int64_t ldu,
-                                                          double *__restrict__ theta, int *__restrict__ info) {
+                                                          double *__restrict__ theta, int *__restrict__ info, int debug) {
+    const long long dbg_c0 = debug ? clock64() : 0, dbg_w0 = debug ? wall_clock64() : 0;
     extern __shared__ __attribute__((aligned(16))) double jsm[];
     double *W = jsm;                                         // [p][kJacLd]
     double *nrm = jsm + (size_t)kJacLd * kJacLd;             // [128] squared column norms
@@ -281,6 +303,7 @@ __global__ __launch_bounds__(512) void jacobi_lds_kernel(const double *__restric
     const int eo0 = q + 8 * (0 ^ swz), eo1 = q + 8 * (1 ^ swz), eo2 = q + 8 * (2 ^ swz), eo3 = q + 8 * (3 ^ swz);
 #define GS_JAC_AT(col, t) ((col)[(((t) & 3) == 0 ? eo0 : ((t) & 3) == 1 ? eo1 : ((t) & 3) == 2 ? eo2 : eo3) + 32 * ((t) >> 2)])
     double x[NT], y[NT];
+    const long long dbg_c1 = debug ? clock64() : 0;
     int sweeps = 0;
     bool limit = false;
     int cur_a = -1;
@@ -330,8 +353,11 @@ __global__ __launch_bounds__(512) void jacobi_lds_kernel(const double *__restric
                 const double ab = alpha * beta, g2 = gamma * gamma;
                 const bool rot = (alpha > floor2) && (beta > floor2) && (g2 > kTolRot2 * ab);
                 if (rot) {
-                    if (q == 0 && g2 > kTolBig2 * ab) flag[0] = 1;
                     const double da = beta - alpha, db = 2.0 * gamma;
+                    // not yet safe to stop: a big rotation, or a small one between columns of (nearly) equal norm - a
+                    // cluster of eigenvalues, where the convergence is not quadratic
+                    const double sm = alpha + beta;
+                    if (q == 0 && (g2 > kTolBig2 * ab || (g2 > 1e-20 * ab && da * da < 1e-6 * sm * sm))) flag[0] = 1;
                     const double ir = rsqrt64_1(da * da + db * db);
                     const double c2 = 0.5 + 0.5 * fabs(da) * ir;
                     const double ic = rsqrt64_1(c2);
@@ -374,6 +400,7 @@ __global__ __launch_bounds__(512) void jacobi_lds_kernel(const double *__restric
         }
         __syncthreads();
     }
+    const long long dbg_c2 = debug ? clock64() : 0;
     // flush the resident columns
     if (act && cur_a >= 0) {
         double *caw = W + cur_a * kJacLd;
@@ -419,6 +446,12 @@ __global__ __launch_bounds__(512) void jacobi_lds_kernel(const double *__restric
     if (tid == 0) {
         info[0] = sweeps;
         info[1] = limit ? 1 : 0;
+        if (debug) {
+            const long long c3 = clock64(), w3 = wall_clock64();
+            printf("[jacobi p=%d] sweeps %d: load %lld clk, sweeps %lld clk (%lld per round), output %lld clk; total %lld clk in %lld x10ns -> %.0f MHz\n",
+                   p, sweeps, dbg_c1 - dbg_c0, dbg_c2 - dbg_c1, (dbg_c2 - dbg_c1) / ((long long)sweeps * m1), c3 - dbg_c2,
+                   c3 - dbg_c0, w3 - dbg_w0, (double)(c3 - dbg_c0) / ((double)(w3 - dbg_w0) * 0.01));
+        }
     }
 }
 
@@ -561,8 +594,9 @@ int chol_blocked_launch(const double *H, int64_t ldh, int p, double *Rm, int64_t
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)kCholLdsBytes));
         attr_set = true;
     }
+    static const int debug = getenv("GS_TOPK_DEBUG") ? 1 : 0;
     hipLaunchKernelGGL(chol_blocked_kernel, dim3(1), dim3(1024), kCholLdsBytes, stream, H, ldh, p, Rm, ldr, Dinv,
-                       rdiag);
+                       rdiag, debug);
     GS_HIP_CHECK(hipGetLastError());
     return GS_OK;
 }
@@ -576,8 +610,9 @@ static int jacobi_launch_nt(const double *B, int64_t ldb, int p, double *U, int6
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)jacobi_lds_bytes()));
         attr_set = true;
     }
+    static const int debug = getenv("GS_TOPK_DEBUG") ? 1 : 0;
     hipLaunchKernelGGL(jacobi_lds_kernel<NT>, dim3(1), dim3(4 * p), jacobi_lds_bytes(), stream, B, ldb, p, U, ldu,
-                       theta, info);
+                       theta, info, debug);
     GS_HIP_CHECK(hipGetLastError());
     return GS_OK;
 }

@@ -251,7 +251,7 @@ class IPCAEstimator:
 
 class _WholeMatrixPCA:
     """Shared body of the two non-batch PCA estimators: ONE pass of the Gram kernel over the whole
-    ``[N, d]`` matrix (EXACT-mode handle, fed in launches of <= 24 576 rows), one top-k eigensolve, then the
+    ``[N, d]`` matrix (EXACT-mode handle, fed in launches of <= 2^20 rows), one top-k eigensolve, then the
     reference's post-processing (estimators.py:96-118 / :137-157): projected standard deviations (ddof = 0),
     components sorted by them, ``total_var = X.var(axis=0).sum()``, ``mean_ = X.mean(axis=0)``.
 
@@ -261,7 +261,7 @@ class _WholeMatrixPCA:
     second pass over X is needed: it is evaluated from the accumulated statistics in float64.
     """
 
-    ROWS_PER_LAUNCH = 24576
+    ROWS_PER_LAUNCH = 1 << 20
 
     def __init__(self, n_components, centre, device=None):
         self.n_components = int(n_components)

@@ -137,7 +137,7 @@ int gs_gram_accumulate_prec(const float *X, int64_t rows, int64_t ld, int64_t d,
 /* Measurement hook for bench.py: average duration in ms of the dominant kernel alone (the
  * partial X^T X MFMA kernel of gs_ipca_update, without the float64 fold), `iters`
  * back-to-back launches bracketed by HIP events on `stream`.  rows_timed_host receives the
- * number of rows one launch covers (min(rows, 24576)).  Results of the launches are
+ * number of rows one launch covers (min(rows, 2^20)).  Results of the launches are
  * discarded (they only touch the handle's scratch slabs).                                  */
 int gs_gram_kernel_time(gs_ipca_t *h, const float *X, int64_t rows, int64_t ld, int iters,
                         float *avg_ms_host, int64_t *rows_timed_host, void *stream);

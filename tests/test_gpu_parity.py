@@ -32,6 +32,8 @@ def _golden(golden_dir, name):
 @pytest.mark.parametrize("rows,d,ld_extra,use_shift", [
     (1000, 64, 0, False), (777, 200, 8, True), (2000, 512, 0, True), (333, 37, 3, True),
     (10000, 512, 0, False), (4097, 384, 0, True), (5, 128, 0, False), (30000, 96, 0, True),
+    # multi-block launches: chunks longer than one float32 accumulation span (1024 rows) carry into float64 registers
+    (70000, 512, 0, True), (200000, 64, 0, False), (50001, 200, 8, True),
 ])
 def test_gram_accumulate_matches_float64(dev, rows, d, ld_extra, use_shift):
     from ganspace_amd import ops
