@@ -7,7 +7,10 @@ models/wrappers.py:167-174, seed list drawn after np.random.seed(1), decompositi
 mapping-network kernel - i.e. through the product's own ``decomposition._presample``.
 
 A *step* is FIVE IPCA blocks (5 x NB = 50 000 rows x 512 features, float32, already resident in HBM) pushed through
-``fit_partial``; the driver's ``--steps 20`` is therefore exactly n = 1e6 samples per GPU.  After the K timed steps
+``fit_partial`` - in exact mode as ONE call on the contiguous 50 000-row view, exactly as the product's
+``decomposition._fit_blocks`` feeds a W-space ``ipca-exact`` fit (the additive statistics do not depend on the
+block boundaries); in faithful mode as five NB-row calls (sklearn's recurrence does).  The driver's ``--steps 20``
+is therefore exactly n = 1e6 samples per GPU.  After the K timed steps
 the job is completed inside the timed region (multi-GPU: the RCCL all-reduce of the sufficient statistics; then
 the eigensolve and the device->host copy of the components), so ``value`` is whole-job throughput and
 ``ms_per_step * steps`` is the timed region.
@@ -63,8 +66,12 @@ def make_blocks(n_blocks, dev, rank=0, world=1):
     np.random.seed(dec.SEED_SAMPLING)
     latents, row0 = dec._presample(model, plan, latent_shape, dev, b_lo, b_hi)
     torch.cuda.synchronize()
-    blocks = [latents[g - row0:g - row0 + NB].reshape(NB, -1) for g in starts]
-    return blocks, time.perf_counter() - t0
+    flat = latents.reshape(latents.shape[0], -1)
+    blocks = [flat[g - row0:g - row0 + NB] for g in starts]
+    assert all(b - a == NB for a, b in zip(starts[:-1], starts[1:]))
+    # one view per step (BLOCKS_PER_STEP consecutive blocks: contiguous rows of the latent array)
+    steps = [flat[starts[i] - row0:starts[i] - row0 + BLOCKS_PER_STEP * NB] for i in range(0, len(starts), BLOCKS_PER_STEP)]
+    return blocks, steps, time.perf_counter() - t0
 
 
 def gram_kernel_us(lib, _lib, est, block, iters=50):
@@ -107,7 +114,7 @@ def main():
 
     K, Wm = args.steps, args.warmup
     n_blocks = K * BLOCKS_PER_STEP
-    blocks, t_sample = make_blocks(n_blocks, dev, rank, world)
+    blocks, step_views, t_sample = make_blocks(n_blocks, dev, rank, world)
     log(f"rank {rank}: {len(blocks)} blocks of {NB} W-space rows resident ({t_sample:.1f} s: z stream + mapping network)")
 
     def barrier():
@@ -116,9 +123,12 @@ def main():
         torch.cuda.synchronize()
 
     def run(est, nsteps, finish=True):
-        for i in range(nsteps * BLOCKS_PER_STEP):
-            ok = est.fit_partial(blocks[i % n_blocks])
-            assert ok
+        if est.mode == "exact":
+            for i in range(nsteps):
+                assert est.fit_partial(step_views[i % K])
+        else:
+            for i in range(nsteps * BLOCKS_PER_STEP):
+                assert est.fit_partial(blocks[i % n_blocks])
         if finish:
             if dist is not None and args.mode == "exact":
                 gdist.allreduce_estimator(est, d=D)
@@ -159,7 +169,9 @@ def main():
 
     # ---- roofline of the dominant kernel of the timed region (the partial X^T X MFMA kernel: one launch per
     #      block, K x 5 launches), HIP events on its stream ----------------------------------------------------
-    us, rows_l = gram_kernel_us(lib, _lib, est2, blocks[0])
+    gram_view = step_views[0] if args.mode == "exact" else blocks[0]
+    n_launches = K if args.mode == "exact" else n_blocks
+    us, rows_l = gram_kernel_us(lib, _lib, est2, gram_view)
     flops = rows_l * D * (D + 1)           # algorithmic: upper triangle incl. diagonal, 2 flop/MAC
     bytes_ = rows_l * D * 4                # algorithmic: one read of the [rows, d] f32 block
     ach_tf = flops / (us * 1e-6) / 1e12
@@ -172,16 +184,16 @@ def main():
         with open(os.path.join(ROOT, "profiles", "gram_pmc_latest.json")) as f:
             pmc = json.load(f)
         if pmc.get("rows_per_launch") == rows_l:
-            traffic = pmc["hbm_read_bytes_per_launch_corrected_x2"]
+            traffic = pmc.get("hbm_bytes_per_launch", pmc["hbm_read_bytes_per_launch_corrected_x2"])
             traffic_note = pmc.get("traffic_breakdown")
     except Exception:
         pass
-    frac_of_region = (n_blocks * us * 1e-6) / (t_updates + t_final) if (t_updates + t_final) > 0 else None
+    frac_of_region = (n_launches * us * 1e-6) / (t_updates + t_final) if (t_updates + t_final) > 0 else None
     roofline = {"bound": "mfma", "kernel": "gram_partial_kernel<true>", "achieved": round(ach_tf, 2),
                 "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach_tf / PEAK_F32_MFMA_TFLOPS, 4),
-                "traffic": traffic, "traffic_source": "profiles/gram_pmc_latest.json (rocprofv3 --pmc FETCH_SIZE, x2)",
+                "traffic": traffic, "traffic_source": "profiles/gram_pmc_latest.json (rocprofv3 --pmc: FETCH_SIZE x2 + WRITE_SIZE)",
                 "traffic_note": traffic_note,
-                "avg_launch_us": round(us, 2), "rows_per_launch": rows_l, "launches_in_timed_region": n_blocks,
+                "avg_launch_us": round(us, 2), "rows_per_launch": rows_l, "launches_in_timed_region": n_launches,
                 "share_of_timed_region": None if frac_of_region is None else round(frac_of_region, 3),
                 "algorithmic_flops_per_launch": flops, "algorithmic_bytes_per_launch": bytes_,
                 "hbm_achieved_GBs": round(ach_gbs, 1), "hbm_frac_of_8TBs": round(ach_gbs / PEAK_HBM_GBS, 4),
@@ -261,7 +273,7 @@ def main():
                 run(e2, K)
                 torch.cuda.synchronize()
                 job = time.perf_counter() - t0
-                us_p, rt = gram_kernel_us(lib, _lib, e2, blocks[0])
+                us_p, rt = gram_kernel_us(lib, _lib, e2, blocks[0])      # split-bf16 launches stay at one block (no float64 carry)
                 mfma_tf = nprod * rt * D * (D + 1) / (us_p * 1e-6) / 1e12
                 gbs = rt * D * 4 / (us_p * 1e-6) / 1e9
                 split[prec] = {"samples_per_s": round(n_blocks * NB / job, 1), "gram_launch_us": round(us_p, 2),

@@ -170,33 +170,42 @@ __global__ __launch_bounds__(1024) void chol_blocked_kernel(const double *__rest
             dbg_t = t;
         }
         if (rem <= 0) break;
-        // ---- (b) panel: P[i][c2] = sum_{t <= i} Es[i][t] H[j0 + t][c2] ----
-        double acc[3];
-        const int npanel = 32 * rem;
+        // ---- (b) panel: P[i][c2] = sum_t Es[i][t] H[j0 + t][c2]; 4 x 4 register tiles (8 LDS reads per 16 FMAs:
+        //      with one output per thread these small products were LDS-bandwidth bound) ----
+        const int ntc = rem >> 2;                       // tile columns
+        const bool ptile = tid < 8 * ntc;
+        const int pti = ptile ? tid / ntc : 0, ptc = ptile ? tid - pti * ntc : 0;
+        double pacc[4][4];
 #pragma unroll
-        for (int w = 0; w < 3; ++w) {
-            const int idx = tid + 1024 * w;
-            acc[w] = 0.0;
-            if (idx < npanel) {
-                const int i = idx / rem, c2 = j1 + (idx - i * rem);
-                double a0 = 0.0, a1 = 0.0;
-#pragma unroll 8
-                for (int t = 0; t < 32; t += 2) {
-                    a0 += Es[i * 33 + t] * Hs[(j0 + t) * kCholLd + c2];
-                    a1 += Es[i * 33 + t + 1] * Hs[(j0 + t + 1) * kCholLd + c2];
-                }
-                acc[w] = a0 + a1;
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) pacc[u][v] = 0.0;
+        if (ptile) {
+            const double *er = Es + (4 * pti) * 33;
+            const double *hc = Hs + j0 * kCholLd + j1 + 4 * ptc;
+#pragma unroll 4
+            for (int t = 0; t < 32; ++t) {
+                double a[4], b[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) a[u] = er[u * 33 + t];
+#pragma unroll
+                for (int v = 0; v < 4; ++v) b[v] = hc[t * kCholLd + v];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) pacc[u][v] += a[u] * b[v];
             }
         }
         __syncthreads();
+        if (ptile) {
 #pragma unroll
-        for (int w = 0; w < 3; ++w) {
-            const int idx = tid + 1024 * w;
-            if (idx < npanel) {
-                const int i = idx / rem, c2 = j1 + (idx - i * rem);
-                Hs[(j0 + i) * kCholLd + c2] = acc[w];
-                if (j0 + i < p && c2 < p) Rm[(int64_t)(j0 + i) * ldr + c2] = acc[w];
-            }
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int i = 4 * pti + u, c2 = j1 + 4 * ptc + v;
+                    Hs[(j0 + i) * kCholLd + c2] = pacc[u][v];
+                    if (j0 + i < p && c2 < p) Rm[(int64_t)(j0 + i) * ldr + c2] = pacc[u][v];
+                }
         }
         __syncthreads();
         if (debug) {
@@ -204,18 +213,34 @@ __global__ __launch_bounds__(1024) void chol_blocked_kernel(const double *__rest
             dbg_panel += t - dbg_t;
             dbg_t = t;
         }
-        // ---- (c) trailing update, upper part: H[r2][c2] -= sum_t R[j0 + t][r2] R[j0 + t][c2] ----
-        const int ntrail = rem * rem;
-        for (int idx = tid; idx < ntrail; idx += 1024) {
-            const int i = idx / rem, r2 = j1 + i, c2 = j1 + (idx - i * rem);
-            if (c2 >= r2) {
-                double a0 = 0.0, a1 = 0.0;
-#pragma unroll 8
-                for (int t = 0; t < 32; t += 2) {
-                    a0 += Hs[(j0 + t) * kCholLd + r2] * Hs[(j0 + t) * kCholLd + c2];
-                    a1 += Hs[(j0 + t + 1) * kCholLd + r2] * Hs[(j0 + t + 1) * kCholLd + c2];
+        // ---- (c) trailing update, upper tiles: H[r2][c2] -= sum_t R[j0 + t][r2] R[j0 + t][c2] (4 x 4 register tiles;
+        //      tiles on the diagonal also touch their lower half, which nothing reads) ----
+        {
+            const int ttr = tid / ntc, ttc = tid - ttr * ntc;
+            if (ttr < ntc && ttc >= ttr) {
+                const double *hr = Hs + j0 * kCholLd + j1 + 4 * ttr;
+                const double *hc = Hs + j0 * kCholLd + j1 + 4 * ttc;
+                double tacc[4][4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) tacc[u][v] = 0.0;
+#pragma unroll 4
+                for (int t = 0; t < 32; ++t) {
+                    double a[4], b[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) a[u] = hr[t * kCholLd + u];
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) b[v] = hc[t * kCholLd + v];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) tacc[u][v] += a[u] * b[v];
                 }
-                Hs[r2 * kCholLd + c2] -= a0 + a1;
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) Hs[(j1 + 4 * ttr + u) * kCholLd + j1 + 4 * ttc + v] -= tacc[u][v];
             }
         }
         __syncthreads();

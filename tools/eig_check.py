@@ -43,7 +43,7 @@ for p in (128, 96, 64):
     print(f"jacobi_small near-diagonal p={p}: sweeps={sw}", timeit(lambda: ops.jacobi_small(Bn)), flush=True)
 
 import bench
-blocks, _ = bench.make_blocks(12, dev)
+blocks, _, _ = bench.make_blocks(15, dev)
 for mode in ("exact", "faithful"):
     for rep in range(3):
         est = IPCAEstimator(80, mode)

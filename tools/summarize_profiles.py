@@ -8,6 +8,7 @@ import os
 import sys
 
 root = sys.argv[1]
+PROBE_ROWS = int(os.environ.get("GS_PROBE_ROWS", "50000"))
 print(f"# rocprofv3 summary ({root})\n")
 ks = os.path.join(root, "bench_trace", "b_kernel_stats.csv")
 if os.path.exists(ks):
@@ -17,7 +18,7 @@ if os.path.exists(ks):
         name = r["Name"].split("(")[0].replace("void ", "")[-60:]
         print(f"| `{name}` | {r['Calls']} | {int(r['TotalDurationNs'])/1e3:.1f} | {float(r['AverageNs'])/1e3:.2f} | {float(r['Percentage']):.2f} |")
     print()
-print("## PMC passes on `tools/gram_probe.py` (10 000 x 512 float32 block), averages per launch\n")
+print(f"## PMC passes on `tools/gram_probe.py` ({PROBE_ROWS} x 512 float32 rows per launch), averages per launch\n")
 print("| kernel | counter | avg per launch | launches |\n|---|---|---|---|")
 for sub in ("pmc_FETCH_SIZE", "pmc_WRITE_SIZE", "pmc_sq", "pmc_lds"):
     p = os.path.join(root, sub, "p_counter_collection.csv")
@@ -57,17 +58,21 @@ if len(sys.argv) > 2:
             vals[c] = (sum(x) / len(x), len(x))
     fetch = vals.get("FETCH_SIZE", (0, 0))
     write = vals.get("WRITE_SIZE", (0, 0))
+    alg = PROBE_ROWS * 512 * 4
+    rd, wr = int(fetch[0] * 2 * 1024), int(write[0] * 1024)
     out = {
-        "kernel": "gram_partial_kernel<true>", "rows_per_launch": 10000, "launches": fetch[1],
+        "kernel": "gram_partial_kernel", "rows_per_launch": PROBE_ROWS, "launches": fetch[1],
         "FETCH_SIZE_KiB_raw": round(fetch[0], 1),
-        "hbm_read_bytes_per_launch_corrected_x2": int(fetch[0] * 2 * 1024),
-        "WRITE_SIZE_KiB_raw": round(write[0], 1), "hbm_write_bytes_per_launch": int(write[0] * 1024),
+        "hbm_read_bytes_per_launch_corrected_x2": rd,
+        "WRITE_SIZE_KiB_raw": round(write[0], 1), "hbm_write_bytes_per_launch": wr,
+        "hbm_bytes_per_launch": rd + wr, "algorithmic_bytes_per_launch": alg,
+        "traffic_over_algorithmic": round((rd + wr) / alg, 3),
         "note": "rocprofv3 --pmc passes on tools/gram_probe.py (separate passes per counter group; the probe launches "
                 "include the piggy-backed fold workgroups); FETCH_SIZE doubled per MI355X_MICROARCH.md HBM section",
         "source": sys.argv[2],
-        "traffic_breakdown": "%.1f MB per launch = 20.5 MB of X rows (each fetched once: algorithmic 20.48 MB) + the "
-                             "piggy-backed fold's reads of the previous block's float32 slabs (%.1f MB written per "
-                             "launch, partly still L2/MALL-resident)" % (fetch[0] * 2 * 1024 / 1e6, write[0] * 1024 / 1e6),
+        "traffic_breakdown": "%.1f MB read + %.1f MB written per launch against %.1f MB of X rows (algorithmic): the rows are "
+                             "fetched once; the rest is the float32 partial-Gram slabs (written by this launch, read back by "
+                             "the fold workgroups of the next one)" % (rd / 1e6, wr / 1e6, alg / 1e6),
     }
     for c in ("SQ_VALU_MFMA_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_BUSY_CYCLES"):
         if c in vals:
