@@ -82,7 +82,7 @@ __device__ __forceinline__ double sum8(double v) {
 // (32 x 32 row-major blocks), rdiag[j] = R_jj (0 = dead).
 constexpr int kCholP = 128;
 constexpr int kCholLd = 129;
-constexpr size_t kCholLdsBytes = sizeof(double) * ((size_t)kCholP * kCholLd + 32 * 33 + 64 + 64 + kCholP);
+constexpr size_t kCholLdsBytes = sizeof(double) * ((size_t)kCholP * kCholLd + 32 * 33 + 128 + 128 + kCholP);
 __global__ __launch_bounds__(1024) void chol_blocked_kernel(const double *__restrict__ H, int64_t ldh, int p,
                                                              double *__restrict__ Rm, int64_t ldr,
                                                              double *__restrict__ Dinv, double *__restrict__ rdiag,
@@ -92,9 +92,9 @@ __global__ __launch_bounds__(1024) void chol_blocked_kernel(const double *__rest
     long long dbg_leaf = 0, dbg_panel = 0, dbg_trail = 0;
     double *Hs = csm;                            // [128][129]
     double *Es = Hs + kCholP * kCholLd;          // [32][33]   R_JJ^-T of the current block (lower triangular)
-    double *rowL = Es + 32 * 33;                 // [2][32]    published pivot row, matrix half
-    double *rowE = rowL + 64;                    // [2][32]    ... identity half
-    double *refd = rowE + 64;                    // [128]      original diagonal
+    double *rowL = Es + 32 * 33;                 // [2][2][32] published pivot rows (two per step), matrix half
+    double *rowE = rowL + 128;                   // [2][2][32] ... identity half
+    double *refd = rowE + 128;                   // [128]      original diagonal
     const int tid = threadIdx.x, r = tid >> 5, c = tid & 31;
     const int nblk = (p + 31) >> 5, pend = nblk * 32;
     for (int e = tid; e < pend * pend; e += 1024) {
@@ -118,34 +118,48 @@ __global__ __launch_bounds__(1024) void chol_blocked_kernel(const double *__rest
             h[i] = (rw <= c) ? Hs[(j0 + rw) * kCholLd + j0 + c] : Hs[(j0 + c) * kCholLd + j0 + rw];
             e[i] = (rw == c) ? 1.0 : 0.0;
         }
-        for (int j = 0; j < 32; ++j) {
-            double *rl = rowL + (j & 1) * 32, *re = rowE + (j & 1) * 32;
-            if (leaf && ry == (j & 7)) {
+        // TWO pivots per barrier: rows j and j + 1 are published as they stand; every thread redoes the 2 x 2 pivot
+        // arithmetic (row j + 1 after the elimination of row j) for the columns it needs - the step is a latency
+        // chain (LDS write -> barrier -> LDS read -> rsqrt -> fma), so halving the barriers nearly halves the time.
+        for (int j = 0; j < 32; j += 2) {
+            const int sel = (j >> 1) & 1;
+            double *r0h = rowL + sel * 64, *r1h = r0h + 32;        // published rows j, j + 1: matrix half
+            double *r0e = rowE + sel * 64, *r1e = r0e + 32;        //                           identity half
+            if (leaf && (ry == (j & 7) || ry == ((j + 1) & 7))) {
                 const int ij = j >> 3;
+                const bool second = ry == ((j + 1) & 7);
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
                     if (i == ij) {
-                        rl[c] = h[i];
-                        re[c] = e[i];
+                        (second ? r1h : r0h)[c] = h[i];
+                        (second ? r1e : r0e)[c] = e[i];
                     }
             }
             __syncthreads();
             if (leaf) {
-                const double d = rl[j];
-                const bool dead = !(d > refd[j0 + j] * 1e-13);
-                const double inv = dead ? 0.0 : rsqrt64(d);
-                const double inv2 = inv * inv;
-                const double hc = rl[c], ec = re[c];
+                const double d0 = r0h[j];
+                const bool dead0 = !(d0 > refd[j0 + j] * 1e-13);
+                const double inv0 = dead0 ? 0.0 : rsqrt64(d0);
+                const double m = r0h[j + 1] * inv0;                // R[j][j+1]
+                const double d1 = r1h[j + 1] - m * m;               // pivot j + 1 after eliminating row j
+                const bool dead1 = !(d1 > refd[j0 + j + 1] * 1e-13);
+                const double inv1 = dead1 ? 0.0 : rsqrt64(d1);
+                const double Rjc = r0h[c] * inv0, Ejc = r0e[c] * inv0;                     // row j of R / R^-T at column c
+                const double Rkc = (r1h[c] - m * Rjc) * inv1, Ekc = (r1e[c] - m * Ejc) * inv1;   // row j + 1
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int rw = ry + 8 * i;
-                    if (rw > j) {
-                        const double f = rl[rw] * inv2;
-                        h[i] -= f * hc;
-                        e[i] -= f * ec;
+                    if (rw > j + 1) {
+                        const double f0 = r0h[rw] * inv0;                                  // R[j][rw]
+                        const double f1 = (r1h[rw] - m * f0) * inv1;                       // R[j+1][rw]
+                        h[i] -= f0 * Rjc + f1 * Rkc;
+                        e[i] -= f0 * Ejc + f1 * Ekc;
                     } else if (rw == j) {
-                        h[i] *= inv;
-                        e[i] *= inv;
+                        h[i] = Rjc;
+                        e[i] = Ejc;
+                    } else if (rw == j + 1) {
+                        h[i] = Rkc;
+                        e[i] = Ekc;
                     }
                 }
             }
