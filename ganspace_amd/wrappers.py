@@ -17,6 +17,15 @@ with the layer names, shapes and call order the reference wrappers rely on (SURV
 ``sample_latent`` reproduces the reference's seeding protocol exactly
 (wrappers.py:167-179, 562-569): one ``np.random.randint(int32.max)`` from the
 GLOBAL legacy NumPy stream per call, then a private ``RandomState(seed)``.
+
+What restates the reference surface statement by statement (BASELINE.json:north_star mandates "Keep the
+models/wrappers.py BaseModel surface"; none of it is arithmetic on the hot path): the ``BaseModel`` abstract
+class incl. ``sample_np`` (reference :27-94), ``BigGAN.partial_forward`` (:611-648) and the factories
+``get_model`` / ``get_instrumented_model`` (:651-735) - same method names, argument order, local-variable
+meaning and error strings, because callers (``decomposition.py``, ``interactive.py``, ``visualize.py``, the
+notebooks) depend on them.  Everything else in this file - the synthetic generators, ``MappingNetwork`` /
+``HipLinear`` on the HIP kernels, the ``z_spec`` / ``latent_from_z`` plumbing for parallel z generation, the
+stage-generator form of ``StyleGAN2.partial_forward`` - is this repository's own design.
 """
 from __future__ import annotations
 
