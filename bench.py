@@ -290,21 +290,33 @@ def main():
     if extras and not args.no_wide:
         wide = {}
         for name, dd in (("cfg3_shape_d32768", 32768), ("cfg5_shape_d131072", 131072)):
-            g = torch.Generator(device=dev).manual_seed(7)
-            A = torch.randn(128, dd, device=dev, generator=g) * (1.03 ** -torch.arange(128, device=dev))[:, None]
-            e = IPCAEstimator(K_COMP, "faithful")
-            ts = []
-            for i in range(4):
-                X = torch.randn(2000, 128, device=dev, generator=g) @ A + 0.05 * torch.randn(2000, dd, device=dev, generator=g) + 0.3
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                e.fit_partial(X)
-                torch.cuda.synchronize()
-                ts.append(time.perf_counter() - t0)
-            steady = sum(ts[1:]) / len(ts[1:])
-            wide[name] = {"block_rows": 2000, "ms_per_block": round(steady * 1e3, 2),
-                          "samples_per_s": round(2000 / steady, 1), "mode": "ipca (small-side, sklearn-faithful)"}
-            del e, A
+            entry = {"block_rows": 2000, "mode": "ipca (small-side, sklearn-faithful)"}
+            for prec in ("f32", "bf16x6"):
+                g = torch.Generator(device=dev).manual_seed(7)
+                A = torch.randn(128, dd, device=dev, generator=g) * (1.03 ** -torch.arange(128, device=dev))[:, None]
+                e = IPCAEstimator(K_COMP, "faithful", precision=prec)
+                ts = []
+                for i in range(4):
+                    X = torch.randn(2000, 128, device=dev, generator=g) @ A + 0.05 * torch.randn(2000, dd, device=dev, generator=g) + 0.3
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    e.fit_partial(X)
+                    torch.cuda.synchronize()
+                    ts.append(time.perf_counter() - t0)
+                steady = sum(ts[1:]) / len(ts[1:])
+                # algorithmic work of a block: 2 d (m + 2k) flop per sample
+                flops = 2000 * 2.0 * dd * (2000 + 2 * K_COMP)
+                entry[prec] = {"ms_per_block": round(steady * 1e3, 2), "samples_per_s": round(2000 / steady, 1),
+                               "useful_TFLOPs": round(flops / steady / 1e12, 1)}
+                if prec == "f32":
+                    comp_ref = e.get_components()[0].copy()
+                else:
+                    c = np.abs(np.sum(e.get_components()[0].astype(np.float64) * comp_ref.astype(np.float64), axis=1))
+                    entry[prec]["top20_min_abs_cos_vs_f32_contraction"] = round(float(c[:20].min()), 7)
+                del e, A
+            entry["ms_per_block"] = entry["f32"]["ms_per_block"]
+            entry["samples_per_s"] = entry["f32"]["samples_per_s"]
+            wide[name] = entry
         out["wide_feature_shapes"] = wide
 
     if rank == 0:

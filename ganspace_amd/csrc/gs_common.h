@@ -153,6 +153,7 @@ int eigh_topk_cheb(SubspaceWorkspace &ws, const double *A, int n, int64_t lda, i
 struct SmallSide {
     int64_t d = 0;
     int k = 0, m_cap = 0, r_cap = 0, rp = 0, kp = 0, nsplit = 0;
+    int precision = 0;       // GS_PREC_*: contraction of T = M M^T (f32 MFMA, or split-bf16 MFMA)
     float *M = nullptr;      // [rp][d]  stacked matrix
     double *T = nullptr;     // [rp][rp] M M^T, then its Jacobi-rotated columns
     double *slab = nullptr;  // [nsplit][rp][rp]

@@ -381,8 +381,6 @@ int gs_ipca_create(int64_t d, int k, int mode, int precision, int device, gs_ipc
                "gs_ipca_create: bad mode");
     GS_REQUIRE(precision == GS_PREC_F32 || precision == GS_PREC_BF16X3 || precision == GS_PREC_BF16X6, GS_ENOTIMPL,
                "gs_ipca_create: unknown precision (GS_PREC_F32 / GS_PREC_BF16X3 / GS_PREC_BF16X6)");
-    GS_REQUIRE(precision == GS_PREC_F32 || mode != GS_MODE_SMALLSIDE, GS_ENOTIMPL,
-               "gs_ipca_create: the split-bf16 contraction is implemented for the Gram-side modes only");
     if (mode == GS_MODE_SMALLSIDE) {
         GS_REQUIRE(d >= 4 && d <= ((int64_t)1 << 21), GS_EINVAL, "gs_ipca_create: feature dim out of range");
         GS_REQUIRE(d % 4 == 0, GS_ENOTIMPL, "gs_ipca_create: small-side mode needs feat_dim % 4 == 0");
@@ -502,6 +500,7 @@ int gs_ipca_update(gs_ipca_t *h, const float *X, int64_t rows, int64_t ld, void 
                    "small-side mode supports n_components + rows + 1 <= 4096 per block");
         if (h->ss.M == nullptr || rows > h->ss.m_cap) {
             GS_HIP_CHECK(hipStreamSynchronize(stream));
+            h->ss.precision = h->prec;
             int rc = smallside_alloc(h->ss, h->d, h->k, (int)rows);
             if (rc != GS_OK) return rc;
         }

@@ -145,17 +145,186 @@ __global__ __launch_bounds__(256, 1) void rowgram_kernel(const float *__restrict
     }
 }
 
+// ---- the same partial products on the bf16 matrix cores (opt-in: GS_PREC_BF16X6 / GS_PREC_BF16X3) -----------------
+// v_mfma_f32_32x32x16_bf16 wants 8 CONSECUTIVE k per lane for a fixed row of either operand - and both operands of
+// M M^T are rows of the row-major M, K-contiguous: no transpose anywhere (unlike X^T X, gs_gram_bf16.hip).  A thread
+// loads 8 consecutive floats of a row (two 16-byte loads; four threads cover a 128-byte line), splits them into
+// bf16 planes  x = hi + mid (+ lo)  (each remainder exact in float32) and writes one 16-byte vector per plane into
+// the LDS image [plane][panel][row][32 k as bf16 = 64 B, padded to 80 B] (conflict-free 16-lane groups for both
+// ds_write_b128 and the ds_read_b128 fragment reads).  Products as in gs_gram_bf16.hip: six MFMAs rebuild x*y to
+// 2^-24 |xy| (float32 class), three to 2^-16.  4 waves x (64 x 64), float32 accumulation with the float64 carry
+// every 1024 columns, float64 slabs - same decomposition and output as rowgram_kernel at 6/16 resp. 3/16 of its
+// matrix-pipe time.
+using bf16x8s = __attribute__((ext_vector_type(8))) __bf16;
+using f32x2s = __attribute__((ext_vector_type(2))) float;
+using bf16x2s = __attribute__((ext_vector_type(2))) __bf16;
+constexpr int kRowBytes = 80;                       // 32 bf16 (64 B) + 16 B pad per row and stage
+constexpr int kPanelB = kRT * kRowBytes;            // one panel, one plane, one stage
+
+template <int NPL>
+__device__ __forceinline__ void split8s(const float4 &lo4, const float4 &hi4, uint4 (&planes)[NPL]) {
+    float rem[8] = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
+#pragma unroll
+    for (int p = 0; p < NPL; ++p) {
+        unsigned w[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x2s pr = {rem[2 * q], rem[2 * q + 1]};
+            const unsigned u = __builtin_bit_cast(unsigned, __builtin_convertvector(pr, bf16x2s));
+            w[q] = u;
+            if (p + 1 < NPL) {
+                rem[2 * q] -= __uint_as_float(u << 16);
+                rem[2 * q + 1] -= __uint_as_float(u & 0xFFFF0000u);
+            }
+        }
+        planes[p] = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+}
+
+template <int NPROD>
+__global__ __launch_bounds__(256, 1) void rowgram_bf16_kernel(const float *__restrict__ M, int64_t d, int64_t ldm,
+                                                              double *__restrict__ slab, int rp, int nmt, int T,
+                                                              int64_t kchunk) {
+    constexpr int NPL = (NPROD == 3) ? 2 : 3;
+    constexpr int kStage = NPL * 2 * kPanelB;            // [plane][panel A|B][128 rows][80 B]
+    extern __shared__ __attribute__((aligned(16))) unsigned char rlds[];   // two stages
+    const int split = blockIdx.x / nmt;
+    int I, J;
+    decode_upper2(blockIdx.x % nmt, T, I, J);
+    const bool diag = (I == J);
+    const int64_t k_begin = (int64_t)split * kchunk;
+    const int64_t k_end = (k_begin + kchunk < d) ? k_begin + kchunk : d;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wi = wave >> 1, wj = wave & 1;
+    const float *Ma = M + (int64_t)I * kRT * ldm;
+    const float *Mb = M + (int64_t)J * kRT * ldm;
+
+    // staging: item = (row, group of 8 columns); 512 items per panel and stage, two per thread
+    float4 ra[2][2], rb[2][2];
+    auto fetch = [&](int64_t k0) {
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const int item = tid + 256 * g, row = item >> 2, kg = item & 3;
+            const int64_t kk = k0 + kg * 8;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int64_t kc = kk + 4 * h;
+                const bool ok = kc < k_end;               // d % 4 == 0: a float4 is valid or not as a whole
+                const int64_t ks = ok ? kc : k_begin;
+                float4 va = *reinterpret_cast<const float4 *>(Ma + (int64_t)row * ldm + ks);
+                float4 vb = diag ? va : *reinterpret_cast<const float4 *>(Mb + (int64_t)row * ldm + ks);
+                if (!ok) {
+                    va = make_float4(0.f, 0.f, 0.f, 0.f);
+                    vb = va;
+                }
+                ra[g][h] = va;
+                rb[g][h] = vb;
+            }
+        }
+    };
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const int item = tid + 256 * g, row = item >> 2, kg = item & 3;
+            unsigned char *dst = rlds + buf * kStage + row * kRowBytes + kg * 16;
+            uint4 pl[NPL];
+            split8s<NPL>(ra[g][0], ra[g][1], pl);
+#pragma unroll
+            for (int p = 0; p < NPL; ++p) *reinterpret_cast<uint4 *>(dst + p * 2 * kPanelB) = pl[p];
+            if (!diag) {
+                split8s<NPL>(rb[g][0], rb[g][1], pl);
+#pragma unroll
+                for (int p = 0; p < NPL; ++p) *reinterpret_cast<uint4 *>(dst + p * 2 * kPanelB + kPanelB) = pl[p];
+            }
+        }
+    };
+
+    f32x16 acc[2][2] = {{{0}, {0}}, {{0}, {0}}};
+    double acc64[2][2][16];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc64[a][b][r] = 0.0;
+    const int fragA = (wi * 64 + (lane & 31)) * kRowBytes + (lane >> 5) * 16;
+    const int fragB = (diag ? 0 : kPanelB) + (wj * 64 + (lane & 31)) * kRowBytes + (lane >> 5) * 16;
+    auto mma_step = [&](int buf, int ks) {
+        const unsigned char *base = rlds + buf * kStage + ks * 32;
+        bf16x8s A[NPL][2], B[NPL][2];
+#pragma unroll
+        for (int p = 0; p < NPL; ++p)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                A[p][q] = *reinterpret_cast<const bf16x8s *>(base + p * 2 * kPanelB + fragA + q * 32 * kRowBytes);
+                B[p][q] = *reinterpret_cast<const bf16x8s *>(base + p * 2 * kPanelB + fragB + q * 32 * kRowBytes);
+            }
+        // plane 0 = leading bf16 term, 1 = second, 2 = third; smallest products first
+        constexpr int PA6[6] = {1, 0, 2, 1, 0, 0}, PB6[6] = {1, 2, 0, 0, 1, 0};
+        constexpr int PA3[3] = {1, 0, 0}, PB3[3] = {0, 1, 0};
+#pragma unroll
+        for (int t = 0; t < NPROD; ++t) {
+            const int pa = (NPROD == 3) ? PA3[t % 3] : PA6[t];
+            const int pb = (NPROD == 3) ? PB3[t % 3] : PB6[t];
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[pa][a], B[pb][b], acc[a][b], 0, 0, 0);
+        }
+    };
+
+    const int nst = (int)((k_end - k_begin + kRK - 1) / kRK);
+    if (nst > 0) {
+        fetch(k_begin);
+        stash(0);
+    }
+    __syncthreads();
+    for (int s = 0; s < nst; ++s) {
+        const int buf = s & 1;
+        if (s + 1 < nst) fetch(k_begin + (int64_t)(s + 1) * kRK);
+        mma_step(buf, 0);
+        mma_step(buf, 1);
+        if ((s + 1) % kFlushStages == 0 || s + 1 == nst) {
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        acc64[a][b][r] += (double)acc[a][b][r];
+                        acc[a][b][r] = 0.f;
+                    }
+        }
+        if (s + 1 < nst) stash(buf ^ 1);
+        __syncthreads();
+    }
+    double *out = slab + (int64_t)split * rp * rp;
+    const int row_base = I * kRT + wi * 64 + 4 * (lane >> 5);
+    const int col_base = J * kRT + wj * 64 + (lane & 31);
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = row_base + 32 * a + (r & 3) + 8 * (r >> 2);
+                out[(int64_t)row * rp + col_base + 32 * b] = acc64[a][b][r];
+            }
+}
+
 // T (full symmetric, leading dim rp) = sum over splits of the upper macro tiles
 __global__ void rowgram_fold_kernel(const double *__restrict__ slab, double *__restrict__ Tm, int rp,
                                     int nsplit) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     const int i = blockIdx.y;
     if (j >= rp) return;
-    if ((i / kRT) > (j / kRT)) return;  // lower macro tiles are filled by mirroring
+    if (i > j) return;  // the lower triangle is filled by mirroring: T is exactly symmetric whatever the order
+                        // of the products inside a diagonal macro tile (split-bf16 contraction: hi*mid before mid*hi)
     double s = 0.0;
     for (int c = 0; c < nsplit; ++c) s += slab[(int64_t)c * rp * rp + (int64_t)i * rp + j];
     Tm[(int64_t)i * rp + j] = s;
-    if ((i / kRT) < (j / kRT)) Tm[(int64_t)j * rp + i] = s;
+    if (i < j) Tm[(int64_t)j * rp + i] = s;
 }
 
 // ---- out[kp x d] = Ct^T M   (Ct: [rp x kp] t-major coefficients, M: [rp x d]) -----------------------
@@ -379,14 +548,34 @@ __global__ __launch_bounds__(1024) void ss_sign_kernel(const float *__restrict__
 
 // ---- host orchestration ---------------------------------------------------------------------------------
 int smallside_alloc(SmallSide &ss, int64_t d, int k, int m) {
+    const int precision = ss.precision;
     smallside_free(ss);
+    ss.precision = precision;
     ss.d = d;
     ss.k = k;
     ss.m_cap = m;
     ss.r_cap = k + m + 1;
     ss.rp = (int)round_up(ss.r_cap, kRT);
     ss.kp = (int)round_up(k, kRT);
-    ss.nsplit = 4;
+    // split of the feature range over workgroups: the launch (macro tiles x splits) should fill whole rounds of the
+    // resident workgroups (f32 kernel: two per CU, split-bf16: one) - 153 tiles x 4 splits = 612 workgroups on 512
+    // slots was two rounds at 60 %
+    {
+        const int Tt = (int)ceil_div(ss.r_cap, kRT), nmt = Tt * (Tt + 1) / 2;
+        const int slots = (ss.precision == GS_PREC_F32) ? 512 : 256;
+        int best = 4;
+        double best_eff = 0.0;
+        for (int ns = 3; ns <= 12; ++ns) {
+            if ((int64_t)ns * 4096 > d) break;             // keep at least 4096 columns per workgroup
+            const int64_t wgs = (int64_t)nmt * ns;
+            const double eff = (double)wgs / (double)(ceil_div(wgs, slots) * slots);
+            if (eff > best_eff + 1e-9) {
+                best_eff = eff;
+                best = ns;
+            }
+        }
+        ss.nsplit = best;
+    }
     auto alloc = [&](void **p, size_t bytes) -> int {
         if (hipMalloc(p, bytes) != hipSuccess) {
             set_error("smallside: hipMalloc failed");
@@ -441,8 +630,30 @@ int smallside_update(SmallSide &ss, const float *X, int64_t rows, int64_t ldx, d
     // 4. T = M M^T
     const int Tt = (int)ceil_div(r, kRT), nmt = Tt * (Tt + 1) / 2;
     const int64_t kchunk = round_up(ceil_div(d, ss.nsplit), kRK);
-    hipLaunchKernelGGL(rowgram_kernel, dim3((unsigned)(nmt * ss.nsplit)), dim3(256), 0, stream, ss.M, d, d, ss.slab,
-                       rp, nmt, Tt, kchunk);
+    if (ss.precision == GS_PREC_F32) {
+        hipLaunchKernelGGL(rowgram_kernel, dim3((unsigned)(nmt * ss.nsplit)), dim3(256), 0, stream, ss.M, d, d, ss.slab,
+                           rp, nmt, Tt, kchunk);
+    } else {
+        const bool x6 = ss.precision == GS_PREC_BF16X6;
+        const size_t lds = (size_t)2 * (x6 ? 3 : 2) * 2 * kPanelB;
+        static bool attr6 = false, attr3 = false;
+        if (x6 && !attr6) {
+            GS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(rowgram_bf16_kernel<6>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr6 = true;
+        }
+        if (!x6 && !attr3) {
+            GS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(rowgram_bf16_kernel<3>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr3 = true;
+        }
+        if (x6)
+            hipLaunchKernelGGL(rowgram_bf16_kernel<6>, dim3((unsigned)(nmt * ss.nsplit)), dim3(256), lds, stream, ss.M, d,
+                               d, ss.slab, rp, nmt, Tt, kchunk);
+        else
+            hipLaunchKernelGGL(rowgram_bf16_kernel<3>, dim3((unsigned)(nmt * ss.nsplit)), dim3(256), lds, stream, ss.M, d,
+                               d, ss.slab, rp, nmt, Tt, kchunk);
+    }
     const int rused = Tt * kRT;
     hipLaunchKernelGGL(rowgram_fold_kernel, dim3((unsigned)ceil_div(rused, 256), (unsigned)rused), dim3(256), 0,
                        stream, ss.slab, ss.T, rp, ss.nsplit);

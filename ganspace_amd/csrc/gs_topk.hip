@@ -703,12 +703,18 @@ int eigh_topk_cheb(SubspaceWorkspace &ws, const double *A, int n, int64_t lda, i
     if (warm) {
         hipLaunchKernelGGL(topk_seed_kernel, dim3((unsigned)ceil_div(k0, 64), (unsigned)n), b64, 0, stream, buf[1], n, ld,
                            V0, k0, ldv0);
-        if (ws.reuse_guards && ws.guards_valid && ws.guards_n == n && ws.guards_p == p && k0 < p)
+        const bool prev_basis = ws.reuse_guards && ws.guards_valid && ws.guards_n == n && ws.guards_p == p && k0 < p;
+        if (prev_basis) {
+            // [previous components | previous guard Ritz vectors] is the previous solve's Ritz basis up to signs:
+            // orthonormal already, the estimate cycle below re-orthonormalises A times it anyway
             hipLaunchKernelGGL(topk_copycols_kernel, dim3((unsigned)ceil_div(p - k0, 64), (unsigned)n), b64, 0, stream,
                                buf[1], ws.G, ld, k0, p);
-        int rc = orth_fast(ws, buf[1], buf[0], n, p, stream);
-        if (rc != GS_OK) return rc;
-        q = 0;
+            q = 1;
+        } else {
+            int rc = orth_fast(ws, buf[1], buf[0], n, p, stream);
+            if (rc != GS_OK) return rc;
+            q = 0;
+        }
     } else {
         q = 1;                      // a uniform random block is well conditioned: no orthonormalisation needed
     }

@@ -62,7 +62,8 @@ enum { GS_MODE_EXACT = 0, GS_MODE_FAITHFUL = 1, GS_MODE_SMALLSIDE = 2 };
  *                 at 6/16 of the f32-MFMA time.
  * GS_PREC_BF16X3  two bf16 terms, three MFMAs: dropped terms <= 2^-16 |xy| with random sign
  *                 (averaging out over the rows of a block); 3/16 of the f32-MFMA time.
- * The split modes exist for the Gram-side modes (EXACT / FAITHFUL).                        */
+ * In GS_MODE_SMALLSIDE the precision selects the contraction of T = M M^T (both operands are K-contiguous rows of
+ * M: the split needs no transpose there).                                                   */
 enum { GS_PREC_F32 = 0, GS_PREC_BF16X3 = 1, GS_PREC_BF16X6 = 2 };
 
 typedef struct gs_ipca gs_ipca_t;

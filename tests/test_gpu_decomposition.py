@@ -190,16 +190,19 @@ def test_cfg5_conv_features_small_side(dev):
     inst.close()
 
 
-def test_cfg5_conv_features_d131072(dev):
+@pytest.mark.parametrize("precision", ["f32", "bf16x6"])
+def test_cfg5_conv_features_d131072(dev, precision):
     """BASELINE config 5 at its own feature dimension: StyleGAN2 ``convs.2`` activations are 512 x 16 x 16 =
     131 072 features (r = k + rows + 1 rows of the stacked matrix, 1 GB per 2000-row block at full NB; small blocks
     here so that the float64 SVD oracle stays affordable).  Same hooked activations to the device estimator and to the
     CPU oracle of sklearn's stacked-SVD recurrence (_incremental_pca.py:347-378)."""
     from ganspace_amd.estimators import get_estimator
     from ganspace_amd.wrappers import get_instrumented_model
+    from ganspace_amd.estimators import IPCAEstimator
     inst = get_instrumented_model("StyleGAN2", "cat", "convs.2", dev)
     model = inst.model
-    est = get_estimator("ipca", 8, 1.0)
+    # 'ipca' picks the small-side recurrence by itself for d > 8192; precision = contraction of T = M M^T
+    est = get_estimator("ipca", 8, 1.0) if precision == "f32" else IPCAEstimator(8, "faithful", precision=precision)
     orc = O.IPCAEstimatorOracle(8, "svd")
     np.random.seed(6)
     with torch.no_grad():

@@ -175,13 +175,24 @@ def test_faithful_mode_split_bf16x6_matches_reference_fixture(dev, golden_dir, n
     np.testing.assert_allclose(est.transformer.singular_values_[:r], g["singular_values"][:r], rtol=1e-4)
 
 
-def test_split_bf16_rejected_for_smallside(dev):
+@pytest.mark.parametrize("precision,cos_tol,sv_tol", [("bf16x6", 5e-6, 1e-4), ("bf16x3", 2e-4, 2e-3)])
+@pytest.mark.parametrize("name", ["d3000_k12_highd", "d512_k20"])
+def test_smallside_split_bf16_matches_reference_fixture(dev, golden_dir, name, precision, cos_tol, sv_tol):
+    """Small-side recurrence with T = M M^T on the bf16 matrix cores (both operands are K-contiguous rows of M).
+    bf16x6 drops terms below 2^-24 |xy| per product: float32-class, same tolerances as the f32 contraction;
+    bf16x3 drops terms below 2^-16 |xy| (zero-mean rounding errors, averaged over d columns)."""
     from ganspace_amd.estimators import IPCAEstimator
-    from ganspace_amd._lib import GanspaceHipError, GS_ENOTIMPL
-    est = IPCAEstimator(4, "smallside", precision="bf16x3")
-    with pytest.raises(GanspaceHipError) as e:
-        est.fit_partial(torch.randn(64, 128, device=dev))
-    assert e.value.code == GS_ENOTIMPL
+    case = gin.IPCA_CASES[name]
+    g = _golden(golden_dir, name)
+    est = IPCAEstimator(case["k"], "smallside", precision=precision)
+    for X in gin.ipca_blocks(case):
+        assert est.fit_partial(torch.from_numpy(X).to(dev)) is True
+    comp, stdev, ratio = est.get_components()
+    r = case["ncheck"]
+    cos = O.signed_cosines(comp[:r], g["components"][:r])
+    assert cos.min() > 1 - cos_tol, (name, precision, cos.min())
+    np.testing.assert_allclose(est.transformer.singular_values_[:r], g["singular_values"][:r], rtol=sv_tol)
+    np.testing.assert_allclose(est.transformer.mean_, g["mean"], atol=2e-6 * max(1.0, np.abs(g["mean"]).max()))
 
 
 # ---- eigensolver -----------------------------------------------------------------------------
