@@ -199,9 +199,14 @@ __global__ __launch_bounds__(256, 1) void rowgram_bf16_kernel(const float *__res
     const float *Ma = M + (int64_t)I * kRT * ldm;
     const float *Mb = M + (int64_t)J * kRT * ldm;
 
-    // staging: item = (row, group of 8 columns); 512 items per panel and stage, two per thread
-    float4 ra[2][2], rb[2][2];
-    auto fetch = [&](int64_t k0) {
+    // staging: item = (row, group of 8 columns); 512 items per panel and stage, two per thread.  With the matrix
+    // work this cheap a stage lasts ~0.6 us, far less than a trip to L2 / HBM: FOUR stages of loads stay in flight
+    // (register ring of four fetch sets; one stage at a time was latency-bound - the split kernel measured no faster
+    // than the f32 one).
+    struct FetchSet {
+        float4 a[2][2], b[2][2];
+    };
+    auto fetch = [&](FetchSet &f, int64_t k0) {
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
             const int item = tid + 256 * g, row = item >> 2, kg = item & 3;
@@ -217,22 +222,22 @@ __global__ __launch_bounds__(256, 1) void rowgram_bf16_kernel(const float *__res
                     va = make_float4(0.f, 0.f, 0.f, 0.f);
                     vb = va;
                 }
-                ra[g][h] = va;
-                rb[g][h] = vb;
+                f.a[g][h] = va;
+                f.b[g][h] = vb;
             }
         }
     };
-    auto stash = [&](int buf) {
+    auto stash = [&](const FetchSet &f, int buf) {
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
             const int item = tid + 256 * g, row = item >> 2, kg = item & 3;
             unsigned char *dst = rlds + buf * kStage + row * kRowBytes + kg * 16;
             uint4 pl[NPL];
-            split8s<NPL>(ra[g][0], ra[g][1], pl);
+            split8s<NPL>(f.a[g][0], f.a[g][1], pl);
 #pragma unroll
             for (int p = 0; p < NPL; ++p) *reinterpret_cast<uint4 *>(dst + p * 2 * kPanelB) = pl[p];
             if (!diag) {
-                split8s<NPL>(rb[g][0], rb[g][1], pl);
+                split8s<NPL>(f.b[g][0], f.b[g][1], pl);
 #pragma unroll
                 for (int p = 0; p < NPL; ++p) *reinterpret_cast<uint4 *>(dst + p * 2 * kPanelB + kPanelB) = pl[p];
             }
@@ -275,14 +280,21 @@ __global__ __launch_bounds__(256, 1) void rowgram_bf16_kernel(const float *__res
     };
 
     const int nst = (int)((k_end - k_begin + kRK - 1) / kRK);
-    if (nst > 0) {
-        fetch(k_begin);
-        stash(0);
-    }
+    // stage t lives in fetch set t % 4.  Entering iteration s: LDS buffer s & 1 holds stage s, the sets of stages
+    // s + 1 .. s + 3 are in flight.  iteration: issue stage s + 4 (into the set stage s used), MFMAs on stage s,
+    // split + write stage s + 1, barrier.  Loads past the end are masked to zero by fetch().
+    FetchSet f0, f1, f2, f3;
+    auto stage_k = [&](int t) { return k_begin + (int64_t)t * kRK; };
+    if (nst > 0) fetch(f0, stage_k(0));
+    if (nst > 1) fetch(f1, stage_k(1));
+    if (nst > 2) fetch(f2, stage_k(2));
+    if (nst > 3) fetch(f3, stage_k(3));
+    if (nst > 0) stash(f0, 0);
     __syncthreads();
-    for (int s = 0; s < nst; ++s) {
+    int s = 0;
+    auto iter = [&](FetchSet &freed, const FetchSet &next) {
         const int buf = s & 1;
-        if (s + 1 < nst) fetch(k_begin + (int64_t)(s + 1) * kRK);
+        if (s + 4 < nst) fetch(freed, stage_k(s + 4));
         mma_step(buf, 0);
         mma_step(buf, 1);
         if ((s + 1) % kFlushStages == 0 || s + 1 == nst) {
@@ -296,8 +308,18 @@ __global__ __launch_bounds__(256, 1) void rowgram_bf16_kernel(const float *__res
                         acc[a][b][r] = 0.f;
                     }
         }
-        if (s + 1 < nst) stash(buf ^ 1);
+        if (s + 1 < nst) stash(next, buf ^ 1);
         __syncthreads();
+        ++s;
+    };
+    while (s < nst) {
+        iter(f0, f1);
+        if (s >= nst) break;
+        iter(f1, f2);
+        if (s >= nst) break;
+        iter(f2, f3);
+        if (s >= nst) break;
+        iter(f3, f0);
     }
     double *out = slab + (int64_t)split * rp * rp;
     const int row_base = I * kRT + wi * 64 + 4 * (lane >> 5);
@@ -558,11 +580,10 @@ int smallside_alloc(SmallSide &ss, int64_t d, int k, int m) {
     ss.rp = (int)round_up(ss.r_cap, kRT);
     ss.kp = (int)round_up(k, kRT);
     // split of the feature range over workgroups: the launch (macro tiles x splits) should fill whole rounds of the
-    // resident workgroups (f32 kernel: two per CU, split-bf16: one) - 153 tiles x 4 splits = 612 workgroups on 512
-    // slots was two rounds at 60 %
+    // resident workgroups (one per CU) - 153 tiles x 4 splits = 612 workgroups on 256 CUs was three rounds at 80 %
     {
         const int Tt = (int)ceil_div(ss.r_cap, kRT), nmt = Tt * (Tt + 1) / 2;
-        const int slots = (ss.precision == GS_PREC_F32) ? 512 : 256;
+        const int slots = 256;      // both kernels need the whole register file of a SIMD per wave: one workgroup per CU
         int best = 4;
         double best_eff = 0.0;
         for (int ns = 3; ns <= 12; ++ns) {
