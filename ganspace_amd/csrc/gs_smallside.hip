@@ -13,8 +13,8 @@
 //     S' = sqrt(w_k),  rows sign-fixed (svd_flip, extmath.py:943-951)
 //
 // M is materialised once per block in HBM (1.09 GB at r = 2081, d = 131 072: 288 GB of HBM make
-// that the simple choice) and streamed: once for T (row panels re-read through L2/MALL), once
-// for V'.
+// that the simple choice), K-blocked ([d / 32][rp][32], see mblk()), and streamed: once for T (row
+// panels re-read through L2/MALL), once for V'.
 #include <cstdlib>
 
 #include "gs_common.h"
@@ -27,6 +27,15 @@ constexpr int kRT = 128;  // output tile
 constexpr int kRK = 32;   // K step (columns of M)
 constexpr int kRP = kRT + 1;
 constexpr int kFlushStages = 32;  // float64 carry every 32 * 32 = 1024 columns
+
+// M is stored K-BLOCKED: [d / 32][rp][32] - the 32 columns of a block for all rp rows are contiguous (128 B per row,
+// rows 128 B apart).  A stage of the T = M M^T kernels (128 rows x 32 columns of a panel) is then ONE contiguous
+// 16 KB run instead of 128 lines that lie a whole row (up to 512 KB) apart: with the row-major layout every 128-byte
+// line came from a different DRAM page and TLB entry, and the kernels ran at ~2.7 TB/s of L2 -> CU traffic whatever
+// the matrix-pipe work (the split-bf16 contraction measured no faster than the f32 one).  `ldm` below is rp.
+__device__ __forceinline__ int64_t mblk(int64_t row, int64_t col, int64_t rp) {
+    return ((col >> 5) * rp + row) * 32 + (col & 31);
+}
 
 __device__ __forceinline__ void decode_upper2(int idx, int T, int &I, int &J) {
     int i = 0, len = T;
@@ -54,8 +63,7 @@ __global__ __launch_bounds__(256, 1) void rowgram_kernel(const float *__restrict
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wi = wave >> 1, wj = wave & 1;
     const int k4 = tid & 7, r8 = tid >> 3;
-    const float *Ma = M + (int64_t)I * kRT * ldm;
-    const float *Mb = M + (int64_t)J * kRT * ldm;
+    const int64_t rowA = (int64_t)I * kRT, rowB = (int64_t)J * kRT;
 
     float4 ra[4], rb[4];
     auto fetch = [&](int64_t k0) {
@@ -64,8 +72,8 @@ __global__ __launch_bounds__(256, 1) void rowgram_kernel(const float *__restrict
         const int64_t kc = ok ? kk : k_begin;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            ra[i] = *reinterpret_cast<const float4 *>(Ma + (int64_t)(r8 + 32 * i) * ldm + kc);
-            if (!diag) rb[i] = *reinterpret_cast<const float4 *>(Mb + (int64_t)(r8 + 32 * i) * ldm + kc);
+            ra[i] = *reinterpret_cast<const float4 *>(M + mblk(rowA + r8 + 32 * i, kc, ldm));
+            if (!diag) rb[i] = *reinterpret_cast<const float4 *>(M + mblk(rowB + r8 + 32 * i, kc, ldm));
             if (!ok) {
                 ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
                 rb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -196,8 +204,7 @@ __global__ __launch_bounds__(256, 1) void rowgram_bf16_kernel(const float *__res
     const int64_t k_end = (k_begin + kchunk < d) ? k_begin + kchunk : d;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wi = wave >> 1, wj = wave & 1;
-    const float *Ma = M + (int64_t)I * kRT * ldm;
-    const float *Mb = M + (int64_t)J * kRT * ldm;
+    const int64_t rowA = (int64_t)I * kRT, rowB = (int64_t)J * kRT;
 
     // staging: item = (row, group of 8 columns); 512 items per panel and stage, two per thread.  With the matrix
     // work this cheap a stage lasts ~0.6 us, far less than a trip to L2 / HBM: FOUR stages of loads stay in flight
@@ -216,8 +223,8 @@ __global__ __launch_bounds__(256, 1) void rowgram_bf16_kernel(const float *__res
                 const int64_t kc = kk + 4 * h;
                 const bool ok = kc < k_end;               // d % 4 == 0: a float4 is valid or not as a whole
                 const int64_t ks = ok ? kc : k_begin;
-                float4 va = *reinterpret_cast<const float4 *>(Ma + (int64_t)row * ldm + ks);
-                float4 vb = diag ? va : *reinterpret_cast<const float4 *>(Mb + (int64_t)row * ldm + ks);
+                float4 va = *reinterpret_cast<const float4 *>(M + mblk(rowA + row, ks, ldm));
+                float4 vb = diag ? va : *reinterpret_cast<const float4 *>(M + mblk(rowB + row, ks, ldm));
                 if (!ok) {
                     va = make_float4(0.f, 0.f, 0.f, 0.f);
                     vb = va;
@@ -373,7 +380,7 @@ __global__ __launch_bounds__(256, 2) void tn_gemm_kernel(const float *__restrict
             const int t = t0 + rr + 8 * i;
             const int tc = t < r ? t : r - 1;
             ra[i] = *reinterpret_cast<const float4 *>(Ct + (int64_t)tc * kp + colA);
-            rb[i] = *reinterpret_cast<const float4 *>(M + (int64_t)tc * ldm + (okB ? colB : 0));
+            rb[i] = *reinterpret_cast<const float4 *>(M + mblk(tc, okB ? colB : 0, ldm));
             if (t >= r) {
                 ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
                 rb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -443,11 +450,11 @@ __global__ void ss_build_kernel(const float *__restrict__ X, int64_t ldx, int m,
     } else if (t == k + m) {
         v = (n0 > 0) ? (float)vec[d + j] : 0.f;
     }
-    M[(int64_t)t * d + j] = v;
+    M[mblk(t, j, rp)] = v;
 }
 
 // colsq[j] += sum over the m data rows of M[k + t][j]^2   (float64)
-__global__ __launch_bounds__(256) void ss_colsq_kernel(const float *__restrict__ M, int64_t d, int k, int m,
+__global__ __launch_bounds__(256) void ss_colsq_kernel(const float *__restrict__ M, int64_t d, int rp, int k, int m,
                                                        double *__restrict__ colsq, int rows_per_block) {
     __shared__ double scr[8][32];
     const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
@@ -457,7 +464,7 @@ __global__ __launch_bounds__(256) void ss_colsq_kernel(const float *__restrict__
     double s = 0;
     if (col < d)
         for (int r = r0 + ry; r < r1; r += 8) {
-            const double v = M[(int64_t)(k + r) * d + col];
+            const double v = M[mblk(k + r, col, rp)];
             s += v * v;
         }
     scr[ry][cx] = s;
@@ -605,7 +612,7 @@ int smallside_alloc(SmallSide &ss, int64_t d, int k, int m) {
         return hipMemset(*p, 0, bytes) == hipSuccess ? GS_OK : GS_EHIP;
     };
     int rc = GS_OK;
-    if (rc == GS_OK) rc = alloc((void **)&ss.M, sizeof(float) * (size_t)ss.rp * d);
+    if (rc == GS_OK) rc = alloc((void **)&ss.M, sizeof(float) * (size_t)ss.rp * (size_t)round_up(d, 32));
     if (rc == GS_OK) rc = alloc((void **)&ss.T, sizeof(double) * (size_t)ss.rp * ss.rp);
     if (rc == GS_OK) rc = alloc((void **)&ss.slab, sizeof(double) * (size_t)ss.nsplit * ss.rp * ss.rp);
     if (rc == GS_OK) rc = alloc((void **)&ss.Ct, sizeof(float) * (size_t)ss.rp * ss.kp);
@@ -646,13 +653,13 @@ int smallside_update(SmallSide &ss, const float *X, int64_t rows, int64_t ldx, d
                        rp, n0, ss.M);
     // 3. per-feature sum of squared deviations of this block -> variance update
     hipLaunchKernelGGL(ss_colsq_kernel, dim3((unsigned)ceil_div(d, 32), (unsigned)ceil_div(m, 256)), dim3(256), 0,
-                       stream, ss.M, d, k, m, ss.colsq, 256);
+                       stream, ss.M, d, rp, k, m, ss.colsq, 256);
     hipLaunchKernelGGL(ss_m2_kernel, dim3(gd), dim3(256), 0, stream, ss.colsq, vec, m2, d, n0, (double)m);
     // 4. T = M M^T
     const int Tt = (int)ceil_div(r, kRT), nmt = Tt * (Tt + 1) / 2;
     const int64_t kchunk = round_up(ceil_div(d, ss.nsplit), kRK);
     if (ss.precision == GS_PREC_F32) {
-        hipLaunchKernelGGL(rowgram_kernel, dim3((unsigned)(nmt * ss.nsplit)), dim3(256), 0, stream, ss.M, d, d, ss.slab,
+        hipLaunchKernelGGL(rowgram_kernel, dim3((unsigned)(nmt * ss.nsplit)), dim3(256), 0, stream, ss.M, d, (int64_t)rp, ss.slab,
                            rp, nmt, Tt, kchunk);
     } else {
         const bool x6 = ss.precision == GS_PREC_BF16X6;
@@ -670,10 +677,10 @@ int smallside_update(SmallSide &ss, const float *X, int64_t rows, int64_t ldx, d
         }
         if (x6)
             hipLaunchKernelGGL(rowgram_bf16_kernel<6>, dim3((unsigned)(nmt * ss.nsplit)), dim3(256), lds, stream, ss.M, d,
-                               d, ss.slab, rp, nmt, Tt, kchunk);
+                               (int64_t)rp, ss.slab, rp, nmt, Tt, kchunk);
         else
             hipLaunchKernelGGL(rowgram_bf16_kernel<3>, dim3((unsigned)(nmt * ss.nsplit)), dim3(256), lds, stream, ss.M, d,
-                               d, ss.slab, rp, nmt, Tt, kchunk);
+                               (int64_t)rp, ss.slab, rp, nmt, Tt, kchunk);
     }
     const int rused = Tt * kRT;
     hipLaunchKernelGGL(rowgram_fold_kernel, dim3((unsigned)ceil_div(rused, 256), (unsigned)rused), dim3(256), 0,
@@ -710,7 +717,7 @@ int smallside_update(SmallSide &ss, const float *X, int64_t rows, int64_t ldx, d
     // 6. V' = Ct^T M, sign convention
     const int64_t ntn = ceil_div(d, kRT);
     hipLaunchKernelGGL(tn_gemm_kernel, dim3((unsigned)((kp / kRT) * ntn)), dim3(256), 0, stream, ss.Ct, kp, ss.M, d,
-                       d, r, ss.Vtmp, d);
+                       (int64_t)rp, r, ss.Vtmp, d);
     hipLaunchKernelGGL(ss_sign_kernel, dim3((unsigned)k), dim3(1024), 0, stream, ss.Vtmp, d, V, d);
     GS_HIP_CHECK(hipGetLastError());
     return GS_OK;
