@@ -65,34 +65,35 @@ __global__ __launch_bounds__(256, 1) void rowgram_kernel(const float *__restrict
     const int k4 = tid & 7, r8 = tid >> 3;
     const int64_t rowA = (int64_t)I * kRT, rowB = (int64_t)J * kRT;
 
+    // Loads are issued at CLAMPED addresses and nothing looks at the loaded values until stash(): a select on a
+    // value just loaded (masking the tail here) makes the compiler wait for every single load (s_waitcnt vmcnt(0)
+    // after each one - the kernel then runs at one L2/HBM round trip per 16 bytes per thread).
     float4 ra[4], rb[4];
     auto fetch = [&](int64_t k0) {
         const int64_t kk = k0 + k4 * 4;
-        const bool ok = kk < k_end;  // d % 4 == 0 is required by the caller
-        const int64_t kc = ok ? kk : k_begin;
+        const int64_t kc = kk < k_end ? kk : k_begin;   // d % 4 == 0 is required by the caller
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
+            // both panels unconditionally (a diagonal tile reads its panel twice - L1 hits): a branch around a load
+            // makes the compiler's s_waitcnt placement pessimistic for every load after the join
             ra[i] = *reinterpret_cast<const float4 *>(M + mblk(rowA + r8 + 32 * i, kc, ldm));
-            if (!diag) rb[i] = *reinterpret_cast<const float4 *>(M + mblk(rowB + r8 + 32 * i, kc, ldm));
-            if (!ok) {
-                ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-                rb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            }
+            rb[i] = *reinterpret_cast<const float4 *>(M + mblk(rowB + r8 + 32 * i, kc, ldm));
         }
     };
-    auto stash = [&](int buf) {
+    auto stash = [&](int buf, int64_t k0) {
+        const bool ok = k0 + k4 * 4 < k_end;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int r = r8 + 32 * i;
-            lds[buf][0][k4 * 4 + 0][r] = ra[i].x;
-            lds[buf][0][k4 * 4 + 1][r] = ra[i].y;
-            lds[buf][0][k4 * 4 + 2][r] = ra[i].z;
-            lds[buf][0][k4 * 4 + 3][r] = ra[i].w;
+            lds[buf][0][k4 * 4 + 0][r] = ok ? ra[i].x : 0.f;
+            lds[buf][0][k4 * 4 + 1][r] = ok ? ra[i].y : 0.f;
+            lds[buf][0][k4 * 4 + 2][r] = ok ? ra[i].z : 0.f;
+            lds[buf][0][k4 * 4 + 3][r] = ok ? ra[i].w : 0.f;
             if (!diag) {
-                lds[buf][1][k4 * 4 + 0][r] = rb[i].x;
-                lds[buf][1][k4 * 4 + 1][r] = rb[i].y;
-                lds[buf][1][k4 * 4 + 2][r] = rb[i].z;
-                lds[buf][1][k4 * 4 + 3][r] = rb[i].w;
+                lds[buf][1][k4 * 4 + 0][r] = ok ? rb[i].x : 0.f;
+                lds[buf][1][k4 * 4 + 1][r] = ok ? rb[i].y : 0.f;
+                lds[buf][1][k4 * 4 + 2][r] = ok ? rb[i].z : 0.f;
+                lds[buf][1][k4 * 4 + 3][r] = ok ? rb[i].w : 0.f;
             }
         }
     };
@@ -109,12 +110,12 @@ __global__ __launch_bounds__(256, 1) void rowgram_kernel(const float *__restrict
     const int acol = wi * 64 + (lane & 31), bcol = wj * 64 + (lane & 31);
     if (nst > 0) {
         fetch(k_begin);
-        stash(0);
+        stash(0, k_begin);
     }
     __syncthreads();
     for (int s = 0; s < nst; ++s) {
         const int buf = s & 1;
-        if (s + 1 < nst) fetch(k_begin + (int64_t)(s + 1) * kRK);
+        fetch(k_begin + (int64_t)(s + 1 < nst ? s + 1 : s) * kRK);      // unconditional (clamped): no branch around loads
         const float *A = &lds[buf][0][arow][acol];
         const float *B = &lds[buf][diag ? 0 : 1][arow][bcol];
 #pragma unroll
@@ -137,7 +138,7 @@ __global__ __launch_bounds__(256, 1) void rowgram_kernel(const float *__restrict
                 }
             }
         }
-        if (s + 1 < nst) stash(buf ^ 1);
+        if (s + 1 < nst) stash(buf ^ 1, k_begin + (int64_t)(s + 1) * kRK);
         __syncthreads();
     }
     double *out = slab + (int64_t)split * rp * rp;
@@ -213,6 +214,8 @@ __global__ __launch_bounds__(256, 1) void rowgram_bf16_kernel(const float *__res
     struct FetchSet {
         float4 a[2][2], b[2][2];
     };
+    // (raw loads at clamped addresses; the tail is masked in stash(): a select on a value just loaded would make the
+    //  compiler wait for every load separately)
     auto fetch = [&](FetchSet &f, int64_t k0) {
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
@@ -221,30 +224,29 @@ __global__ __launch_bounds__(256, 1) void rowgram_bf16_kernel(const float *__res
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const int64_t kc = kk + 4 * h;
-                const bool ok = kc < k_end;               // d % 4 == 0: a float4 is valid or not as a whole
-                const int64_t ks = ok ? kc : k_begin;
-                float4 va = *reinterpret_cast<const float4 *>(M + mblk(rowA + row, ks, ldm));
-                float4 vb = diag ? va : *reinterpret_cast<const float4 *>(M + mblk(rowB + row, ks, ldm));
-                if (!ok) {
-                    va = make_float4(0.f, 0.f, 0.f, 0.f);
-                    vb = va;
-                }
-                f.a[g][h] = va;
-                f.b[g][h] = vb;
+                const int64_t ks = kc < k_end ? kc : k_begin;      // d % 4 == 0: a float4 is valid or not as a whole
+                // both panels unconditionally (a diagonal tile reads its panel twice - L1 hits): a branch around a
+                // load makes the compiler's s_waitcnt placement pessimistic for every load after the join
+                f.a[g][h] = *reinterpret_cast<const float4 *>(M + mblk(rowA + row, ks, ldm));
+                f.b[g][h] = *reinterpret_cast<const float4 *>(M + mblk(rowB + row, ks, ldm));
             }
         }
     };
-    auto stash = [&](const FetchSet &f, int buf) {
+    auto masked = [&](const float4 &v, bool ok) {
+        return ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    auto stash = [&](const FetchSet &f, int buf, int64_t k0) {
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
             const int item = tid + 256 * g, row = item >> 2, kg = item & 3;
+            const bool ok0 = k0 + kg * 8 < k_end, ok1 = k0 + kg * 8 + 4 < k_end;
             unsigned char *dst = rlds + buf * kStage + row * kRowBytes + kg * 16;
             uint4 pl[NPL];
-            split8s<NPL>(f.a[g][0], f.a[g][1], pl);
+            split8s<NPL>(masked(f.a[g][0], ok0), masked(f.a[g][1], ok1), pl);
 #pragma unroll
             for (int p = 0; p < NPL; ++p) *reinterpret_cast<uint4 *>(dst + p * 2 * kPanelB) = pl[p];
             if (!diag) {
-                split8s<NPL>(f.b[g][0], f.b[g][1], pl);
+                split8s<NPL>(masked(f.b[g][0], ok0), masked(f.b[g][1], ok1), pl);
 #pragma unroll
                 for (int p = 0; p < NPL; ++p) *reinterpret_cast<uint4 *>(dst + p * 2 * kPanelB + kPanelB) = pl[p];
             }
@@ -291,17 +293,20 @@ __global__ __launch_bounds__(256, 1) void rowgram_bf16_kernel(const float *__res
     // s + 1 .. s + 3 are in flight.  iteration: issue stage s + 4 (into the set stage s used), MFMAs on stage s,
     // split + write stage s + 1, barrier.  Loads past the end are masked to zero by fetch().
     FetchSet f0, f1, f2, f3;
-    auto stage_k = [&](int t) { return k_begin + (int64_t)t * kRK; };
-    if (nst > 0) fetch(f0, stage_k(0));
-    if (nst > 1) fetch(f1, stage_k(1));
-    if (nst > 2) fetch(f2, stage_k(2));
-    if (nst > 3) fetch(f3, stage_k(3));
-    if (nst > 0) stash(f0, 0);
+    // (every fetch is UNCONDITIONAL - a stage index past the end is clamped to the last stage and simply never
+    //  stashed: a branch around loads makes the compiler drain the whole ring at the join)
+    auto stage_k = [&](int t) { return k_begin + (int64_t)(t < nst ? t : nst - 1) * kRK; };
+    if (nst <= 0) return;            // (cannot happen: kchunk >= 32)
+    fetch(f0, stage_k(0));
+    fetch(f1, stage_k(1));
+    fetch(f2, stage_k(2));
+    fetch(f3, stage_k(3));
+    stash(f0, 0, stage_k(0));
     __syncthreads();
     int s = 0;
     auto iter = [&](FetchSet &freed, const FetchSet &next) {
         const int buf = s & 1;
-        if (s + 4 < nst) fetch(freed, stage_k(s + 4));
+        fetch(freed, stage_k(s + 4));
         mma_step(buf, 0);
         mma_step(buf, 1);
         if ((s + 1) % kFlushStages == 0 || s + 1 == nst) {
@@ -315,7 +320,7 @@ __global__ __launch_bounds__(256, 1) void rowgram_bf16_kernel(const float *__res
                         acc[a][b][r] = 0.f;
                     }
         }
-        if (s + 1 < nst) stash(next, buf ^ 1);
+        if (s + 1 < nst) stash(next, buf ^ 1, stage_k(s + 1));
         __syncthreads();
         ++s;
     };
@@ -377,14 +382,12 @@ __global__ __launch_bounds__(256, 2) void tn_gemm_kernel(const float *__restrict
     auto fetch = [&](int t0) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
+            // rows t >= r of Ct are zero (the coefficient kernels write 0 there, the buffer is cleared per block): the
+            // product needs no mask, and no select on a freshly loaded value stalls the other loads
             const int t = t0 + rr + 8 * i;
             const int tc = t < r ? t : r - 1;
-            ra[i] = *reinterpret_cast<const float4 *>(Ct + (int64_t)tc * kp + colA);
+            ra[i] = *reinterpret_cast<const float4 *>(Ct + (int64_t)(t < r ? t : r) * kp + colA);
             rb[i] = *reinterpret_cast<const float4 *>(M + mblk(tc, okB ? colB : 0, ldm));
-            if (t >= r) {
-                ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-                rb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            }
         }
     };
     auto stash = [&](int buf) {
