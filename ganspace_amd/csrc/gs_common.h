@@ -114,6 +114,7 @@ struct SubspaceWorkspace {
     // warm starts of a SEQUENCE of related matrices (faithful mode: one per block) may take the guard columns
     // k .. p-1 from the previous solve's Ritz basis instead of random vectors (set by the owner of the workspace)
     bool reuse_guards = false;
+    int guards = 0;                // guard columns beyond k for this workspace's solves (0 = subspace_dim's default)
     bool guards_valid = false;
     int guards_n = 0, guards_p = 0;
     double *G = nullptr;           // [n][pp] Ritz basis of the last converged solve
@@ -127,7 +128,7 @@ struct SubspaceWorkspace {
 int subspace_workspace_alloc(SubspaceWorkspace &ws, int n, int p);
 void subspace_workspace_free(SubspaceWorkspace &ws);
 // subspace dimension used for (n, k), or 0 when the full Jacobi solver should be used instead
-int subspace_dim(int n, int k);
+int subspace_dim(int n, int k, int guards = 0);   // guards = 0: the default 48 .. k/2 guard columns
 int eigh_topk_subspace(SubspaceWorkspace &ws, const double *A, int n, int64_t lda, int k, const double *V0, int k0,
                        int64_t ldv0, double *Vk, int64_t ldv, double *lam, int *iters_out, int *converged,
                        hipStream_t stream);

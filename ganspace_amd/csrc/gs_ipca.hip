@@ -435,6 +435,8 @@ int gs_ipca_create(int64_t d, int k, int mode, int precision, int device, gs_ipc
     // consecutive blocks of the faithful recurrence have near-identical leading AND trailing spectra: the guard
     // columns of one block's solve are good guards for the next
     h->sws.reuse_guards = (mode == GS_MODE_FAITHFUL);
+    // ... and the matrix of every block after the first has rank <= k + rows with a cliff behind lambda_k
+    h->sws.guards = (mode == GS_MODE_FAITHFUL) ? 16 : 0;
     h->dp = h->gws.dp;
     const int64_t dp = h->dp;
     alloc((void **)&h->shift, sizeof(float) * dp);

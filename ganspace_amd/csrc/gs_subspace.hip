@@ -467,7 +467,7 @@ void subspace_workspace_free(SubspaceWorkspace &ws) {
     ws = SubspaceWorkspace();
 }
 
-int subspace_dim(int n, int k) {
+int subspace_dim(int n, int k, int guards) {
     static const int extra_env = []() {
         const char *e = getenv("GS_SUBSPACE_EXTRA");     // experiment knob: guard columns beyond k
         return e ? atoi(e) : 0;
@@ -476,7 +476,10 @@ int subspace_dim(int n, int k) {
     // Rayleigh-Ritz step costs ~p, p^2, p^3.  48 .. k/2 guards measured best on the cfg2 spectrum (k = 80:
     // p = 128 -> 26 products, 3.4 ms; p = 160 -> 18 products, 3.9 ms; p = 112 -> 34 products, 3.6 ms); a flatter
     // spectrum only costs more products - the residual test, not p, decides when the solve is done.
-    int p = k + (extra_env > 0 ? extra_env : (k / 2 > 48 ? k / 2 : 48));
+    // `guards` > 0 (per workspace): the warm solves of the sklearn-faithful recurrence see a matrix whose spectrum
+    // drops by orders of magnitude right behind lambda_k (k old components + one block), so 16 guards converge in the
+    // same number of products and the p^3 Rayleigh-Ritz step shrinks (k = 80: p = 96, 1.3 -> 0.95 ms per block)
+    int p = k + (extra_env > 0 ? extra_env : guards > 0 ? guards : (k / 2 > 48 ? k / 2 : 48));
     p = (int)round_up(p, 16);
     // the subspace must stay well below n for the iteration to pay off
     if (p > 256 || 2 * p > n) return 0;
@@ -489,7 +492,7 @@ int subspace_dim(int n, int k) {
 int eigh_topk_subspace(SubspaceWorkspace &ws, const double *A, int n, int64_t lda, int k, const double *V0, int k0,
                        int64_t ldv0, double *Vk, int64_t ldv, double *lam, int *iters_out, int *converged,
                        hipStream_t stream) {
-    const int p = subspace_dim(n, k);
+    const int p = subspace_dim(n, k, ws.guards);
     GS_REQUIRE(p > 0 && n <= ws.n_cap && p <= ws.p_cap, GS_EINVAL, "eigh_topk_subspace: bad sizes");
     static const bool legacy = getenv("GS_SUBSPACE_LEGACY") != nullptr;
     if (p <= 128 && !legacy)

@@ -683,7 +683,7 @@ static double cheb_T(int m, double x) { return x <= 1.0 ? 1.0 : std::cosh((doubl
 int eigh_topk_cheb(SubspaceWorkspace &ws, const double *A, int n, int64_t lda, int k, const double *V0, int k0,
                    int64_t ldv0, double *Vk, int64_t ldv, double *lam, int *iters_out, int *converged,
                    hipStream_t stream) {
-    const int p = subspace_dim(n, k);
+    const int p = subspace_dim(n, k, ws.guards);
     GS_REQUIRE(p > 0 && p <= kCholP && (p % 8) == 0 && n <= ws.n_cap && p <= ws.p_cap, GS_EINVAL,
                "eigh_topk_cheb: bad sizes");
     const int64_t ld = ws.pp;
