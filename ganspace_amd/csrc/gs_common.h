@@ -118,6 +118,10 @@ struct SubspaceWorkspace {
     bool guards_valid = false;
     int guards_n = 0, guards_p = 0;
     double *G = nullptr;           // [n][pp] Ritz basis of the last converged solve
+    // invsub_iterate (gs_topk.hip): schedule carried from one block of the faithful recurrence to the next
+    int inv_plan = 0;              // products before the Rayleigh quotient (0 = derive from the block count)
+    double inv_ratio1 = 0.0;       // max / min pivot of R per product at the last orthonormalisation (~lambda_1 / lambda_k)
+    int inv_last_products = 0;
     double *Q = nullptr, *Y = nullptr, *Z = nullptr, *R = nullptr;  // [n][pp]
     double *H = nullptr, *B = nullptr, *U = nullptr;                // [pp][pp]
     double *theta = nullptr;                                        // [3*pp + 32]: Ritz values | residuals | pivot floors / R diagonal | statistics (8) | filter coefficients (6)
@@ -149,6 +153,15 @@ int trsm_rows_launch(const double *Y, double *Qout, int64_t ld, int n, int p, co
 int eigh_topk_cheb(SubspaceWorkspace &ws, const double *A, int n, int64_t lda, int k, const double *V0, int k0,
                    int64_t ldv0, double *Vk, int64_t ldv, double *lam, int *iters_out, int *converged,
                    hipStream_t stream);
+
+// Invariant-subspace step of the faithful recurrence with the diagonalisation deferred (gs_topk.hip): A = Q0 B0 Q0^T +
+// (one block), whose k leading eigenvalues are (t + 1) times above the rest once t blocks have been absorbed.  Plain
+// orthogonal iteration with exactly k columns from Q0 = rows of Vk converges like (t + 1)^-products; on success
+// (*converged = 1) Vk holds an orthonormal basis of the leading invariant subspace (rows) and Bk = Vk A Vk^T
+// (k x k, symmetric, NOT diagonal).  *converged = 0 (Vk, Bk untouched): the schedule would cost more than the
+// Rayleigh-Ritz solver, or the residual target was missed - the caller falls back to eigh_topk_subspace.
+int invsub_iterate(SubspaceWorkspace &ws, const double *A, int n, int64_t lda, int k, double *Vk, int64_t ldv,
+                   double *Bk, int64_t ldbk, double blocks_seen, int *mults_out, int *converged, hipStream_t stream);
 
 // ---- small-side recurrence for d >> m: gs_smallside.hip -------------------------------------------
 struct SmallSide {

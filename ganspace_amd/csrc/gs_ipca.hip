@@ -10,6 +10,10 @@
 //   FAITHFUL  per block:  Gc = sum (x-bm)(x-bm)^T
 //                                          Gc += V^T diag(S^2) V + mc mc^T   (n > 0)
 //             eigh(Gc) -> S' = sqrt(w_top), V' = sign-fixed rows; Chan update of mean/var.
+//             The recurrence only ever uses V^T diag(S^2) V, i.e. the truncated operator: from the fifth block
+//             on the state is carried as an orthonormal basis Q of the leading invariant subspace plus the
+//             k x k matrix B = Q^T Gc Q (invsub_iterate, gs_topk.hip), and the diagonalisation of B - the
+//             p^3 step of every solve - happens once, when the components are asked for.
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
@@ -45,6 +49,9 @@ struct gs_ipca {
     double *vec = nullptr;       // [4*dp]  scratch vectors (bm', mc, ...)
     double *Vk = nullptr;        // [k*dp]  float64 components (rows)
     double *lam = nullptr;       // [k]     top-k eigenvalues of the last solve (= S^2)
+    double *Bk = nullptr;        // [k*k]   FAITHFUL: Vk Gc Vk^T (diag(lam) unless pending_diag)
+    double *T = nullptr;         // [k*dp]  FAITHFUL: Bk Vk
+    bool pending_diag = false;   // FAITHFUL: (Vk, Bk) is an undiagonalised basis; lam / outs / comp32 are stale
     double *scal = nullptr;      // [8]     device scalars: [0]=trace
     double *outs = nullptr;      // [3*k]   sv, ev, evr
     float *comp32 = nullptr;     // [k*d]
@@ -106,8 +113,10 @@ __global__ void faithful_stats_kernel(const double *__restrict__ S1, const float
     }
 }
 
+// T = Bk Vk (k x dp); the old-state term Vk^T Bk Vk is evaluated as sum_t T[t][lo] Vk[t][hi] with lo <= hi so that W
+// is symmetric to the last bit whatever rounding Bk carries.
 __global__ void faithful_assemble_kernel(const double *__restrict__ G, const double *__restrict__ vec,
-                                         const double *__restrict__ Vk, const double *__restrict__ lam,
+                                         const double *__restrict__ Vk, const double *__restrict__ T,
                                          double *__restrict__ W, double *__restrict__ m2, int d, int dp,
                                          int k, double n0, double m) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
@@ -117,8 +126,9 @@ __global__ void faithful_assemble_kernel(const double *__restrict__ G, const dou
     double c = gc;
     if (n0 > 0) {
         c += vec[dp + i] * vec[dp + j];
+        const int lo = i < j ? i : j, hi = i < j ? j : i;
         double acc = 0;
-        for (int t = 0; t < k; ++t) acc += lam[t] * Vk[(int64_t)t * dp + i] * Vk[(int64_t)t * dp + j];
+        for (int t = 0; t < k; ++t) acc += T[(int64_t)t * dp + lo] * Vk[(int64_t)t * dp + hi];
         c += acc;
     }
     W[(int64_t)i * dp + j] = c;
@@ -199,6 +209,31 @@ __global__ __launch_bounds__(256) void signfix_rows_kernel(double *__restrict__ 
     }
     const double sgn = (bestv < 0) ? -1.0 : 1.0;
     for (int e = lane; e < dp; e += 64) row[e] = (e < n) ? row[e] * sgn : 0.0;
+}
+
+__global__ void set_diag_kernel(double *__restrict__ Bk, const double *__restrict__ lam, int k) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = blockIdx.y;
+    if (j < k) Bk[(int64_t)i * k + j] = (i == j) ? lam[i] : 0.0;
+}
+
+// Vk rows <- U^T Vk for the first k Ritz vectors of Bk (U: columns, leading dim ldu), lam <- theta
+__global__ void rotate_basis_kernel(const double *__restrict__ U, int64_t ldu, const double *__restrict__ theta,
+                                    const double *__restrict__ Vk, double *__restrict__ out, double *__restrict__ lam,
+                                    int k, int dp) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    const int r = blockIdx.y;
+    if (e == 0) lam[r] = theta[r];
+    if (e >= dp) return;
+    double acc = 0;
+    for (int s = 0; s < k; ++s) acc += U[(int64_t)s * ldu + r] * Vk[(int64_t)s * dp + e];
+    out[(int64_t)r * dp + e] = acc;
+}
+
+__global__ void pad_copy_kernel(const double *__restrict__ Bk, int k, double *__restrict__ out, int64_t ldo, int pj) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = blockIdx.y;
+    if (j < pj) out[(int64_t)i * ldo + j] = (i < k && j < k) ? Bk[(int64_t)i * k + j] : 0.0;
 }
 
 // sv = sqrt(lambda), ev = lambda/(n-1), evr = lambda/total
@@ -338,11 +373,47 @@ int solve_topk(gs_ipca *h, bool warm, const double *total_src, int total_len, hi
         hipLaunchKernelGGL(select_topk_kernel, dim3((unsigned)ceil_div(n, 4)), dim3(256), 0, stream, h->W,
                            h->ews.norms, h->ews.rank, h->Vk, h->lam, n, (int64_t)dp, dp, k);
     }
+    if (h->Bk) hipLaunchKernelGGL(set_diag_kernel, dim3((unsigned)ceil_div(k, 64), (unsigned)k), dim3(64), 0, stream, h->Bk,
+                                  h->lam, k);
+    h->pending_diag = false;
     hipLaunchKernelGGL(derive_outputs_kernel, dim3(1), dim3(256), 0, stream, h->lam, total_src, total_len, h->outs, k,
                        (double)h->n_seen);
     hipLaunchKernelGGL(to_f32_kernel, dim3((unsigned)ceil_div(h->d, 256), (unsigned)(k + 1)), dim3(256), 0, stream,
                        h->Vk, h->mean, h->comp32, h->mean32, (int)h->d, dp, k);
     GS_HIP_CHECK(hipGetLastError());
+    return GS_OK;
+}
+
+// FAITHFUL with the diagonalisation deferred: (Vk, Bk) -> eigenpairs of Bk rotate the basis into the components
+// (sklearn's sign convention), lam / outs / comp32 follow, and the state becomes the diagonal form again.
+int faithful_materialize(gs_ipca *h, hipStream_t stream) {
+    if (!h->pending_diag) return GS_OK;
+    const int k = h->k, dp = (int)h->dp, n = h->n2;
+    SubspaceWorkspace &ws = h->sws;
+    const int pj = (int)round_up(k, 8);
+    const int64_t ld = ws.pp;
+    int *jinfo = ws.ews.rank;
+    hipLaunchKernelGGL(pad_copy_kernel, dim3((unsigned)ceil_div(pj, 64), (unsigned)pj), dim3(64), 0, stream, h->Bk, k, ws.B,
+                       ld, pj);
+    int rc = jacobi_small_launch(ws.B, ld, pj, ws.U, ld, ws.theta, jinfo, stream);
+    if (rc != GS_OK) return rc;
+    // T is free between blocks: rotated rows land there, then replace Vk
+    hipLaunchKernelGGL(rotate_basis_kernel, dim3((unsigned)ceil_div(dp, 256), (unsigned)k), dim3(256), 0, stream, ws.U, ld,
+                       ws.theta, h->Vk, h->T, h->lam, k, dp);
+    GS_HIP_CHECK(hipMemcpyAsync(h->Vk, h->T, sizeof(double) * (size_t)k * dp, hipMemcpyDeviceToDevice, stream));
+    int jhost[2] = {0, 0};
+    GS_HIP_CHECK(hipMemcpyAsync(jhost, jinfo, sizeof(int) * 2, hipMemcpyDeviceToHost, stream));
+    GS_HIP_CHECK(hipStreamSynchronize(stream));
+    GS_REQUIRE(jhost[1] == 0, GS_ENOCONV, "faithful: the k x k Jacobi solve hit its sweep limit");
+    h->last_sweeps = jhost[0];
+    hipLaunchKernelGGL(signfix_rows_kernel, dim3((unsigned)ceil_div(k, 4)), dim3(256), 0, stream, h->Vk, n, dp, k);
+    hipLaunchKernelGGL(set_diag_kernel, dim3((unsigned)ceil_div(k, 64), (unsigned)k), dim3(64), 0, stream, h->Bk, h->lam, k);
+    hipLaunchKernelGGL(derive_outputs_kernel, dim3(1), dim3(256), 0, stream, h->lam, h->m2, (int)h->d, h->outs, k,
+                       (double)h->n_seen);
+    hipLaunchKernelGGL(to_f32_kernel, dim3((unsigned)ceil_div(h->d, 256), (unsigned)(k + 1)), dim3(256), 0, stream,
+                       h->Vk, h->mean, h->comp32, h->mean32, (int)h->d, dp, k);
+    GS_HIP_CHECK(hipGetLastError());
+    h->pending_diag = false;
     return GS_OK;
 }
 
@@ -448,6 +519,10 @@ int gs_ipca_create(int64_t d, int k, int mode, int precision, int device, gs_ipc
     alloc((void **)&h->vec, sizeof(double) * dp * 4);
     alloc((void **)&h->Vk, sizeof(double) * k * dp);
     alloc((void **)&h->lam, sizeof(double) * k);
+    if (mode == GS_MODE_FAITHFUL) {
+        alloc((void **)&h->Bk, sizeof(double) * k * k);
+        alloc((void **)&h->T, sizeof(double) * k * dp);
+    }
     alloc((void **)&h->scal, sizeof(double) * 8);
     alloc((void **)&h->outs, sizeof(double) * 3 * k);
     alloc((void **)&h->comp32, sizeof(float) * k * d);
@@ -468,7 +543,7 @@ int gs_ipca_destroy(gs_ipca_t *h) {
     smallside_free(h->ss);
     subspace_workspace_free(h->sws);
     void *ptrs[] = {h->shift, h->S1, h->G64, h->W,   h->mean,   h->m2,    h->vec, h->bs,
-                    h->Vk,    h->lam, h->scal, h->outs, h->comp32, h->mean32};
+                    h->Vk,    h->lam, h->scal, h->outs, h->comp32, h->mean32, h->Bk, h->T};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     delete h;
@@ -483,6 +558,9 @@ int gs_ipca_reset(gs_ipca_t *h) {
     h->gws.pend_valid = false;
     h->sws.guards_valid = false;
     h->sws.plan_valid = false;
+    h->sws.inv_plan = 0;
+    h->sws.inv_ratio1 = 0.0;
+    h->pending_diag = false;
     return GS_OK;
 }
 
@@ -539,12 +617,32 @@ int gs_ipca_update(gs_ipca_t *h, const float *X, int64_t rows, int64_t ld, void 
     const double n0 = (double)h->n_seen, m = (double)rows;
     hipLaunchKernelGGL(faithful_stats_kernel, dim3((unsigned)ceil_div(d, 256)), dim3(256), 0, stream, h->S1,
                        h->shift, h->mean, h->vec, d, dp, n0, m);
+    if (n0 > 0)   // T = Bk Vk
+        gemm_f64(h->k, dp, h->k, h->Bk, h->k, 1, h->Vk, dp, 1, h->T, dp, stream, 1.0, 0.0, GemmEpilogue(), false);
     hipLaunchKernelGGL(faithful_assemble_kernel, dim3((unsigned)ceil_div(d, 256), (unsigned)d), dim3(256), 0,
-                       stream, h->G64, h->vec, h->Vk, h->lam, h->W, h->m2, d, dp, h->k, n0, m);
+                       stream, h->G64, h->vec, h->Vk, h->T, h->W, h->m2, d, dp, h->k, n0, m);
     h->n_seen += rows;
     h->blocks += 1;
-    rc = solve_topk(h, /*warm=*/n0 > 0, h->m2, d, stream);
-    if (rc != GS_OK) return rc;
+    // From the fifth block on the k leading eigenvalues of W sit (n0 / m + 1) times above the rest: carry the
+    // invariant subspace by orthogonal iteration and leave the diagonalisation to whoever reads the components.
+    static const bool eager = getenv("GS_FAITHFUL_EAGER") != nullptr;
+    bool carried = false;
+    if (!eager && h->sws.Q != nullptr && h->k <= 128 && n0 >= 4.0 * m) {
+        int mults = 0, converged = 0;
+        rc = invsub_iterate(h->sws, h->W, h->n2, dp, h->k, h->Vk, dp, h->Bk, h->k, n0 / m, &mults, &converged, stream);
+        if (rc != GS_OK) return rc;
+        if (converged) {
+            carried = true;
+            h->pending_diag = true;
+            h->last_mults = mults;
+            h->last_sweeps = 0;
+            h->sws.guards_valid = false;   // the Rayleigh-Ritz solver's guard columns belong to an older matrix
+        }
+    }
+    if (!carried) {
+        rc = solve_topk(h, /*warm=*/n0 > 0, h->m2, d, stream);
+        if (rc != GS_OK) return rc;
+    }
     hipLaunchKernelGGL(mean_to_shift_kernel, dim3((unsigned)ceil_div(dp, 256)), dim3(256), 0, stream, h->mean,
                        h->shift, d, dp);
     GS_HIP_CHECK(hipGetLastError());
@@ -619,6 +717,10 @@ int gs_ipca_finalize(gs_ipca_t *h, float *components_host, double *singular_valu
         h->finalized = true;
     }
     GS_REQUIRE(h->finalized, GS_ESTATE, "gs_ipca_finalize: nothing fitted");
+    if (h->pending_diag) {
+        int rc = faithful_materialize(h, stream);
+        if (rc != GS_OK) return rc;
+    }
     std::vector<double> outs(3 * (size_t)k);
     GS_HIP_CHECK(hipMemcpyAsync(outs.data(), h->outs, sizeof(double) * 3 * k, hipMemcpyDeviceToHost, stream));
     if (components_host)
@@ -647,7 +749,7 @@ int gs_ipca_last_mults(const gs_ipca_t *h) { return h ? h->last_mults : GS_EINVA
 
 int gs_ipca_components_device(gs_ipca_t *h, const float **components, const float **mean) {
     GS_REQUIRE(h != nullptr, GS_EINVAL, "gs_ipca_components_device: NULL handle");
-    GS_REQUIRE(h->finalized, GS_ESTATE, "gs_ipca_components_device: call finalize first");
+    GS_REQUIRE(h->finalized && !h->pending_diag, GS_ESTATE, "gs_ipca_components_device: call finalize first");
     if (components) *components = h->comp32;
     if (mean) *mean = h->mean32;
     return GS_OK;

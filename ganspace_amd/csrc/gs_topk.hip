@@ -677,6 +677,157 @@ int orth_fast(SubspaceWorkspace &ws, const double *Y, double *Qout, int n, int p
     return trsm_rows_launch(Y, Qout, ld, n, p, ws.Rm, ws.Dinv, stream);
 }
 
+// ---- invariant-subspace iteration (faithful recurrence, diagonalisation deferred) ------------------------------
+__global__ __launch_bounds__(256) void invsub_resid_kernel(const double *__restrict__ Y, const double *__restrict__ Z,
+                                                           int64_t ld, const double *__restrict__ B, int64_t ldb, int n,
+                                                           double *__restrict__ resid, double *__restrict__ bdiag) {
+    __shared__ double scr[256];
+    const int c = blockIdx.x;
+    double s = 0;
+    for (int r = threadIdx.x; r < n; r += 256) {
+        const double v = Y[(int64_t)r * ld + c] - Z[(int64_t)r * ld + c];
+        s += v * v;
+    }
+    scr[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) scr[threadIdx.x] += scr[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        resid[c] = scr[0];
+        bdiag[c] = B[(int64_t)c * ldb + c];
+    }
+}
+
+// Vk rows <- columns of Q (zero beyond n), Bk <- (B + B^T) / 2
+__global__ void invsub_emit_kernel(const double *__restrict__ Q, int64_t ld, int n, int k, double *__restrict__ Vk,
+                                   int64_t ldv, const double *__restrict__ B, int64_t ldb, double *__restrict__ Bk,
+                                   int64_t ldbk) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = blockIdx.y;
+    if (e < ldv) Vk[(int64_t)i * ldv + e] = (e < n) ? Q[(int64_t)e * ld + i] : 0.0;
+    if (e < k) Bk[(int64_t)i * ldbk + e] = 0.5 * (B[(int64_t)i * ldb + e] + B[(int64_t)e * ldb + i]);
+}
+
+int invsub_iterate(SubspaceWorkspace &ws, const double *A, int n, int64_t lda, int k, double *Vk, int64_t ldv,
+                   double *Bk, int64_t ldbk, double blocks_seen, int *mults_out, int *converged, hipStream_t stream) {
+    GS_REQUIRE(k >= 1 && k <= kCholP && k <= ws.p_cap && n <= ws.n_cap && blocks_seen >= 1.0, GS_EINVAL,
+               "invsub_iterate: bad sizes");
+    const int64_t ld = ws.pp;
+    const double tol_rel = 1e-9;
+    double *buf[4] = {ws.Q, ws.Y, ws.Z, ws.R};
+    GemmEpilogue none;
+    *converged = 0;
+    if (mults_out) *mults_out = 0;
+    const double ln_gap = std::log(blocks_seen + 1.0);   // lambda_k / lambda_{k+1} >= t + 1
+    int P = ws.inv_plan > 0 ? ws.inv_plan : (int)std::ceil(std::log(1.0 / tol_rel) / ln_gap);
+    P = P < 1 ? 1 : (P > 24 ? 24 : P);
+    // products chained between two CholeskyQR steps: the block's condition grows like (lambda_1 / lambda_k)^j, and
+    // CholeskyQR squares it once more - keep it below 1e5 (first call: unknown spectrum, every product)
+    int j = 1;
+    if (ws.inv_ratio1 > 1.0) {
+        const double jf = std::floor(std::log(1e5) / std::log(ws.inv_ratio1 > 1.0001 ? ws.inv_ratio1 : 1.0001));
+        j = jf < 1.0 ? 1 : (jf > 4.0 ? 4 : (int)jf);
+    }
+    // each CholeskyQR step costs about five products; past eight of them the Chebyshev + Rayleigh-Ritz solver wins
+    // (an unknown spectrum pays one block of single products to measure lambda_1 / lambda_k)
+    if (ws.inv_ratio1 > 1.0 ? ceil_div(P, j) > 8 : P > 16) {
+        ws.inv_plan = 0;
+        return GS_OK;
+    }
+    hipLaunchKernelGGL(topk_seed_kernel, dim3((unsigned)ceil_div(k, 64), (unsigned)n), dim3(64), 0, stream, buf[0], n, ld,
+                       Vk, k, ldv);
+    int q = 0, used = 0;
+    const int P0 = P;
+    std::vector<double> host(3 * (size_t)ws.pp);
+    for (int attempt = 0; attempt < 3; ++attempt) {
+        int rem = P, jj_last = 1;
+        while (rem > 0) {
+            const int jj = j < rem ? j : rem;
+            int cur = q;
+            for (int s = 0; s < jj; ++s) {
+                const int nxt = (cur + 1) & 3;
+                gemm_f64(n, k, n, A, lda, 1, buf[cur], ld, 1, buf[nxt], ld, stream, 1.0, 0.0, none, true);
+                cur = nxt;
+                ++used;
+            }
+            const int o = (cur + 1) & 3;
+            int rc = orth_fast(ws, buf[cur], buf[o], n, k, stream);   // R diagonal -> theta + 2 pp
+            if (rc != GS_OK) return rc;
+            q = o;
+            rem -= jj;
+            jj_last = jj;
+        }
+        // a second pass when the first one cannot have left the basis orthonormal to ~1e-12 (cond^2 eps)
+        const bool pass2 = !(ws.inv_ratio1 > 1.0) || std::pow(ws.inv_ratio1, 2.0 * jj_last) * 1e-16 > 1e-12;
+        if (pass2) {
+            const int o = (q + 1) & 3;
+            gemm_f64(k, k, n, buf[q], 1, ld, buf[q], ld, 1, ws.H, ld, stream, 1.0, 0.0, none, true);
+            int rc = chol_blocked_launch(ws.H, ld, k, ws.Rm, ld, ws.Dinv, ws.theta, stream);   // keeps theta + 2 pp
+            if (rc != GS_OK) return rc;
+            rc = trsm_rows_launch(buf[q], buf[o], ld, n, k, ws.Rm, ws.Dinv, stream);
+            if (rc != GS_OK) return rc;
+            q = o;
+        }
+        const int y = (q + 1) & 3, z = (q + 2) & 3;
+        gemm_f64(n, k, n, A, lda, 1, buf[q], ld, 1, buf[y], ld, stream, 1.0, 0.0, none, true);     // Y = A Q
+        ++used;
+        gemm_f64(k, k, n, buf[q], 1, ld, buf[y], ld, 1, ws.B, ld, stream, 1.0, 0.0, none, true);   // B = Q^T Y
+        gemm_f64(n, k, k, buf[q], ld, 1, ws.B, ld, 1, buf[z], ld, stream, 1.0, 0.0, none, false);  // Z = Q B
+        hipLaunchKernelGGL(invsub_resid_kernel, dim3((unsigned)k), dim3(256), 0, stream, buf[y], buf[z], ld, ws.B, ld, n,
+                           ws.theta + ws.pp, ws.theta);
+        GS_HIP_CHECK(hipMemcpyAsync(host.data(), ws.theta, sizeof(double) * 3 * ws.pp, hipMemcpyDeviceToHost, stream));
+        GS_HIP_CHECK(hipStreamSynchronize(stream));
+        const double *bdiag = host.data(), *resid = host.data() + ws.pp, *rdiag = host.data() + 2 * ws.pp;
+        double th1 = 0.0, worst2 = 0.0, rmax = 0.0, rmin = 1e300;
+        bool sane = true;
+        for (int i = 0; i < k; ++i) {
+            if (!(resid[i] == resid[i]) || !(rdiag[i] > 0.0)) sane = false;   // NaN, or a dead pivot (rank lost)
+            th1 = bdiag[i] > th1 ? bdiag[i] : th1;
+            worst2 = resid[i] > worst2 ? resid[i] : worst2;
+            rmax = rdiag[i] > rmax ? rdiag[i] : rmax;
+            rmin = rdiag[i] < rmin ? rdiag[i] : rmin;
+        }
+        if (!sane || !(th1 > 0.0)) break;
+        // R_ii ~ lambda_i^jj after jj products: the target is relative to the SMALLEST wanted eigenvalue (the subspace
+        // is carried from block to block; an error relative to lambda_1 would swamp the trailing components of a
+        // steep spectrum), floored at what float64 products can resolve
+        const double lamk = std::pow(rmin, 1.0 / jj_last);
+        const double ratio1 = std::pow(rmax / rmin, 1.0 / jj_last);
+        double target = tol_rel * lamk;
+        if (target < 3e-14 * th1) target = 3e-14 * th1;
+        const double rel = std::sqrt(worst2) / target;
+        ws.inv_ratio1 = ratio1;
+        static const bool debug = getenv("GS_TOPK_DEBUG") != nullptr;
+        if (debug)
+            fprintf(stderr, "invsub: t=%.0f attempt=%d P=%d j=%d pass2=%d used=%d rel=%.2e ratio1=%.2e lamk/th1=%.2e\n",
+                    blocks_seen, attempt, P, j, (int)pass2, used, rel, ratio1, lamk / th1);
+        if (rel <= 1.0) {
+            *converged = 1;
+            hipLaunchKernelGGL(invsub_emit_kernel, dim3((unsigned)ceil_div((int)(ldv > k ? ldv : k), 256), (unsigned)k),
+                               dim3(256), 0, stream, buf[q], ld, n, k, Vk, ldv, ws.B, ld, Bk, ldbk);
+            GS_HIP_CHECK(hipGetLastError());
+            if (attempt == 0) {
+                // a wide margin shortens the next block's schedule (its gap is wider still)
+                int dec = 0;
+                if (rel < 1.0 / 30.0) dec = (int)std::floor(std::log(1.0 / (30.0 * (rel > 1e-7 ? rel : 1e-7))) / ln_gap);
+                ws.inv_plan = P0 - dec > 1 ? P0 - dec : 1;
+            } else {
+                ws.inv_plan = used - 1;
+            }
+            break;
+        }
+        if (attempt == 2) break;
+        const double need = std::ceil(std::log(10.0 * rel) / ln_gap);
+        P = need < 1.0 ? 1 : (need > 12.0 ? 12 : (int)need);
+    }
+    if (!*converged) ws.inv_plan = 0;
+    ws.inv_last_products = used;
+    if (mults_out) *mults_out = used;
+    return GS_OK;
+}
+
 static double cheb_T(int m, double x) { return x <= 1.0 ? 1.0 : std::cosh((double)m * std::acosh(x)); }
 
 // Same contract as eigh_topk_subspace (gs_subspace.hip); requires subspace_dim(n, k) <= 128.

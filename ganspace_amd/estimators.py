@@ -174,6 +174,7 @@ class _DeviceIncrementalPCA:
         torch = _torch()
         self._results()
         Xd = self._as_device_rows(X)
+        self._results()                    # finalizes (the faithful mode defers its diagonalisation until here)
         comp, mean = C.c_void_p(), C.c_void_p()
         _lib.check(self._lib.gs_ipca_components_device(self._h, C.byref(comp), C.byref(mean)))
         k, d = self.n_components, self._d

@@ -557,3 +557,43 @@ def test_feature_count_mismatch_and_bad_k_raise(dev):
         est.transformer.partial_fit(torch.randn(16, 40, device=dev))      # sklearn: feature-count change
     est2 = get_estimator("ipca", 64, 1.0)
     assert est2.fit_partial(torch.randn(128, 32, device=dev)) is False     # k > n_features -> ValueError -> False
+
+
+@pytest.mark.parametrize("d,k,decay,probe", [(256, 40, 1.0, False), (256, 40, 3.0, False), (192, 21, 1.5, True),
+                                              (512, 80, 1.0, True)])
+def test_faithful_many_blocks_deferred_diagonalisation_matches_oracle(dev, d, k, decay, probe):
+    """From the fifth block on the faithful mode carries (basis, k x k matrix) instead of diagonalising every block
+    (gs_ipca.hip / invsub_iterate): the recurrence - sklearn's truncation to the k leading directions after every
+    block - must come out the same as the oracle's block-by-block eigendecomposition, whether the components are
+    only read at the end or also in the middle of the stream (which folds the pending rotation into the state)."""
+    from ganspace_amd import _lib
+    from ganspace_amd.estimators import get_estimator
+    lib = _lib.load()
+    rng = np.random.default_rng(7)
+    basis = np.linalg.qr(rng.standard_normal((d, d)))[0] * np.sqrt((1.0 / np.arange(1, d + 1)) ** decay)
+    blocks = [(rng.standard_normal((700, d)) @ basis.T + 0.25).astype(np.float32) for _ in range(16)]
+    est = get_estimator("ipca", k, 1.0)
+    orc = O.IPCAEstimatorOracle(k, "gram")
+    carried = 0
+    for i, X in enumerate(blocks):
+        assert est.fit_partial(torch.from_numpy(X).to(dev)) is True
+        orc.fit_partial(X)
+        h = est.transformer._h
+        carried += int(lib.gs_ipca_last_sweeps(h) == 0 and lib.gs_ipca_last_mults(h) > 0)
+        if probe and i in (6, 11):
+            mid = est.get_components()[0]
+            sv = orc.transformer.singular_values_
+            live = sv > 1e-3 * sv[0]
+            assert O.signed_cosines(mid[live], orc.transformer.components_[live]).min() > 1 - 2e-6, i
+    if decay <= 1.5:
+        assert carried >= 8, carried          # blocks 5.. take the deferred path on a gently decaying spectrum
+    comp = est.get_components()[0]
+    sv, svo = est.transformer.singular_values_, orc.transformer.singular_values_
+    live = svo > 1e-3 * svo[0]
+    cos = O.signed_cosines(comp[live], orc.transformer.components_[live])
+    assert cos.min() > 1 - 2e-6, cos.min()
+    np.testing.assert_allclose(sv[live], svo[live], rtol=1e-4)
+    np.testing.assert_allclose(sv, svo, atol=5e-4 * svo[0])
+    np.testing.assert_allclose(est.transformer.explained_variance_ratio_[live],
+                               orc.transformer.explained_variance_ratio_[live], rtol=2e-4)
+    np.testing.assert_allclose(est.transformer.mean_, orc.transformer.mean_, atol=2e-6)
