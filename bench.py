@@ -254,6 +254,25 @@ def main():
         out["cos_sim_vs_reference"] = cos
         out["vs_cpu_baseline"] = round(value / out["cpu_baseline"]["value"], 1)
 
+        # ---- the same job in the sklearn-faithful mode (the reference's own recurrence: truncation to k components
+        #      after every block), whole n ------------------------------------------------------------------------
+        if args.mode == "exact":
+            ef = IPCAEstimator(K_COMP, "faithful")
+            for b in blocks[:BLOCKS_PER_STEP * max(1, Wm)]:
+                ef.fit_partial(b)
+            ef.get_components()
+            ef = IPCAEstimator(K_COMP, "faithful")
+            ef.transformer._ensure(D)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for b in blocks:
+                ef.fit_partial(b)
+            ef.get_components()
+            torch.cuda.synchronize()
+            tf_ = time.perf_counter() - t0
+            out["faithful_mode_same_job"] = {"samples_per_s": round(n_blocks * NB / tf_, 1),
+                                             "ms_per_block": round(tf_ / n_blocks * 1e3, 4), "blocks": n_blocks}
+
         # ---- opt-in split-bf16 contraction modes (precision="bf16x6" / "bf16x3"; the headline stays exact f32):
         #      same job, same timed region; cos-sim against the same sklearn reference sample ------------------
         if args.mode == "exact":

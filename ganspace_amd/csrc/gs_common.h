@@ -160,8 +160,10 @@ int eigh_topk_cheb(SubspaceWorkspace &ws, const double *A, int n, int64_t lda, i
 // (*converged = 1) Vk holds an orthonormal basis of the leading invariant subspace (rows) and Bk = Vk A Vk^T
 // (k x k, symmetric, NOT diagonal).  *converged = 0 (Vk, Bk untouched): the schedule would cost more than the
 // Rayleigh-Ritz solver, or the residual target was missed - the caller falls back to eigh_topk_subspace.
+// identity_start: Q0 = the first k unit vectors (small side: the leading k x k block of T is the old state).
 int invsub_iterate(SubspaceWorkspace &ws, const double *A, int n, int64_t lda, int k, double *Vk, int64_t ldv,
-                   double *Bk, int64_t ldbk, double blocks_seen, int *mults_out, int *converged, hipStream_t stream);
+                   double *Bk, int64_t ldbk, double blocks_seen, int *mults_out, int *converged, hipStream_t stream,
+                   bool identity_start = false);
 
 // ---- small-side recurrence for d >> m: gs_smallside.hip -------------------------------------------
 struct SmallSide {
@@ -181,10 +183,18 @@ struct SmallSide {
     double *Uk = nullptr;    // [k][rp] leading eigenvectors of T (rows)
     double *wk = nullptr;    // [k]     leading eigenvalues of T
     int last_mults = 0;
+    // diagonalisation deferred (see invsub_iterate): the caller's V then holds W = Q^T M (k x d, W W^T = Bk, the
+    // truncated operator in an undiagonalised basis) instead of unit components, and lam is stale
+    bool w_state = false;
+    int last_r = 0;          // rows of M in the last update
+    double *Bk = nullptr;    // [k][k]   Q^T T Q of the last deferred block
+    double *Qc = nullptr;    // [rp][kp] Q U scratch of smallside_materialize
 };
 int smallside_alloc(SmallSide &ss, int64_t d, int k, int m);
 void smallside_free(SmallSide &ss);
 int smallside_update(SmallSide &ss, const float *X, int64_t rows, int64_t ldx, double n0, float *V, double *lam,
                      double *mean, double *m2, double *vec, double *bs, int *sweeps_out, hipStream_t stream);
+// w_state -> unit components in V (sklearn's sign convention) and their eigenvalues in lam
+int smallside_materialize(SmallSide &ss, float *V, double *lam, int *sweeps_out, hipStream_t stream);
 
 }  // namespace gs

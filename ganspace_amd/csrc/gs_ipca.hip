@@ -560,6 +560,9 @@ int gs_ipca_reset(gs_ipca_t *h) {
     h->sws.plan_valid = false;
     h->sws.inv_plan = 0;
     h->sws.inv_ratio1 = 0.0;
+    h->ss.sws.inv_plan = 0;
+    h->ss.sws.inv_ratio1 = 0.0;
+    h->ss.w_state = false;
     h->pending_diag = false;
     return GS_OK;
 }
@@ -590,6 +593,7 @@ int gs_ipca_update(gs_ipca_t *h, const float *X, int64_t rows, int64_t ld, void 
         h->last_mults = h->ss.last_mults;
         h->n_seen += rows;
         h->blocks += 1;
+        h->pending_diag = h->ss.w_state;    // comp32 holds W, lam is stale: gs_ipca_finalize materialises
         hipLaunchKernelGGL(derive_outputs_kernel, dim3(1), dim3(256), 0, stream, h->lam, h->m2, (int)h->d, h->outs,
                            h->k, (double)h->n_seen);
         hipLaunchKernelGGL(to_f32_kernel, dim3((unsigned)ceil_div(h->d, 256), 1), dim3(256), 0, stream,
@@ -717,7 +721,14 @@ int gs_ipca_finalize(gs_ipca_t *h, float *components_host, double *singular_valu
         h->finalized = true;
     }
     GS_REQUIRE(h->finalized, GS_ESTATE, "gs_ipca_finalize: nothing fitted");
-    if (h->pending_diag) {
+    if (h->pending_diag && h->mode == GS_MODE_SMALLSIDE) {
+        int rc = smallside_materialize(h->ss, h->comp32, h->lam, &h->last_sweeps, stream);
+        if (rc != GS_OK) return rc;
+        hipLaunchKernelGGL(derive_outputs_kernel, dim3(1), dim3(256), 0, stream, h->lam, h->m2, (int)h->d, h->outs,
+                           h->k, (double)h->n_seen);
+        GS_HIP_CHECK(hipGetLastError());
+        h->pending_diag = false;
+    } else if (h->pending_diag) {
         int rc = faithful_materialize(h, stream);
         if (rc != GS_OK) return rc;
     }

@@ -457,13 +457,14 @@ __global__ __launch_bounds__(256, 2) void tn_gemm_kernel(const float *__restrict
 // rows [0,k): S_t V_t ; [k, k+m): X - bm ; k+m: mc ; beyond: zero.   vec = [bm | mc | delta] (float64)
 __global__ void ss_build_kernel(const float *__restrict__ X, int64_t ldx, int m, const float *__restrict__ V,
                                 const double *__restrict__ lam, const double *__restrict__ vec, int64_t d,
-                                int k, int rp, double n0, float *__restrict__ M) {
+                                int k, int rp, double n0, float *__restrict__ M, int w_state) {
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int t = blockIdx.y;
     if (j >= d) return;
     float v = 0.f;
     if (t < k) {
-        if (n0 > 0) v = (float)(sqrt(lam[t]) * (double)V[(int64_t)t * d + j]);
+        // w_state: V already holds the rows whose Gram matrix is the truncated operator (W = Q^T M of the last block)
+        if (n0 > 0) v = w_state ? V[(int64_t)t * d + j] : (float)(sqrt(lam[t]) * (double)V[(int64_t)t * d + j]);
     } else if (t < k + m) {
         v = (float)((double)X[(int64_t)(t - k) * ldx + j] - vec[j]);
     } else if (t == k + m) {
@@ -556,6 +557,33 @@ __global__ void ss_coef_rows_kernel(const double *__restrict__ Uk, int64_t ldu, 
     if (t == 0) lam[i] = dead ? 0.0 : w;
 }
 
+// Ct[t][i] = Q[t][i] from the ROWS Uk[i][:] of an orthonormal basis (deferred diagonalisation: no scaling)
+__global__ void ss_coef_plain_kernel(const double *__restrict__ Uk, int64_t ldu, int r, int rp, int k, int kp,
+                                     float *__restrict__ Ct) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = blockIdx.y;
+    if (i >= k || t >= rp) return;
+    Ct[(int64_t)t * kp + i] = (t < r) ? (float)Uk[(int64_t)i * ldu + t] : 0.f;
+}
+
+// Ct[t][i] = (Q U)[t][i] / sqrt(theta_i), lam = theta  (smallside_materialize)
+__global__ void ss_coef_scaled_kernel(const double *__restrict__ Qc, int64_t ldq, const double *__restrict__ theta, int r,
+                                      int rp, int k, int kp, float *__restrict__ Ct, double *__restrict__ lam) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = blockIdx.y;
+    if (i >= k || t >= rp) return;
+    const double w = theta[i];
+    const bool dead = !(w > theta[0] * 1e-13);
+    Ct[(int64_t)t * kp + i] = (dead || t >= r) ? 0.f : (float)(Qc[(int64_t)t * ldq + i] / sqrt(w));
+    if (t == 0) lam[i] = dead ? 0.0 : w;
+}
+
+__global__ void ss_pad_copy_kernel(const double *__restrict__ Bk, int k, double *__restrict__ out, int64_t ldo, int pj) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = blockIdx.y;
+    if (j < pj) out[(int64_t)i * ldo + j] = (i < k && j < k) ? Bk[(int64_t)i * k + j] : 0.0;
+}
+
 // per row: sign of the largest-magnitude entry (first index wins ties), V[i] = sign * Vtmp[i]
 __global__ __launch_bounds__(1024) void ss_sign_kernel(const float *__restrict__ Vtmp, int64_t ldv,
                                                        float *__restrict__ V, int64_t d) {
@@ -641,12 +669,14 @@ int smallside_alloc(SmallSide &ss, int64_t d, int k, int m) {
     if (rc == GS_OK) rc = eigh_workspace_alloc(ss.ews, ss.rp + 2);
     if (rc == GS_OK) rc = alloc((void **)&ss.Uk, sizeof(double) * (size_t)k * ss.rp);
     if (rc == GS_OK) rc = alloc((void **)&ss.wk, sizeof(double) * (size_t)k);
+    if (rc == GS_OK) rc = alloc((void **)&ss.Bk, sizeof(double) * (size_t)k * k);
+    if (rc == GS_OK) rc = alloc((void **)&ss.Qc, sizeof(double) * (size_t)ss.rp * ss.kp);
     if (rc == GS_OK && subspace_dim(ss.r_cap, k) > 0) rc = subspace_workspace_alloc(ss.sws, ss.rp, subspace_dim(ss.r_cap, k));
     return rc;
 }
 
 void smallside_free(SmallSide &ss) {
-    void *ptrs[] = {ss.M, ss.T, ss.slab, ss.Ct, ss.Vtmp, ss.colsq, ss.Uk, ss.wk, ss.tile_order};
+    void *ptrs[] = {ss.M, ss.T, ss.slab, ss.Ct, ss.Vtmp, ss.colsq, ss.Uk, ss.wk, ss.tile_order, ss.Bk, ss.Qc};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     eigh_workspace_free(ss.ews);
@@ -670,7 +700,8 @@ int smallside_update(SmallSide &ss, const float *X, int64_t rows, int64_t ldx, d
     hipLaunchKernelGGL(ss_stats_kernel, dim3(gd), dim3(256), 0, stream, bs, mean, vec, d, n0, (double)m);
     // 2. M = [S V ; X - bm ; mc ; 0]
     hipLaunchKernelGGL(ss_build_kernel, dim3(gd, (unsigned)rp), dim3(256), 0, stream, X, ldx, m, V, lam, vec, d, k,
-                       rp, n0, ss.M);
+                       rp, n0, ss.M, ss.w_state ? 1 : 0);
+    ss.last_r = r;
     // 3. per-feature sum of squared deviations of this block -> variance update
     hipLaunchKernelGGL(ss_colsq_kernel, dim3((unsigned)ceil_div(d, 32), (unsigned)ceil_div(m, 256)), dim3(256), 0,
                        stream, ss.M, d, rp, k, m, ss.colsq, 256);
@@ -731,6 +762,30 @@ int smallside_update(SmallSide &ss, const float *X, int64_t rows, int64_t ldx, d
     bool done = false;
     ss.last_mults = 0;
     static const bool no_subspace = getenv("GS_EIGH_FULL") != nullptr;
+    static const bool eager = getenv("GS_FAITHFUL_EAGER") != nullptr;
+    const int64_t ntn = ceil_div(d, kRT);
+    // From the fifth block on: carry W = Q^T M for an orthonormal basis Q of T's leading invariant subspace (rows
+    // whose Gram matrix is the truncated operator - exactly what the next block stacks on top of its data) and leave
+    // the diagonalisation to smallside_materialize.
+    if (ss.sws.Q != nullptr && !no_subspace && !eager && k <= 128 && k <= ss.sws.p_cap && n0 >= 4.0 * m) {
+        int mults = 0, converged = 0;
+        rc = invsub_iterate(ss.sws, ss.T, r, rp, k, ss.Uk, rp, ss.Bk, k, n0 / m, &mults, &converged, stream,
+                            /*identity_start=*/true);
+        if (rc != GS_OK) return rc;
+        if (converged) {
+            hipLaunchKernelGGL(ss_coef_plain_kernel, dim3((unsigned)ceil_div(rp, 256), (unsigned)k), dim3(256), 0, stream,
+                               ss.Uk, (int64_t)rp, r, rp, k, kp, ss.Ct);
+            hipLaunchKernelGGL(tn_gemm_kernel, dim3((unsigned)((kp / kRT) * ntn)), dim3(256), 0, stream, ss.Ct, kp, ss.M, d,
+                               (int64_t)rp, r, ss.Vtmp, d);
+            GS_HIP_CHECK(hipMemcpyAsync(V, ss.Vtmp, sizeof(float) * (size_t)k * d, hipMemcpyDeviceToDevice, stream));
+            GS_HIP_CHECK(hipGetLastError());
+            ss.last_mults = mults;
+            ss.w_state = true;
+            if (sweeps_out) *sweeps_out = 0;
+            return GS_OK;
+        }
+    }
+    ss.w_state = false;    // the Rayleigh-Ritz paths below return unit components and their eigenvalues
     if (ss.sws.Q != nullptr && subspace_dim(r, k) > 0 && !no_subspace) {
         int mults = 0, converged = 0;
         rc = eigh_topk_subspace(ss.sws, ss.T, r, rp, k, nullptr, n0 > 0 ? k : 0, 0, ss.Uk, rp, ss.wk, &mults,
@@ -754,11 +809,40 @@ int smallside_update(SmallSide &ss, const float *X, int64_t rows, int64_t ldx, d
                            lam);
     }
     // 6. V' = Ct^T M, sign convention
-    const int64_t ntn = ceil_div(d, kRT);
     hipLaunchKernelGGL(tn_gemm_kernel, dim3((unsigned)((kp / kRT) * ntn)), dim3(256), 0, stream, ss.Ct, kp, ss.M, d,
                        (int64_t)rp, r, ss.Vtmp, d);
     hipLaunchKernelGGL(ss_sign_kernel, dim3((unsigned)k), dim3(1024), 0, stream, ss.Vtmp, d, V, d);
     GS_HIP_CHECK(hipGetLastError());
+    return GS_OK;
+}
+
+int smallside_materialize(SmallSide &ss, float *V, double *lam, int *sweeps_out, hipStream_t stream) {
+    if (!ss.w_state) return GS_OK;
+    const int k = ss.k, rp = ss.rp, kp = ss.kp, r = ss.last_r;
+    const int64_t d = ss.d;
+    SubspaceWorkspace &ws = ss.sws;
+    const int pj = (int)round_up(k, 8);
+    const int64_t ld = ws.pp;
+    int *jinfo = ws.ews.rank;
+    // Bk = Q^T T Q = U diag(theta) U^T: the components are diag(theta)^-1/2 (Q U)^T M with the M of the last block
+    hipLaunchKernelGGL(ss_pad_copy_kernel, dim3((unsigned)ceil_div(pj, 64), (unsigned)pj), dim3(64), 0, stream, ss.Bk, k,
+                       ws.B, ld, pj);
+    int rc = jacobi_small_launch(ws.B, ld, pj, ws.U, ld, ws.theta, jinfo, stream);
+    if (rc != GS_OK) return rc;
+    gemm_f64(r, k, k, ss.Uk, 1, rp, ws.U, ld, 1, ss.Qc, kp, stream, 1.0, 0.0, GemmEpilogue(), false);
+    GS_HIP_CHECK(hipMemsetAsync(ss.Ct, 0, sizeof(float) * (size_t)rp * kp, stream));
+    hipLaunchKernelGGL(ss_coef_scaled_kernel, dim3((unsigned)ceil_div(rp, 256), (unsigned)k), dim3(256), 0, stream, ss.Qc,
+                       (int64_t)kp, ws.theta, r, rp, k, kp, ss.Ct, lam);
+    const int64_t ntn = ceil_div(d, kRT);
+    hipLaunchKernelGGL(tn_gemm_kernel, dim3((unsigned)((kp / kRT) * ntn)), dim3(256), 0, stream, ss.Ct, kp, ss.M, d,
+                       (int64_t)rp, r, ss.Vtmp, d);
+    hipLaunchKernelGGL(ss_sign_kernel, dim3((unsigned)k), dim3(1024), 0, stream, ss.Vtmp, d, V, d);
+    int jhost[2] = {0, 0};
+    GS_HIP_CHECK(hipMemcpyAsync(jhost, jinfo, sizeof(int) * 2, hipMemcpyDeviceToHost, stream));
+    GS_HIP_CHECK(hipStreamSynchronize(stream));
+    GS_REQUIRE(jhost[1] == 0, GS_ENOCONV, "smallside: the k x k Jacobi solve hit its sweep limit");
+    if (sweeps_out) *sweeps_out = jhost[0];
+    ss.w_state = false;
     return GS_OK;
 }
 

@@ -711,7 +711,8 @@ __global__ void invsub_emit_kernel(const double *__restrict__ Q, int64_t ld, int
 }
 
 int invsub_iterate(SubspaceWorkspace &ws, const double *A, int n, int64_t lda, int k, double *Vk, int64_t ldv,
-                   double *Bk, int64_t ldbk, double blocks_seen, int *mults_out, int *converged, hipStream_t stream) {
+                   double *Bk, int64_t ldbk, double blocks_seen, int *mults_out, int *converged, hipStream_t stream,
+                   bool identity_start) {
     GS_REQUIRE(k >= 1 && k <= kCholP && k <= ws.p_cap && n <= ws.n_cap && blocks_seen >= 1.0, GS_EINVAL,
                "invsub_iterate: bad sizes");
     const int64_t ld = ws.pp;
@@ -737,7 +738,7 @@ int invsub_iterate(SubspaceWorkspace &ws, const double *A, int n, int64_t lda, i
         return GS_OK;
     }
     hipLaunchKernelGGL(topk_seed_kernel, dim3((unsigned)ceil_div(k, 64), (unsigned)n), dim3(64), 0, stream, buf[0], n, ld,
-                       Vk, k, ldv);
+                       identity_start ? (const double *)nullptr : Vk, k, ldv);
     int q = 0, used = 0;
     const int P0 = P;
     std::vector<double> host(3 * (size_t)ws.pp);

@@ -597,3 +597,40 @@ def test_faithful_many_blocks_deferred_diagonalisation_matches_oracle(dev, d, k,
     np.testing.assert_allclose(est.transformer.explained_variance_ratio_[live],
                                orc.transformer.explained_variance_ratio_[live], rtol=2e-4)
     np.testing.assert_allclose(est.transformer.mean_, orc.transformer.mean_, atol=2e-6)
+
+
+@pytest.mark.parametrize("precision,cos_tol", [("f32", 3e-6), ("bf16x6", 8e-6)])
+@pytest.mark.parametrize("d,k,rows,decay,probe", [(6000, 24, 400, 1.0, False), (3000, 21, 300, 2.0, True)])
+def test_smallside_many_blocks_deferred_diagonalisation_matches_oracle(dev, d, k, rows, decay, probe, precision, cos_tol):
+    """Small side (T = M M^T) with the diagonalisation deferred: from the fifth block on the state is W = Q^T M
+    (gs_smallside.hip).  Checked against the sklearn-recurrence oracle (SVD of the stacked matrix), read at the end
+    and, in the probing variant, in mid-stream (which folds the pending rotation back into unit components)."""
+    from ganspace_amd import _lib
+    from ganspace_amd.estimators import IPCAEstimator
+    lib = _lib.load()
+    rng = np.random.default_rng(11)
+    latent = 96
+    A = rng.standard_normal((latent, d)) * np.sqrt((1.0 / np.arange(1, latent + 1)) ** decay)[:, None]
+    blocks = [(rng.standard_normal((rows, latent)) @ A + 0.02 * rng.standard_normal((rows, d)) + 0.1).astype(np.float32)
+              for _ in range(14)]
+    est = IPCAEstimator(k, "smallside", precision=precision)
+    orc = O.IPCAEstimatorOracle(k, "svd")
+    carried = 0
+    for i, X in enumerate(blocks):
+        assert est.fit_partial(torch.from_numpy(X).to(dev)) is True
+        orc.fit_partial(X)
+        h = est.transformer._h
+        carried += int(i >= 4 and lib.gs_ipca_last_sweeps(h) == 0 and lib.gs_ipca_last_mults(h) > 0)
+        if probe and i in (6, 10):
+            mid = est.get_components()[0]
+            assert O.signed_cosines(mid, orc.transformer.components_).min() > 1 - cos_tol, i
+    if decay <= 1.0:
+        assert carried >= 6, carried
+    comp = est.get_components()[0]
+    cos = O.signed_cosines(comp, orc.transformer.components_)
+    assert cos.min() > 1 - cos_tol, cos.min()
+    np.testing.assert_allclose(est.transformer.singular_values_, orc.transformer.singular_values_, rtol=2e-4)
+    np.testing.assert_allclose(est.transformer.explained_variance_ratio_, orc.transformer.explained_variance_ratio_,
+                               rtol=4e-4)
+    np.testing.assert_allclose(est.transformer.mean_, orc.transformer.mean_, atol=2e-6)
+    np.testing.assert_allclose(est.transformer.var_, orc.transformer.var_, rtol=1e-4)
