@@ -107,7 +107,10 @@ int     gs_state_recenter(double *state, int64_t d, const double *new_mean, void
  *     convention of sklearn svd_flip(u_based_decision=False) (extmath.py:943-951);
  *   singular_values/explained_variance/explained_variance_ratio [k] float64;
  *   mean/var [d] float64 (var = biased per-feature variance, sklearn var_);
- *   n_seen int64.  Synchronises `stream`.  EXACT mode runs the eigensolve here.         */
+ *   n_seen int64.  Synchronises `stream`.  EXACT mode runs the eigensolve here; FAITHFUL /
+ *   SMALLSIDE carry an undiagonalised basis of the k leading directions from block to block
+ *   once five blocks have been absorbed and run the (k x k) diagonalisation here - the
+ *   update may be continued afterwards (the recurrence does not depend on when it is read). */
 int gs_ipca_finalize(gs_ipca_t *h, float *components_host, double *singular_values_host,
                      double *mean_host, double *var_host, double *explained_variance_host,
                      double *explained_variance_ratio_host, int64_t *n_seen_host, void *stream);
@@ -117,8 +120,9 @@ int gs_ipca_last_sweeps(const gs_ipca_t *h);
 /* Multiplications by A used by the most recent top-k subspace solve (0 = the full Jacobi solver ran). */
 int gs_ipca_last_mults(const gs_ipca_t *h);
 
-/* Device-resident results of the last finalize/block close (float32 [k*d] components,
- * float32 [d] mean) for projection without a host round trip.                            */
+/* Device-resident results of the last finalize (float32 [k*d] components, float32 [d] mean)
+ * for projection without a host round trip.  GS_ESTATE while results are pending: call
+ * gs_ipca_finalize (all outputs may be NULL) after the last update first.                  */
 int gs_ipca_components_device(gs_ipca_t *h, const float **components, const float **mean);
 
 /* ---- building blocks exposed for unit tests / benches ------------------------------- */
