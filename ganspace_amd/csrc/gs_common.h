@@ -47,6 +47,7 @@ struct GramWorkspace {
     bool pend_valid = false;       // a slab set still waits to be folded
     int pend_buf = 0, pend_nchunks = 0;
     bool pend_acc = false;         // fold adds to (true) or overwrites (false) the accumulators
+    unsigned long long *pace = nullptr;   // [max_chunks][macro tiles] progress words (see FoldJob::pace)
 };
 
 int gram_workspace_alloc(GramWorkspace &ws, int64_t d);

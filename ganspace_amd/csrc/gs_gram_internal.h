@@ -97,6 +97,10 @@ struct FoldJob {
     double *G64, *S1;
     int nchunks, T32, ntiles, accumulate;
     unsigned long long *trace;  // profiling only
+    // pacing of the diagonal-tile workgroups of long chunks (gs_gram.hip): one progress word per (chunk, macro tile),
+    // values of this launch are pace_base + stages done (pace_base grows from launch to launch: no clearing)
+    unsigned long long *pace;
+    unsigned long long pace_base;
 };
 
 

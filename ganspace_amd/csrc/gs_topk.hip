@@ -722,7 +722,12 @@ int invsub_iterate(SubspaceWorkspace &ws, const double *A, int n, int64_t lda, i
     *converged = 0;
     if (mults_out) *mults_out = 0;
     const double ln_gap = std::log(blocks_seen + 1.0);   // lambda_k / lambda_{k+1} >= t + 1
-    int P = ws.inv_plan > 0 ? ws.inv_plan : (int)std::ceil(std::log(1.0 / tol_rel) / ln_gap);
+    // products that reach the target from an O(1) start if the gap is what the block count promises (the target is
+    // relative to lambda_k, the start residual to lambda_1); the schedule carried over from the previous block is
+    // usually shorter (its start is much better than O(1)), never longer
+    const double spread = ws.inv_ratio1 > 1.0 ? ws.inv_ratio1 : 1.0;
+    const int P_gap = (int)std::ceil(std::log(spread / tol_rel) / ln_gap);
+    int P = ws.inv_plan > 0 && ws.inv_plan < P_gap ? ws.inv_plan : P_gap;
     P = P < 1 ? 1 : (P > 24 ? 24 : P);
     // products chained between two CholeskyQR steps: the block's condition grows like (lambda_1 / lambda_k)^j, and
     // CholeskyQR squares it once more - keep it below 1e5 (first call: unknown spectrum, every product)

@@ -634,3 +634,40 @@ def test_smallside_many_blocks_deferred_diagonalisation_matches_oracle(dev, d, k
                                rtol=4e-4)
     np.testing.assert_allclose(est.transformer.mean_, orc.transformer.mean_, atol=2e-6)
     np.testing.assert_allclose(est.transformer.var_, orc.transformer.var_, rtol=1e-4)
+
+
+@pytest.mark.parametrize("case", ["shift", "lowrank", "tiny_late_blocks"])
+def test_faithful_deferred_path_falls_back_when_its_assumptions_break(dev, case):
+    """The carried-basis blocks assume a (t + 1)-fold gap behind lambda_k.  A distribution shift in mid-stream (new
+    directions 30x stronger than anything seen), data of rank < k (lambda_k = 0: dead pivots) and late blocks of a
+    handful of rows must all still reproduce the oracle's recurrence - through the retry / Rayleigh-Ritz fallback."""
+    from ganspace_amd.estimators import get_estimator
+    rng = np.random.default_rng(3)
+    d, k = 160, 16
+    Qb = np.linalg.qr(rng.standard_normal((d, d)))[0]
+    def draw(rows, cols, scale):
+        return (rng.standard_normal((rows, len(cols))) * scale) @ Qb[:, cols].T
+    blocks = []
+    for i in range(14):
+        if case == "shift":
+            X = draw(500, np.arange(0, 40), 1.0 / np.arange(1, 41)) if i < 8 else \
+                draw(500, np.arange(0, 40), 1.0 / np.arange(1, 41)) + draw(500, np.arange(60, 90), 30.0 / np.arange(1, 31))
+        elif case == "lowrank":
+            X = draw(400, np.arange(0, 10), 1.0 / np.arange(1, 11))
+        else:
+            X = draw(600 if i < 6 else 7 + i, np.arange(0, 60), 1.0 / np.arange(1, 61))
+        blocks.append((X + 0.5).astype(np.float32))
+    est = get_estimator("ipca", k, 1.0)
+    orc = O.IPCAEstimatorOracle(k, "gram")
+    for X in blocks:
+        assert est.fit_partial(torch.from_numpy(X).to(dev)) is True
+        orc.fit_partial(X)
+    comp = est.get_components()[0]
+    svo = orc.transformer.singular_values_
+    live = svo > 1e-3 * svo[0]
+    assert live.sum() >= (10 if case == "lowrank" else k)
+    cos = O.signed_cosines(comp[live], orc.transformer.components_[live])
+    assert cos.min() > 1 - 3e-6, (case, cos.min())
+    np.testing.assert_allclose(est.transformer.singular_values_[live], svo[live], rtol=1e-4)
+    np.testing.assert_allclose(est.transformer.singular_values_, svo, atol=5e-4 * svo[0])
+    np.testing.assert_allclose(est.transformer.mean_, orc.transformer.mean_, atol=2e-6)
