@@ -261,17 +261,21 @@ def main():
             for b in blocks[:BLOCKS_PER_STEP * max(1, Wm)]:
                 ef.fit_partial(b)
             ef.get_components()
-            ef = IPCAEstimator(K_COMP, "faithful")
-            ef.transformer._ensure(D)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for b in blocks:
-                ef.fit_partial(b)
-            ef.get_components()
-            torch.cuda.synchronize()
-            tf_ = time.perf_counter() - t0
+            runs = []
+            for rep in range(3):           # one host round trip per block: sensitive to what else the host is doing
+                ef = IPCAEstimator(K_COMP, "faithful")
+                ef.transformer._ensure(D)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for b in blocks:
+                    ef.fit_partial(b)
+                ef.get_components()
+                torch.cuda.synchronize()
+                runs.append(time.perf_counter() - t0)
+            tf_ = min(runs)
             out["faithful_mode_same_job"] = {"samples_per_s": round(n_blocks * NB / tf_, 1),
-                                             "ms_per_block": round(tf_ / n_blocks * 1e3, 4), "blocks": n_blocks}
+                                             "ms_per_block": round(tf_ / n_blocks * 1e3, 4), "blocks": n_blocks,
+                                             "job_s_of_3_runs": [round(r, 5) for r in runs]}
 
         # ---- opt-in split-bf16 contraction modes (precision="bf16x6" / "bf16x3"; the headline stays exact f32):
         #      same job, same timed region; cos-sim against the same sklearn reference sample ------------------
