@@ -99,9 +99,11 @@ struct GemmEpilogue {
     const double *E1 = nullptr;
     const double *E2 = nullptr;
 };
+// c_is_zero: C is known to hold zeros (a fresh slot of SubspaceWorkspace's ring) - the split-K path then skips its
+// zeroing launch.
 void gemm_f64(int M, int N, int K, const double *A, int64_t a_i, int64_t a_t, const double *B, int64_t b_t,
               int64_t b_j, double *C, int64_t ldc, hipStream_t stream, double alpha = 1.0, double beta = 0.0,
-              const GemmEpilogue &epi = GemmEpilogue(), bool allow_split = true);
+              const GemmEpilogue &epi = GemmEpilogue(), bool allow_split = true, bool c_is_zero = false);
 
 // ---- top-k subspace eigensolver: gs_subspace.hip / gs_topk.hip ----------------------------------------
 struct SubspaceWorkspace {
@@ -123,7 +125,20 @@ struct SubspaceWorkspace {
     int inv_plan = 0;              // products before the Rayleigh quotient (0 = derive from the block count)
     double inv_ratio1 = 0.0;       // max / min pivot of R per product at the last orthonormalisation (~lambda_1 / lambda_k)
     int inv_last_products = 0;
-    double *Q = nullptr, *Y = nullptr, *Z = nullptr, *R = nullptr;  // [n][pp]
+    double *Q = nullptr, *Y = nullptr, *Z = nullptr, *R = nullptr;  // [n][pp]  (= ring[0..3])
+    // gs_topk.hip: every n x pp block of a solve is taken from a ring of slots that ONE memset has zeroed at the start
+    // of the solve, so that the split-K products (atomic epilogue) do not need a zeroing launch each (18 products +
+    // 6 Gram matrices per cold solve were 24 launches of 4.6 us).  A slot is reused only after ring_n - 1 further
+    // takes - longer than anything stays live; a reused slot is simply no longer "clean".
+    static constexpr int kRingMax = 32, kHRing = 12;
+    double *pool = nullptr;         // one allocation: ring slots, then the p x p slots
+    size_t pool_elems = 0;
+    double *ring[kRingMax] = {};    // [n_cap][pp] each
+    bool ring_clean[kRingMax] = {};
+    int ring_n = 0, ring_next = 0;
+    double *hring[kHRing] = {};     // [pp][pp] each (Gram matrices, Rayleigh quotients)
+    bool h_clean[kHRing] = {};
+    int h_next = 0;
     double *H = nullptr, *B = nullptr, *U = nullptr;                // [pp][pp]
     double *theta = nullptr;                                        // [3*pp + 32]: Ritz values | residuals | pivot floors / R diagonal | statistics (8) | filter coefficients (6)
     double *Rm = nullptr;                                           // [pp][pp] Cholesky factor
@@ -147,6 +162,10 @@ int chol_blocked_launch(const double *H, int64_t ldh, int p, double *Rm, int64_t
 int jacobi_small_launch(const double *B, int64_t ldb, int p, double *U, int64_t ldu, double *theta, int *info,
                         hipStream_t stream);
 int orth_fast(SubspaceWorkspace &ws, const double *Y, double *Qout, int n, int p, hipStream_t stream);
+// ring management (gs_subspace.hip): zero every slot / take the next slot (clean_out: still zero?)
+int ring_reset(SubspaceWorkspace &ws, hipStream_t stream);
+double *ring_take(SubspaceWorkspace &ws, bool *clean_out);
+double *hring_take(SubspaceWorkspace &ws, bool *clean_out);
 // Qout = Y R^-1 from the blocked factor (gs_subspace.hip)
 int trsm_rows_launch(const double *Y, double *Qout, int64_t ld, int n, int p, const double *Rm, const double *Dinv,
                      hipStream_t stream);

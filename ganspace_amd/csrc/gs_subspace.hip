@@ -157,7 +157,7 @@ __global__ void zero_rows_kernel(double *__restrict__ C, int M, int N, int64_t l
 
 void gemm_f64(int M, int N, int K, const double *A, int64_t a_i, int64_t a_t, const double *B, int64_t b_t,
               int64_t b_j, double *C, int64_t ldc, hipStream_t stream, double alpha, double beta,
-              const GemmEpilogue &epi, bool allow_split) {
+              const GemmEpilogue &epi, bool allow_split, bool c_is_zero) {
     if (M <= 0 || N <= 0) return;
     const bool small_tiles = ceil_div(M, 64) * ceil_div(N, 64) < 64;
     const int TMv = small_tiles ? 32 : 64;
@@ -171,7 +171,7 @@ void gemm_f64(int M, int N, int K, const double *A, int64_t a_i, int64_t a_t, co
     }
     const int kchunk = (int)round_up(ceil_div(K, splits), kTK);
     splits = (int)ceil_div(K, kchunk);
-    if (splits > 1)
+    if (splits > 1 && !c_is_zero)
         hipLaunchKernelGGL(zero_rows_kernel, dim3((unsigned)ceil_div(N, 256), (unsigned)M), dim3(256), 0, stream, C, M, N,
                            ldc);
     dim3 grid((unsigned)ceil_div(N, TMv), (unsigned)ceil_div(M, TMv), (unsigned)splits);
@@ -443,10 +443,18 @@ int subspace_workspace_alloc(SubspaceWorkspace &ws, int n, int p) {
     };
     int rc = GS_OK;
     const size_t np = (size_t)n * ws.pp, ppp = (size_t)ws.pp * ws.pp;
-    if (rc == GS_OK) rc = alloc(&ws.Q, np);
-    if (rc == GS_OK) rc = alloc(&ws.Y, np);
-    if (rc == GS_OK) rc = alloc(&ws.Z, np);
-    if (rc == GS_OK) rc = alloc(&ws.R, np);
+    // ring of n x pp slots (the first four double as Q, Y, Z, R of the legacy path) + p x p slots, one allocation
+    ws.ring_n = np * sizeof(double) <= ((size_t)1 << 20) ? SubspaceWorkspace::kRingMax : 16;
+    ws.pool_elems = (size_t)ws.ring_n * np + (size_t)SubspaceWorkspace::kHRing * ppp;
+    if (rc == GS_OK) rc = alloc(&ws.pool, ws.pool_elems);
+    if (rc == GS_OK) {
+        for (int i = 0; i < ws.ring_n; ++i) ws.ring[i] = ws.pool + (size_t)i * np;
+        for (int i = 0; i < SubspaceWorkspace::kHRing; ++i) ws.hring[i] = ws.pool + (size_t)ws.ring_n * np + (size_t)i * ppp;
+        ws.Q = ws.ring[0];
+        ws.Y = ws.ring[1];
+        ws.Z = ws.ring[2];
+        ws.R = ws.ring[3];
+    }
     if (rc == GS_OK) rc = alloc(&ws.G, np);
     if (rc == GS_OK) rc = alloc(&ws.H, ppp);
     if (rc == GS_OK) rc = alloc(&ws.B, ppp);
@@ -460,11 +468,36 @@ int subspace_workspace_alloc(SubspaceWorkspace &ws, int n, int p) {
 }
 
 void subspace_workspace_free(SubspaceWorkspace &ws) {
-    double *ptrs[] = {ws.Q, ws.Y, ws.Z, ws.R, ws.G, ws.H, ws.B, ws.U, ws.theta, ws.Rm, ws.Dinv};
+    double *ptrs[] = {ws.pool, ws.G, ws.H, ws.B, ws.U, ws.theta, ws.Rm, ws.Dinv};
     for (double *p : ptrs)
         if (p) (void)hipFree(p);
     eigh_workspace_free(ws.ews);
     ws = SubspaceWorkspace();
+}
+
+int ring_reset(SubspaceWorkspace &ws, hipStream_t stream) {
+    GS_HIP_CHECK(hipMemsetAsync(ws.pool, 0, sizeof(double) * ws.pool_elems, stream));
+    for (int i = 0; i < ws.ring_n; ++i) ws.ring_clean[i] = true;
+    for (int i = 0; i < SubspaceWorkspace::kHRing; ++i) ws.h_clean[i] = true;
+    ws.ring_next = 0;
+    ws.h_next = 0;
+    return GS_OK;
+}
+
+double *ring_take(SubspaceWorkspace &ws, bool *clean_out) {
+    const int i = ws.ring_next;
+    ws.ring_next = (i + 1) % ws.ring_n;
+    if (clean_out) *clean_out = ws.ring_clean[i];
+    ws.ring_clean[i] = false;
+    return ws.ring[i];
+}
+
+double *hring_take(SubspaceWorkspace &ws, bool *clean_out) {
+    const int i = ws.h_next;
+    ws.h_next = (i + 1) % SubspaceWorkspace::kHRing;
+    if (clean_out) *clean_out = ws.h_clean[i];
+    ws.h_clean[i] = false;
+    return ws.hring[i];
 }
 
 int subspace_dim(int n, int k, int guards) {

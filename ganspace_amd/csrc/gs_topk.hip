@@ -671,8 +671,10 @@ int jacobi_small_launch(const double *B, int64_t ldb, int p, double *U, int64_t 
 int orth_fast(SubspaceWorkspace &ws, const double *Y, double *Qout, int n, int p, hipStream_t stream) {
     const int64_t ld = ws.pp;
     GemmEpilogue none;
-    gemm_f64(p, p, n, Y, 1, ld, Y, ld, 1, ws.H, ld, stream, 1.0, 0.0, none, true);
-    int rc = chol_blocked_launch(ws.H, ld, p, ws.Rm, ld, ws.Dinv, ws.theta + 2 * ws.pp, stream);
+    bool clean = false;
+    double *H = hring_take(ws, &clean);
+    gemm_f64(p, p, n, Y, 1, ld, Y, ld, 1, H, ld, stream, 1.0, 0.0, none, true, clean);
+    int rc = chol_blocked_launch(H, ld, p, ws.Rm, ld, ws.Dinv, ws.theta + 2 * ws.pp, stream);
     if (rc != GS_OK) return rc;
     return trsm_rows_launch(Y, Qout, ld, n, p, ws.Rm, ws.Dinv, stream);
 }
@@ -717,7 +719,6 @@ int invsub_iterate(SubspaceWorkspace &ws, const double *A, int n, int64_t lda, i
                "invsub_iterate: bad sizes");
     const int64_t ld = ws.pp;
     const double tol_rel = 1e-9;
-    double *buf[4] = {ws.Q, ws.Y, ws.Z, ws.R};
     GemmEpilogue none;
     *converged = 0;
     if (mults_out) *mults_out = 0;
@@ -742,46 +743,55 @@ int invsub_iterate(SubspaceWorkspace &ws, const double *A, int n, int64_t lda, i
         ws.inv_plan = 0;
         return GS_OK;
     }
-    hipLaunchKernelGGL(topk_seed_kernel, dim3((unsigned)ceil_div(k, 64), (unsigned)n), dim3(64), 0, stream, buf[0], n, ld,
+    int rcr = ring_reset(ws, stream);     // every block below comes out of the zeroed ring
+    if (rcr != GS_OK) return rcr;
+    double *Qc = ring_take(ws, nullptr);
+    hipLaunchKernelGGL(topk_seed_kernel, dim3((unsigned)ceil_div(k, 64), (unsigned)n), dim3(64), 0, stream, Qc, n, ld,
                        identity_start ? (const double *)nullptr : Vk, k, ldv);
-    int q = 0, used = 0;
+    int used = 0;
     const int P0 = P;
     std::vector<double> host(3 * (size_t)ws.pp);
+    double *Bm = nullptr;
     for (int attempt = 0; attempt < 3; ++attempt) {
         int rem = P, jj_last = 1;
         while (rem > 0) {
             const int jj = j < rem ? j : rem;
-            int cur = q;
+            double *cur = Qc;
             for (int s = 0; s < jj; ++s) {
-                const int nxt = (cur + 1) & 3;
-                gemm_f64(n, k, n, A, lda, 1, buf[cur], ld, 1, buf[nxt], ld, stream, 1.0, 0.0, none, true);
+                bool clean = false;
+                double *nxt = ring_take(ws, &clean);
+                gemm_f64(n, k, n, A, lda, 1, cur, ld, 1, nxt, ld, stream, 1.0, 0.0, none, true, clean);
                 cur = nxt;
                 ++used;
             }
-            const int o = (cur + 1) & 3;
-            int rc = orth_fast(ws, buf[cur], buf[o], n, k, stream);   // R diagonal -> theta + 2 pp
+            double *o = ring_take(ws, nullptr);
+            int rc = orth_fast(ws, cur, o, n, k, stream);   // R diagonal -> theta + 2 pp
             if (rc != GS_OK) return rc;
-            q = o;
+            Qc = o;
             rem -= jj;
             jj_last = jj;
         }
         // a second pass when the first one cannot have left the basis orthonormal to ~1e-12 (cond^2 eps)
         const bool pass2 = !(ws.inv_ratio1 > 1.0) || std::pow(ws.inv_ratio1, 2.0 * jj_last) * 1e-16 > 1e-12;
         if (pass2) {
-            const int o = (q + 1) & 3;
-            gemm_f64(k, k, n, buf[q], 1, ld, buf[q], ld, 1, ws.H, ld, stream, 1.0, 0.0, none, true);
-            int rc = chol_blocked_launch(ws.H, ld, k, ws.Rm, ld, ws.Dinv, ws.theta, stream);   // keeps theta + 2 pp
+            bool clean = false;
+            double *H = hring_take(ws, &clean);
+            double *o = ring_take(ws, nullptr);
+            gemm_f64(k, k, n, Qc, 1, ld, Qc, ld, 1, H, ld, stream, 1.0, 0.0, none, true, clean);
+            int rc = chol_blocked_launch(H, ld, k, ws.Rm, ld, ws.Dinv, ws.theta, stream);   // keeps theta + 2 pp
             if (rc != GS_OK) return rc;
-            rc = trsm_rows_launch(buf[q], buf[o], ld, n, k, ws.Rm, ws.Dinv, stream);
+            rc = trsm_rows_launch(Qc, o, ld, n, k, ws.Rm, ws.Dinv, stream);
             if (rc != GS_OK) return rc;
-            q = o;
+            Qc = o;
         }
-        const int y = (q + 1) & 3, z = (q + 2) & 3;
-        gemm_f64(n, k, n, A, lda, 1, buf[q], ld, 1, buf[y], ld, stream, 1.0, 0.0, none, true);     // Y = A Q
+        bool cleany = false, cleanb = false;
+        double *Yb = ring_take(ws, &cleany), *Zb = ring_take(ws, nullptr);
+        Bm = hring_take(ws, &cleanb);
+        gemm_f64(n, k, n, A, lda, 1, Qc, ld, 1, Yb, ld, stream, 1.0, 0.0, none, true, cleany);     // Y = A Q
         ++used;
-        gemm_f64(k, k, n, buf[q], 1, ld, buf[y], ld, 1, ws.B, ld, stream, 1.0, 0.0, none, true);   // B = Q^T Y
-        gemm_f64(n, k, k, buf[q], ld, 1, ws.B, ld, 1, buf[z], ld, stream, 1.0, 0.0, none, false);  // Z = Q B
-        hipLaunchKernelGGL(invsub_resid_kernel, dim3((unsigned)k), dim3(256), 0, stream, buf[y], buf[z], ld, ws.B, ld, n,
+        gemm_f64(k, k, n, Qc, 1, ld, Yb, ld, 1, Bm, ld, stream, 1.0, 0.0, none, true, cleanb);     // B = Q^T Y
+        gemm_f64(n, k, k, Qc, ld, 1, Bm, ld, 1, Zb, ld, stream, 1.0, 0.0, none, false);            // Z = Q B
+        hipLaunchKernelGGL(invsub_resid_kernel, dim3((unsigned)k), dim3(256), 0, stream, Yb, Zb, ld, Bm, ld, n,
                            ws.theta + ws.pp, ws.theta);
         GS_HIP_CHECK(hipMemcpyAsync(host.data(), ws.theta, sizeof(double) * 3 * ws.pp, hipMemcpyDeviceToHost, stream));
         GS_HIP_CHECK(hipStreamSynchronize(stream));
@@ -812,7 +822,7 @@ int invsub_iterate(SubspaceWorkspace &ws, const double *A, int n, int64_t lda, i
         if (rel <= 1.0) {
             *converged = 1;
             hipLaunchKernelGGL(invsub_emit_kernel, dim3((unsigned)ceil_div((int)(ldv > k ? ldv : k), 256), (unsigned)k),
-                               dim3(256), 0, stream, buf[q], ld, n, k, Vk, ldv, ws.B, ld, Bk, ldbk);
+                               dim3(256), 0, stream, Qc, ld, n, k, Vk, ldv, Bm, ld, Bk, ldbk);
             GS_HIP_CHECK(hipGetLastError());
             if (attempt == 0) {
                 // a wide margin shortens the next block's schedule (its gap is wider still)
@@ -845,7 +855,6 @@ int eigh_topk_cheb(SubspaceWorkspace &ws, const double *A, int n, int64_t lda, i
                "eigh_topk_cheb: bad sizes");
     const int64_t ld = ws.pp;
     const double tol_rel = 1e-9, tol2 = tol_rel * tol_rel;
-    double *buf[4] = {ws.Q, ws.Y, ws.Z, ws.R};
     double *stats = ws.theta + 3 * ws.pp, *coef = stats + 8;
     int *jinfo = ws.ews.rank;   // two ints of scratch
     const bool warm = k0 > 0;
@@ -855,35 +864,37 @@ int eigh_topk_cheb(SubspaceWorkspace &ws, const double *A, int n, int64_t lda, i
     int mults = 0;
 
     // ---- start basis -------------------------------------------------------------------------------------
-    int q = 0;                      // buf[q] = current orthonormal basis Q
-    hipLaunchKernelGGL(topk_init_kernel, gnp, b64, 0, stream, buf[1], n, p, ld);
+    int rcr = ring_reset(ws, stream);     // every n x p block below comes out of the zeroed ring
+    if (rcr != GS_OK) return rcr;
+    double *Qc = ring_take(ws, nullptr);  // current orthonormal basis Q
+    hipLaunchKernelGGL(topk_init_kernel, gnp, b64, 0, stream, Qc, n, p, ld);
     if (warm) {
-        hipLaunchKernelGGL(topk_seed_kernel, dim3((unsigned)ceil_div(k0, 64), (unsigned)n), b64, 0, stream, buf[1], n, ld,
+        hipLaunchKernelGGL(topk_seed_kernel, dim3((unsigned)ceil_div(k0, 64), (unsigned)n), b64, 0, stream, Qc, n, ld,
                            V0, k0, ldv0);
         const bool prev_basis = ws.reuse_guards && ws.guards_valid && ws.guards_n == n && ws.guards_p == p && k0 < p;
         if (prev_basis) {
             // [previous components | previous guard Ritz vectors] is the previous solve's Ritz basis up to signs:
             // orthonormal already, the estimate cycle below re-orthonormalises A times it anyway
             hipLaunchKernelGGL(topk_copycols_kernel, dim3((unsigned)ceil_div(p - k0, 64), (unsigned)n), b64, 0, stream,
-                               buf[1], ws.G, ld, k0, p);
-            q = 1;
+                               Qc, ws.G, ld, k0, p);
         } else {
-            int rc = orth_fast(ws, buf[1], buf[0], n, p, stream);
+            double *o = ring_take(ws, nullptr);
+            int rc = orth_fast(ws, Qc, o, n, p, stream);
             if (rc != GS_OK) return rc;
-            q = 0;
+            Qc = o;
         }
-    } else {
-        q = 1;                      // a uniform random block is well conditioned: no orthonormalisation needed
     }
+    // (cold: a uniform random block is well conditioned - no orthonormalisation needed)
     // ---- estimate phase: single products (robust for lambda_1 / lambda_p up to ~1e6) ------------------------
     const int est_cycles = warm ? 1 : 2;
     for (int c = 0; c < est_cycles; ++c) {
-        const int y = (q + 1) & 3, o = (q + 2) & 3;
-        gemm_f64(n, p, n, A, lda, 1, buf[q], ld, 1, buf[y], ld, stream, 1.0, 0.0, none, true);
+        bool clean = false;
+        double *y = ring_take(ws, &clean), *o = ring_take(ws, nullptr);
+        gemm_f64(n, p, n, A, lda, 1, Qc, ld, 1, y, ld, stream, 1.0, 0.0, none, true, clean);
         ++mults;
-        int rc = orth_fast(ws, buf[y], buf[o], n, p, stream);
+        int rc = orth_fast(ws, y, o, n, p, stream);
         if (rc != GS_OK) return rc;
-        q = o;
+        Qc = o;
     }
     hipLaunchKernelGGL(cheb_setup_kernel, dim3(1), dim3(64), 0, stream, ws.theta + 2 * ws.pp, p, k, 1, stats, coef);
 
@@ -940,49 +951,44 @@ int eigh_topk_cheb(SubspaceWorkspace &ws, const double *A, int n, int64_t lda, i
     for (int attempt = 0; attempt < 3; ++attempt) {
         // ---- filter cycles -------------------------------------------------------------------------------
         for (int c = 0; c < ncyc; ++c) {
-            // three rotating buffers besides Q
-            int t0 = q, t1 = (q + 1) & 3, t2 = (q + 2) & 3, t3 = (q + 3) & 3;
+            bool clean = false;
+            double *prev = Qc, *cur = ring_take(ws, &clean);
             GemmEpilogue e1;
             e1.coef = coef;
-            e1.E1 = buf[t0];
-            gemm_f64(n, p, n, A, lda, 1, buf[t0], ld, 1, buf[t1], ld, stream, 1.0, 0.0, e1, true);
+            e1.E1 = Qc;
+            gemm_f64(n, p, n, A, lda, 1, Qc, ld, 1, cur, ld, stream, 1.0, 0.0, e1, true, clean);
             ++mults;
-            int prev = t0, cur = t1;
-            int freeb[2] = {t2, t3};
-            int fi = 0;
             for (int s = 2; s <= deg; ++s) {
                 GemmEpilogue e2;
                 e2.coef = coef + 3;
-                e2.E1 = buf[cur];
-                e2.E2 = buf[prev];
-                const int nxt = freeb[fi];
-                gemm_f64(n, p, n, A, lda, 1, buf[cur], ld, 1, buf[nxt], ld, stream, 1.0, 0.0, e2, true);
+                e2.E1 = cur;
+                e2.E2 = prev;
+                double *nxt = ring_take(ws, &clean);
+                gemm_f64(n, p, n, A, lda, 1, cur, ld, 1, nxt, ld, stream, 1.0, 0.0, e2, true, clean);
                 ++mults;
-                // `prev` becomes free - except Q itself in the first step, which nothing needs any more either
-                freeb[fi] = prev;
-                fi ^= 1;
                 prev = cur;
                 cur = nxt;
             }
-            // orthonormalise into any buffer other than `cur`
-            int o = (cur + 1) & 3;
-            int rc = orth_fast(ws, buf[cur], buf[o], n, p, stream);
+            double *o = ring_take(ws, nullptr);
+            int rc = orth_fast(ws, cur, o, n, p, stream);
             if (rc != GS_OK) return rc;
-            q = o;
+            Qc = o;
         }
         // (no second CholeskyQR pass: a single pass leaves the filtered basis orthonormal to ~1e-14 - see the degree
         //  cap above; whatever is left shows up in the residuals below, which are computed from the emitted vectors)
         // ---- Rayleigh-Ritz -------------------------------------------------------------------------------
-        const int y = (q + 1) & 3, z = (q + 2) & 3, w = (q + 3) & 3;
-        gemm_f64(n, p, n, A, lda, 1, buf[q], ld, 1, buf[y], ld, stream, 1.0, 0.0, none, true);   // Y = A Q
-        gemm_f64(p, p, n, buf[q], 1, ld, buf[y], ld, 1, ws.B, ld, stream, 1.0, 0.0, none, true);  // B = Q^T Y
+        bool cleany = false, cleanb = false;
+        double *Yb = ring_take(ws, &cleany), *Zb = ring_take(ws, nullptr), *Wb = ring_take(ws, nullptr);
+        double *Bm = hring_take(ws, &cleanb);
+        gemm_f64(n, p, n, A, lda, 1, Qc, ld, 1, Yb, ld, stream, 1.0, 0.0, none, true, cleany);   // Y = A Q
+        gemm_f64(p, p, n, Qc, 1, ld, Yb, ld, 1, Bm, ld, stream, 1.0, 0.0, none, true, cleanb);   // B = Q^T Y
         {
-            int rcj = jacobi_small_launch(ws.B, ld, p, ws.U, ld, ws.theta, jinfo, stream);
+            int rcj = jacobi_small_launch(Bm, ld, p, ws.U, ld, ws.theta, jinfo, stream);
             if (rcj != GS_OK) return rcj;
         }
-        gemm_f64(n, p, p, buf[q], ld, 1, ws.U, ld, 1, buf[z], ld, stream, 1.0, 0.0, none, false);    // Z = Q U
-        gemm_f64(n, k, p, buf[y], ld, 1, ws.U, ld, 1, buf[w], ld, stream, 1.0, 0.0, none, false);    // (A Q) U_k
-        hipLaunchKernelGGL(topk_resid_kernel, dim3((unsigned)k), dim3(256), 0, stream, buf[w], buf[z], ld, ws.theta, n,
+        gemm_f64(n, p, p, Qc, ld, 1, ws.U, ld, 1, Zb, ld, stream, 1.0, 0.0, none, false);    // Z = Q U
+        gemm_f64(n, k, p, Yb, ld, 1, ws.U, ld, 1, Wb, ld, stream, 1.0, 0.0, none, false);    // (A Q) U_k
+        hipLaunchKernelGGL(topk_resid_kernel, dim3((unsigned)k), dim3(256), 0, stream, Wb, Zb, ld, ws.theta, n,
                            k, ws.theta + ws.pp);
         GS_HIP_CHECK(hipMemcpyAsync(host.data(), ws.theta + ws.pp, sizeof(double) * k, hipMemcpyDeviceToHost, stream));
         GS_HIP_CHECK(hipMemcpyAsync(host.data() + k, ws.theta, sizeof(double), hipMemcpyDeviceToHost, stream));
@@ -1001,10 +1007,10 @@ int eigh_topk_cheb(SubspaceWorkspace &ws, const double *A, int n, int64_t lda, i
         if (ok) {
             *converged = 1;
             hipLaunchKernelGGL(topk_emit_kernel, dim3((unsigned)ceil_div(n, 256), (unsigned)k), dim3(256), 0, stream,
-                               buf[z], ld, ws.theta, n, k, Vk, ldv, lam);
+                               Zb, ld, ws.theta, n, k, Vk, ldv, lam);
             GS_HIP_CHECK(hipGetLastError());
             if (ws.reuse_guards) {
-                GS_HIP_CHECK(hipMemcpyAsync(ws.G, buf[z], sizeof(double) * (size_t)n * ld, hipMemcpyDeviceToDevice, stream));
+                GS_HIP_CHECK(hipMemcpyAsync(ws.G, Zb, sizeof(double) * (size_t)n * ld, hipMemcpyDeviceToDevice, stream));
                 ws.guards_valid = true;
                 ws.guards_n = n;
                 ws.guards_p = p;
@@ -1024,7 +1030,7 @@ int eigh_topk_cheb(SubspaceWorkspace &ws, const double *A, int n, int64_t lda, i
         ws.plan_valid = false;
         if (!finite || !(th1 > 0.0) || attempt == 2) break;
         // not there yet: continue from the Ritz basis.  Cycles still needed from the measured residual.
-        q = z;
+        Qc = Zb;
         int extra = 2;
         if (gain > 2.0 && worst > 0.0) {
             const double need = std::log(std::sqrt(worst) / (tol_rel / 3.0 * th1)) / std::log(gain);
