@@ -296,10 +296,13 @@ def main():
                 run(e2, K)
                 torch.cuda.synchronize()
                 job = time.perf_counter() - t0
-                us_p, rt = gram_kernel_us(lib, _lib, e2, blocks[0])      # split-bf16 launches stay at one block (no float64 carry)
+                # the launch of one step: bf16x3 takes the 50 000 rows in one "wide" launch (pairs of workgroups hold
+                # the whole upper triangle); bf16x6 launches are capped at 24 576 rows (no float64 carry)
+                us_p, rt = gram_kernel_us(lib, _lib, e2, step_views[0])
                 mfma_tf = nprod * rt * D * (D + 1) / (us_p * 1e-6) / 1e12
                 gbs = rt * D * 4 / (us_p * 1e-6) / 1e9
                 split[prec] = {"samples_per_s": round(n_blocks * NB / job, 1), "gram_launch_us": round(us_p, 2),
+                               "rows_per_launch": rt,
                                "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS,
                                             "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4)},
                                "bf16_mfma_TFLOPs_executed": round(mfma_tf, 1),

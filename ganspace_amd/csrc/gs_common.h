@@ -41,6 +41,7 @@ struct GramWorkspace {
     float *partial[2] = {nullptr, nullptr};         // [chunks][dp][dp] f32 partial Grams (upper 32x32 sub-tiles)
     float *colsum_partial[2] = {nullptr, nullptr};  // [chunks][dp]
     int64_t dp = 0;                // d rounded up to kMacroTile
+    int64_t d = 0;
     int max_chunks = 0;
     int cur = 0;
     int precision = 0;             // GS_PREC_*: which MFMA path computes the partial Grams
@@ -64,7 +65,7 @@ int gram_flush(GramWorkspace &ws, double *G64, double *S1, hipStream_t stream);
 
 // average duration of the partial-Gram kernel alone (HIP events on `stream`)
 int gram_partial_time(GramWorkspace &ws, const float *X, int64_t rows, int64_t ld, int64_t d,
-                      const float *shift, int iters, float *avg_ms, hipStream_t stream);
+                      const float *shift, int iters, float *avg_ms, hipStream_t stream, int64_t *rows_timed = nullptr);
 
 // column means of X[rows, ld] -> out[dp] f32 (padded columns zero)
 int column_means_f32(const float *X, int64_t rows, int64_t ld, int64_t d, int64_t dp, float *out,

@@ -543,7 +543,9 @@ int gram_workspace_alloc(GramWorkspace &ws, int64_t d) {
     int64_t mc = round_up(ceil_div(1024, nmt), 8);
     if (mc > 64) mc = 64;
     if (mc < 8) mc = 8;
+    if (ws.dp == 512) mc = 128;          // the wide split-bf16 launch: one slab per workgroup pair
     ws.max_chunks = (int)mc;
+    ws.d = d;
     for (int i = 0; i < 2; ++i) {
         GS_HIP_CHECK(hipMalloc(&ws.partial[i], sizeof(float) * ws.max_chunks * ws.dp * ws.dp));
         GS_HIP_CHECK(hipMalloc(&ws.colsum_partial[i], sizeof(float) * ws.max_chunks * ws.dp));
@@ -564,16 +566,47 @@ void gram_workspace_free(GramWorkspace &ws) {
 
 // Launch geometry of one partial-Gram launch over n rows.
 struct GramGeom {
+    bool wide = false;     // split-bf16 launch with one workgroup pair per chunk (d = 512)
     int nmt, T, want, nchunks, grid;
     ChunkPlan plan;
     int64_t rows_per_launch;
 };
 
-static GramGeom gram_geometry(const GramWorkspace &ws, int64_t n) {
+static GramGeom gram_geometry(const GramWorkspace &ws, int64_t n, bool aligned16 = true) {
     GramGeom g;
     const int dp = (int)ws.dp;
     g.T = dp / kMacroTile;
     g.nmt = g.T * (g.T + 1) / 2;
+    static const bool no_wide = getenv("GS_GRAM_NO_WIDE") != nullptr;
+    // (launches below ~20 000 rows - the 10 000-row block of the faithful loop - stay with the tiled kernel: the 71 MB of
+    //  slabs of 128 pairs, or the long chunks of fewer pairs, cost more than its panel re-reads: 28 vs 21 us)
+    if (ws.precision == GS_PREC_BF16X3 && ws.d == 512 && aligned16 && !no_wide && n >= 20000) {
+        // pairs of workgroups, each pair one chunk of <= 1024 rows (float32 accumulation span) and one 0.56 MB slab
+        // (upper triangle): more pairs shorten the matrix work per pair (~108 clk per row), fewer pairs write and
+        // fold fewer slabs (~5 TB/s) - pick the multiple of 8 that minimises the sum
+        g.wide = true;
+        g.want = 128;
+        g.rows_per_launch = (int64_t)128 * kMaxChunkRows;
+        if (n > g.rows_per_launch) n = g.rows_per_launch;
+        const int64_t units = ceil_div(n, (int64_t)kRowUnit);
+        int best = 8;
+        double best_t = 1e300;
+        for (int np = 8; np <= 128; np += 8) {
+            if ((int64_t)np * 4 > units && np > 8) break;                      // at least 64 rows per pair
+            if (ceil_div(units, (int64_t)np) * kRowUnit > kMaxChunkRows) continue;
+            const double t = (double)n / np * 108.0 / 2.4e9 + 2.0 * np * 0.557e6 / 5e12;   // 102 clk per row and pair ideal, 18 / 17 imbalance
+            if (t < best_t) {
+                best_t = t;
+                best = np;
+            }
+        }
+        g.nchunks = best;
+        if ((int64_t)g.nchunks > units) g.nchunks = (int)units;
+        g.plan.q = (int)(units / g.nchunks);
+        g.plan.rem = (int)(units % g.nchunks);
+        g.grid = (int)round_up(g.nchunks, 8) * 2;
+        return g;
+    }
     static const int target_wgs = []() {
         const char *e = getenv("GS_GRAM_TARGET_WGS");
         const int v = e ? atoi(e) : 0;
@@ -679,6 +712,17 @@ static void launch_partial(const GramWorkspace &ws, const GramGeom &g, int buf, 
     static unsigned long long pace_epoch = 0;       // launches of one workspace are ordered on its stream
     fj.pace = no_pace ? nullptr : ws.pace;
     fj.pace_base = (++pace_epoch) << 32;
+    if (g.wide && !vec) {
+        // rows not 16-byte aligned: the float4 staging of the wide kernel does not apply - same geometry through the
+        // tiled kernel is not possible (different grid), so the caller's geometry must not have chosen it
+        set_error("gram: internal - wide geometry for unaligned rows");
+        return;
+    }
+    if (g.wide) {
+        (void)launch_gram_bf16_wide(g.grid, fold.P != nullptr ? 64 : 0, Xb, n, ld, shift, ws.partial[buf],
+                                    ws.colsum_partial[buf], g.nchunks, g.plan, fj, stream);
+        return;
+    }
     if (ws.precision != GS_PREC_F32) {
         (void)launch_gram_bf16(ws.precision, g.grid, nfold, Xb, n, ld, (int)d, shift, ws.partial[buf],
                                ws.colsum_partial[buf], dp, g.nchunks, g.plan, g.nmt, g.T, fj, stream);
@@ -733,11 +777,12 @@ int gram_flush(GramWorkspace &ws, double *G64, double *S1, hipStream_t stream) {
 int gram_update(GramWorkspace &ws, const float *X, int64_t rows, int64_t ld, int64_t d, const float *shift,
                 double *G64, double *S1, bool accumulate, bool defer, hipStream_t stream) {
     if (rows <= 0) return GS_OK;
-    const int64_t rows_per_launch = gram_geometry(ws, rows).rows_per_launch;
+    const bool al = (ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0);
+    const int64_t rows_per_launch = gram_geometry(ws, rows, al).rows_per_launch;
     bool acc = accumulate;
     for (int64_t base = 0; base < rows; base += rows_per_launch) {
         const int64_t n = (rows - base < rows_per_launch) ? rows - base : rows_per_launch;
-        const GramGeom g = gram_geometry(ws, n);
+        const GramGeom g = gram_geometry(ws, n, al);
         // the previous launch's slabs are folded by this launch's spare workgroups
         const FoldJob f = pending_job(ws, G64, S1);
         const int buf = ws.cur;
@@ -756,11 +801,12 @@ int gram_update(GramWorkspace &ws, const float *X, int64_t rows, int64_t ld, int
 
 // Average duration (ms) of the partial-Gram kernel alone, HIP events on `stream`.
 int gram_partial_time(GramWorkspace &ws, const float *X, int64_t rows, int64_t ld, int64_t d,
-                      const float *shift, int iters, float *avg_ms, hipStream_t stream) {
+                      const float *shift, int iters, float *avg_ms, hipStream_t stream, int64_t *rows_timed) {
     const FoldJob nofold = {};
     const int buf = ws.pend_valid ? (ws.pend_buf ^ 1) : ws.cur;  // never clobber slabs that still wait for a fold
-    const GramGeom g = gram_geometry(ws, rows);
+    const GramGeom g = gram_geometry(ws, rows, (ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0));
     const int64_t n = rows < g.rows_per_launch ? rows : g.rows_per_launch;
+    if (rows_timed) *rows_timed = n;
     hipEvent_t e0, e1;
     GS_HIP_CHECK(hipEventCreate(&e0));
     GS_HIP_CHECK(hipEventCreate(&e1));

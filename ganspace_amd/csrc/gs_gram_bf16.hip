@@ -342,6 +342,283 @@ static int launch_variant(size_t lds_bytes, int grid, int nfold, const float *X,
     return GS_OK;
 }
 
+// =====================================================================================================
+// "Wide" variant for d = 512 (cfg2) and the bf16x3 split: the WHOLE upper triangle of the 512 x 512 Gram is held in
+// the accumulators of two workgroups (a "pair", both on one XCD) that stream the same row chunk.
+//
+// Why: with the tiled kernel above every 128-column panel is fetched by the 4 macro tiles that use it and the kernel is
+// bound by the L2 -> CU path (82 MB per 10 000 rows).  Here every workgroup stages each 16-row k-step of ALL 512
+// columns exactly once (one column per thread: 16 coalesced dword loads, split into 2 bf16 planes, four
+// ds_write_b128) and reads its operand fragments from LDS - 136 sub-tiles of 32 x 32 are 557 KB of accumulators,
+// more than one CU's register file (512 KB), hence the pair: 68 sub-tiles each.
+//   * half 0: macro blocks (0,1) (0,2) (0,3) + diagonal (0,0) (1,1);  half 1: (1,2) (1,3) (2,3) + (2,2) (3,3)
+//   * 8 waves: waves 0-5 own a 4 x 2 rectangle of sub-tiles (8 accumulators, 4 A + 2 B fragments per plane), waves 6-7
+//     the 10 upper sub-tiles of a diagonal macro block (4 fragments per plane serve as A and B); the SIMD pairs
+//     (w, w + 4) carry 16, 16, 18, 18 sub-tiles: 18 x 3 MFMA x 32 clk = 1 728 clk per k-step against 1 632 ideal
+//   * LDS image per k-step [plane][k-group][512 columns][16 B]: fragment reads and staging writes are both
+//     16-byte accesses at a 16-byte lane stride - conflict-free without padding; two stages (64 KB)
+//   * per row the pair moves 2 x 2 KB from L2 and 2 KB from HBM: the matrix pipe (204 clk per row and pair) and HBM
+//     (8 TB/s over 128 pairs) balance at ~6 TB/s; what is left is the slab: 278 KB per workgroup per launch, i.e.
+//     the launch has to be long (the chunk of a pair is capped at 1024 rows, the float32 accumulation span).
+constexpr int kWThreads = 512;
+// LDS image of one k-step: [plane 2][k-group 2][slot 4 x 132][16 B = 8 rows of one column as bf16]; column c sits in
+// slot (c & 3) * 132 + (c >> 2): a thread stages the 4 columns of a float4, consecutive lanes then write consecutive
+// slots, and the 132 (= 4 mod 16) keeps the 16-lane groups of the fragment reads on distinct bank groups.
+constexpr int kWKgBytes = 4 * 132 * 16;
+constexpr int kWPlaneBytes = 2 * kWKgBytes;
+constexpr int kWStageBytes = 2 * kWPlaneBytes;
+
+// 4 float32 (consecutive rows of one column) -> 2 planes of 4 bf16 (see split8)
+__device__ __forceinline__ void split4(const float (&v)[4], uint2 (&planes)[2]) {
+    unsigned hi[2], mid[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const f32x2 pr = {v[2 * q], v[2 * q + 1]};
+        const unsigned u = __builtin_bit_cast(unsigned, __builtin_convertvector(pr, bf16x2));
+        hi[q] = u;
+        const f32x2 rem = {v[2 * q] - __uint_as_float(u << 16), v[2 * q + 1] - __uint_as_float(u & 0xFFFF0000u)};
+        mid[q] = __builtin_bit_cast(unsigned, __builtin_convertvector(rem, bf16x2));
+    }
+    planes[0] = make_uint2(hi[0], hi[1]);
+    planes[1] = make_uint2(mid[0], mid[1]);
+}
+
+template <bool DIAGROLE, bool MMA_FIRST>
+__device__ __forceinline__ void gram_wide_body(const float *__restrict__ X, int64_t ld, const float *__restrict__ shift,
+                                               float *__restrict__ P, float *__restrict__ CS, int chunk, int64_t r0,
+                                               int64_t r1, int half, int wave, unsigned char *lds, int ablate) {
+    constexpr int dp = 512;
+    const int tid = threadIdx.x, lane = tid & 63;
+    // ---- sub-tile ownership (in units of 32-column blocks) ----
+    int ablk0, bblk0;
+    if (DIAGROLE) {
+        ablk0 = bblk0 = (half * 2 + (wave - 6)) * 4;
+    } else {
+        const int m = wave >> 1, sub = wave & 1;
+        const int I = half == 0 ? 0 : (m < 2 ? 1 : 2);
+        const int J = half == 0 ? m + 1 : (m == 0 ? 2 : 3);
+        ablk0 = I * 4;
+        bblk0 = J * 4 + sub * 2;
+    }
+    constexpr int NT = DIAGROLE ? 10 : 8;
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = f32x16{0};
+
+    // ---- staging: thread = (column quad, row quad): four float4 loads per k-step (dword loads, one column per thread,
+    //      were limited by the vector-memory instruction rate: 128 wave loads of 256 B per k-step took 1 800 clk) ----
+    const int cq = tid & 127, rq = tid >> 7;
+    const float4 sh = *reinterpret_cast<const float4 *>(shift + 4 * cq);
+    float cs[4] = {0.f, 0.f, 0.f, 0.f};
+    const int ld32 = (int)ld;                                      // 16 * ld < 2^31 (checked by the launcher)
+    // ONE code path for every k-step: the loads are unconditional and clamped to the chunk's last row (also for the
+    // two k-steps "after the end" the pipeline asks for), the row masks are applied to values that were loaded two
+    // k-steps earlier.  A branch around a load or a select on a fresh value makes the compiler wait for every load
+    // where the paths join (s_waitcnt vmcnt(0)) - the prefetch would be worthless.
+    auto fetch = [&](float4 (&f)[4], int64_t rbase) {
+        const int64_t rb = rbase < r1 ? rbase : r1 - 1;
+        const float *p = X + rb * ld;
+        const int last = (int)(r1 - 1 - rb);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = rq * 4 + i;
+            f[i] = *reinterpret_cast<const float4 *>(p + (unsigned)((row < last ? row : last) * ld32) + (unsigned)(4 * cq));
+        }
+    };
+    auto stash = [&](const float4 (&f)[4], int buf, int64_t rbase) {
+        float m[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) m[i] = (rbase + rq * 4 + i < r1) ? 1.f : 0.f;
+        unsigned char *base = lds + buf * kWStageBytes + (rq >> 1) * kWKgBytes + cq * 16 + (rq & 1) * 8;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float v[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float x = j == 0 ? f[i].x : j == 1 ? f[i].y : j == 2 ? f[i].z : f[i].w;
+                const float s0 = j == 0 ? sh.x : j == 1 ? sh.y : j == 2 ? sh.z : sh.w;
+                v[i] = (x - s0) * m[i];
+                cs[j] += v[i];
+            }
+            uint2 pl[2];
+            split4(v, pl);
+            *reinterpret_cast<uint2 *>(base + j * (132 * 16)) = pl[0];
+            *reinterpret_cast<uint2 *>(base + j * (132 * 16) + kWPlaneBytes) = pl[1];
+        }
+    };
+    const int fragoff = (lane >> 5) * kWKgBytes + ((lane & 3) * 132 + ((lane & 31) >> 2)) * 16;
+    auto frag = [&](int buf, int pl, int blk) {
+        return *reinterpret_cast<const bf16x8 *>(lds + buf * kWStageBytes + pl * kWPlaneBytes + blk * 128 + fragoff);
+    };
+    // plane 0 = leading bf16 term, 1 = second: mid*hi, hi*mid, hi*hi (smallest products first)
+    constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0};
+    auto mma = [&](int buf) {
+        if (DIAGROLE) {
+            bf16x8 F[2][4];
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) F[pl][q] = frag(buf, pl, ablk0 + q);
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                int idx = 0;
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int b = a; b < 4; ++b) {
+                        acc[idx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F[PA[t]][a], F[PB[t]][b], acc[idx], 0, 0, 0);
+                        ++idx;
+                    }
+            }
+        } else {
+            bf16x8 A[2][4], B[2][2];
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) A[pl][q] = frag(buf, pl, ablk0 + q);
+#pragma unroll
+                for (int q = 0; q < 2; ++q) B[pl][q] = frag(buf, pl, bblk0 + q);
+            }
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b)
+                        acc[a * 2 + b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[PA[t]][a], B[PB[t]][b], acc[a * 2 + b], 0, 0, 0);
+        }
+    };
+
+    // ---- pipeline: loads of k-step s + 2 | MFMA on k-step s | split + write k-step s + 1 | barrier ----
+    // The two waves of a SIMD (w and w + 4) run the MFMA phase and the split / LDS-write phase of a k-step in opposite
+    // order, so the matrix pipe of one overlaps the vector work of the other.
+    const int64_t nrows = r1 - r0;
+    const int nst = (int)((nrows + 15) / 16);
+    float4 f0[4], f1[4];
+    fetch(f0, r0);
+    fetch(f1, r0 + 16);
+    stash(f0, 0, r0);
+    __syncthreads();
+    int s = 0;
+    auto step = [&](float4 (&fnext2)[4], const float4 (&fnext1)[4]) {
+        const int buf = s & 1;
+        if (!(ablate & 4)) fetch(fnext2, r0 + (int64_t)(s + 2) * 16);
+        __builtin_amdgcn_sched_barrier(0);          // the loads go out first: two k-steps of latency cover
+        if (MMA_FIRST) {
+            if (!(ablate & 1)) mma(buf);
+            if (!(ablate & 2)) stash(fnext1, buf ^ 1, r0 + (int64_t)(s + 1) * 16);
+        } else {
+            if (!(ablate & 2)) stash(fnext1, buf ^ 1, r0 + (int64_t)(s + 1) * 16);
+            if (!(ablate & 1)) mma(buf);
+        }
+        __syncthreads();
+        ++s;
+    };
+    while (s + 1 < nst) {
+        step(f0, f1);
+        step(f1, f0);
+    }
+    if (s < nst) step(f0, f1);
+    // (column sums: the stashes "after the end" added zeros)
+
+    // ---- epilogue ----
+    // sub-tiles ON the diagonal: products are accumulated in an order that is not symmetric under i <-> j; mirror
+    // the upper triangle through LDS so the slab is exactly symmetric
+    float *Pc = P + (int64_t)chunk * dp * dp;
+    const int cc = lane & 31, hh = lane >> 5;
+    if (DIAGROLE) {
+        float *t = reinterpret_cast<float *>(lds) + (wave - 6) * (32 * 33);
+        constexpr int diag_idx[4] = {0, 4, 7, 9};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) t[((r & 3) + 8 * (r >> 2) + 4 * hh) * 33 + cc] = acc[diag_idx[q]][r];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;
+                const float m = t[cc * 33 + row];
+                if (row > cc) acc[diag_idx[q]][r] = m;
+            }
+        }
+        int idx = 0;
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = a; b < 4; ++b) {
+                float *dst = Pc + (int64_t)((ablk0 + a) * 32 + 4 * hh) * dp + (ablk0 + b) * 32 + cc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dst[(int64_t)((r & 3) + 8 * (r >> 2)) * dp] = acc[idx][r];
+                ++idx;
+            }
+    } else {
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                float *dst = Pc + (int64_t)((ablk0 + a) * 32 + 4 * hh) * dp + (bblk0 + b) * 32 + cc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dst[(int64_t)((r & 3) + 8 * (r >> 2)) * dp] = acc[a * 2 + b][r];
+            }
+    }
+    // column sums: the four row-quad threads of a column quad meet in LDS (the two halves computed the same numbers)
+    {
+        float *scr = reinterpret_cast<float *>(lds + 16384);
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) scr[rq * 512 + 4 * cq + j] = cs[j];
+        __syncthreads();
+        if (half == 0) CS[(int64_t)chunk * dp + tid] = scr[tid] + scr[512 + tid] + scr[1024 + tid] + scr[1536 + tid];
+    }
+}
+
+__global__ __launch_bounds__(kWThreads, 1) void gram_bf16_wide_kernel(
+    const float *__restrict__ X, int64_t rows, int64_t ld, const float *__restrict__ shift, float *__restrict__ P,
+    float *__restrict__ CS, int nchunks, ChunkPlan plan, int ncompute, FoldJob fold, int ablate) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // 2 x kWStageBytes
+    if ((int)blockIdx.x >= ncompute) {
+        fold_elements(fold.P, fold.CS, fold.G64, fold.S1, 512, fold.nchunks, fold.T32, fold.ntiles, fold.accumulate,
+                      (int)blockIdx.x - ncompute, (int)gridDim.x - ncompute, kWThreads);
+        return;
+    }
+    // the two halves of a pair sit on the same XCD (workgroup b -> XCD b % 8) and stream the same rows through its L2
+    const int b = blockIdx.x;
+    const int xcd = b & 7, local = b >> 3;
+    const int half = local & 1;
+    const int chunk = (local >> 1) * 8 + xcd;
+    if (chunk >= nchunks) return;
+    int64_t r0, r1;
+    chunk_range(plan, chunk, rows, r0, r1);
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    // waves w and w + 4 share a SIMD: 0-3 run MFMA then split / write, 4-7 the other way round
+    if (wave < 4)
+        gram_wide_body<false, true>(X, ld, shift, P, CS, chunk, r0, r1, half, wave, lds, ablate);
+    else if (wave < 6)
+        gram_wide_body<false, false>(X, ld, shift, P, CS, chunk, r0, r1, half, wave, lds, ablate);
+    else
+        gram_wide_body<true, false>(X, ld, shift, P, CS, chunk, r0, r1, half, wave, lds, ablate);
+}
+
+int launch_gram_bf16_wide(int grid, int nfold, const float *X, int64_t n, int64_t ld, const float *shift, float *P,
+                          float *CS, int nchunks, ChunkPlan plan, const FoldJob &fold, hipStream_t stream) {
+    const size_t lds_bytes = (size_t)2 * kWStageBytes;
+    GS_REQUIRE(ld < ((int64_t)1 << 27) && ld % 4 == 0 && (reinterpret_cast<uintptr_t>(X) & 15) == 0, GS_EINVAL,
+               "gram (wide): rows must be 16-byte aligned");
+    static bool attr = false;
+    if (!attr) {
+        GS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gram_bf16_wide_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        attr = true;
+    }
+    // measurement only (results wrong by design): GS_GRAM_ABLATE bit 0 no MFMA, bit 1 no split / LDS writes, bit 2 no loads
+    static const int ablate = []() {
+        const char *e = getenv("GS_GRAM_ABLATE");
+        return e ? atoi(e) : 0;
+    }();
+    hipLaunchKernelGGL(gram_bf16_wide_kernel, dim3((unsigned)(grid + nfold)), dim3(kWThreads), lds_bytes, stream, X, n, ld,
+                       shift, P, CS, nchunks, plan, grid, fold, ablate);
+    return GS_OK;
+}
+
 int launch_gram_bf16(int precision, int grid, int nfold, const float *X, int64_t n, int64_t ld, int d,
                      const float *shift, float *P, float *CS, int dp, int nchunks, ChunkPlan plan, int nmt, int T,
                      const FoldJob &fold, hipStream_t stream) {

@@ -109,4 +109,8 @@ int launch_gram_bf16(int precision, int grid, int nfold, const float *X, int64_t
                      const float *shift, float *P, float *CS, int dp, int nchunks, ChunkPlan plan, int nmt, int T,
                      const FoldJob &fold, hipStream_t stream);
 
+// bf16x3 "wide" variant for d = 512: pairs of workgroups hold the whole upper triangle (gs_gram_bf16.hip)
+int launch_gram_bf16_wide(int grid, int nfold, const float *X, int64_t n, int64_t ld, const float *shift, float *P,
+                          float *CS, int nchunks, ChunkPlan plan, const FoldJob &fold, hipStream_t stream);
+
 }  // namespace gs

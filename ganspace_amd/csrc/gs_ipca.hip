@@ -818,9 +818,11 @@ int gs_gram_kernel_time(gs_ipca_t *h, const float *X, int64_t rows, int64_t ld, 
     GS_REQUIRE(h && X && avg_ms_host && iters >= 1 && rows >= 1 && ld >= h->d, GS_EINVAL,
                "gs_gram_kernel_time: bad argument");
     const int64_t cap = (int64_t)1 << 20;
-    if (rows_timed_host) *rows_timed_host = rows < cap ? rows : cap;
-    return gram_partial_time(h->gws, X, rows < cap ? rows : cap, ld, h->d, h->shift, iters, avg_ms_host,
-                             (hipStream_t)stream_);
+    int64_t timed = 0;
+    const int rc = gram_partial_time(h->gws, X, rows < cap ? rows : cap, ld, h->d, h->shift, iters, avg_ms_host,
+                                     (hipStream_t)stream_, &timed);
+    if (rows_timed_host) *rows_timed_host = timed;     // one launch: the precision's row cap may be below `rows`
+    return rc;
 }
 
 int gs_eigh_sym(double *A, double *w, int n, int *sweeps_out_host, void *stream_) {

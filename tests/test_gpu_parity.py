@@ -104,8 +104,12 @@ def test_gram_accumulates_and_is_linear(dev):
 
 # ---- split-bf16 contraction modes (opt-in precision) ---------------------------------------------
 
+# (d = 512 launches of >= 20 000 rows take the "wide" bf16x3 kernel - pairs of workgroups holding the whole upper
+#  triangle: a multiple of the k-step, a ragged end, more than one launch, an aligned padded stride and an unaligned
+#  one that has to stay with the tiled kernel)
 @pytest.mark.parametrize("rows,d,ld_extra", [(1, 4, 0), (17, 100, 3), (1000, 512, 0), (10000, 512, 0),
-                                             (2311, 640, 0), (4097, 96, 5)])
+                                             (2311, 640, 0), (4097, 96, 5), (20000, 512, 0), (50001, 512, 4),
+                                             (131072 + 20777, 512, 0), (30003, 512, 3)])
 @pytest.mark.parametrize("precision,tol", [("bf16x6", 3e-6), ("bf16x3", 6e-5)])
 def test_gram_split_bf16_matches_float64(dev, rows, d, ld_extra, precision, tol):
     """x = hi + mid (+ lo) in bf16, products rebuilt from 3 / 6 bf16 MFMAs: dropped terms are 2^-16 / 2^-24 of
