@@ -490,8 +490,7 @@ __device__ __forceinline__ void gram_wide_body(const float *__restrict__ X, int6
     };
 
     // ---- pipeline: loads of k-step s + 2 | MFMA on k-step s | split + write k-step s + 1 | barrier ----
-    // The two waves of a SIMD (w and w + 4) run the MFMA phase and the split / LDS-write phase of a k-step in opposite
-    // order, so the matrix pipe of one overlaps the vector work of the other.
+    // (MMA_FIRST = false - split / write before the MFMAs - exists for the ordering experiments of the launcher)
     const int64_t nrows = r1 - r0;
     const int nst = (int)((nrows + 15) / 16);
     float4 f0[4], f1[4];
@@ -590,12 +589,20 @@ __global__ __launch_bounds__(kWThreads, 1) void gram_bf16_wide_kernel(
     chunk_range(plan, chunk, rows, r0, r1);
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     // waves w and w + 4 share a SIMD: 0-3 run MFMA then split / write, 4-7 the other way round
-    if (wave < 4)
-        gram_wide_body<false, true>(X, ld, shift, P, CS, chunk, r0, r1, half, wave, lds, ablate);
-    else if (wave < 6)
-        gram_wide_body<false, false>(X, ld, shift, P, CS, chunk, r0, r1, half, wave, lds, ablate);
-    else
-        gram_wide_body<true, false>(X, ld, shift, P, CS, chunk, r0, r1, half, wave, lds, ablate);
+    // GS_GRAM_ABLATE bit 3: waves 4-7 run split / write before MFMA; bit 4: odd waves do (experiments on which waves
+    // share a SIMD - neither order beat "MFMA first" everywhere)
+    const bool second = ((ablate & 8) && wave >= 4) || ((ablate & 16) && (wave & 1));
+    if (wave < 6) {
+        if (second)
+            gram_wide_body<false, false>(X, ld, shift, P, CS, chunk, r0, r1, half, wave, lds, ablate);
+        else
+            gram_wide_body<false, true>(X, ld, shift, P, CS, chunk, r0, r1, half, wave, lds, ablate);
+    } else {
+        if (second)
+            gram_wide_body<true, false>(X, ld, shift, P, CS, chunk, r0, r1, half, wave, lds, ablate);
+        else
+            gram_wide_body<true, true>(X, ld, shift, P, CS, chunk, r0, r1, half, wave, lds, ablate);
+    }
 }
 
 int launch_gram_bf16_wide(int grid, int nfold, const float *X, int64_t n, int64_t ld, const float *shift, float *P,
