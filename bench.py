@@ -39,6 +39,8 @@ import torch
 
 D, NB, K_COMP = 512, 10_000, 80
 BLOCKS_PER_STEP = 5
+RESIDENT_ROWS = None              # set by make_blocks: this rank's W-space rows as one contiguous view
+LAUNCH_ROWS = 131072              # rows per Gram launch when the estimator may merge resident rows (gs_ipca_update_resident)
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_HBM_GBS = 8000.0             # HBM3E spec
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # dense bf16 MFMA peak (the 2:1-sparsity headline figure is not used)
@@ -71,6 +73,8 @@ def make_blocks(n_blocks, dev, rank=0, world=1):
     assert all(b - a == NB for a, b in zip(starts[:-1], starts[1:]))
     # one view per step (BLOCKS_PER_STEP consecutive blocks: contiguous rows of the latent array)
     steps = [flat[starts[i] - row0:starts[i] - row0 + BLOCKS_PER_STEP * NB] for i in range(0, len(starts), BLOCKS_PER_STEP)]
+    global RESIDENT_ROWS
+    RESIDENT_ROWS = flat[starts[0] - row0:starts[-1] - row0 + NB]     # this rank's rows, contiguous
     return blocks, steps, time.perf_counter() - t0
 
 
@@ -124,8 +128,10 @@ def main():
 
     def run(est, nsteps, finish=True):
         if est.mode == "exact":
+            # (the product's W-space loop does the same: decomposition._fit_blocks hands over views of the resident
+            #  latent array, the estimator contracts them in launches of 131 072 rows)
             for i in range(nsteps):
-                assert est.fit_partial(step_views[i % K])
+                assert est.fit_partial(step_views[i % K], resident=True)
         else:
             for i in range(nsteps * BLOCKS_PER_STEP):
                 assert est.fit_partial(blocks[i % n_blocks])
@@ -169,8 +175,12 @@ def main():
 
     # ---- roofline of the dominant kernel of the timed region (the partial X^T X MFMA kernel: one launch per
     #      block, K x 5 launches), HIP events on its stream ----------------------------------------------------
-    gram_view = step_views[0] if args.mode == "exact" else blocks[0]
-    n_launches = K if args.mode == "exact" else n_blocks
+    if args.mode == "exact":
+        gram_view = RESIDENT_ROWS[:LAUNCH_ROWS]
+        n_launches = -(-K * BLOCKS_PER_STEP * NB // LAUNCH_ROWS)
+    else:
+        gram_view = blocks[0]
+        n_launches = n_blocks
     us, rows_l = gram_kernel_us(lib, _lib, est2, gram_view)
     flops = rows_l * D * (D + 1)           # algorithmic: upper triangle incl. diagonal, 2 flop/MAC
     bytes_ = rows_l * D * 4                # algorithmic: one read of the [rows, d] f32 block
@@ -189,7 +199,8 @@ def main():
     except Exception:
         pass
     frac_of_region = (n_launches * us * 1e-6) / (t_updates + t_final) if (t_updates + t_final) > 0 else None
-    roofline = {"bound": "mfma", "kernel": "gram_partial_kernel<true>", "achieved": round(ach_tf, 2),
+    roofline = {"bound": "mfma", "kernel": "gram_f32_wide_kernel" if args.mode == "exact" else "gram_partial_kernel<true, false>",
+                "achieved": round(ach_tf, 2),
                 "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach_tf / PEAK_F32_MFMA_TFLOPS, 4),
                 "traffic": traffic, "traffic_source": "profiles/gram_pmc_latest.json (rocprofv3 --pmc: FETCH_SIZE x2 + WRITE_SIZE)",
                 "traffic_note": traffic_note,

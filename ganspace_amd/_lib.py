@@ -27,6 +27,7 @@ SIGNATURES = {
     "gs_ipca_destroy": (_int, [_vp]),
     "gs_ipca_reset": (_int, [_vp]),
     "gs_ipca_update": (_int, [_vp, _vp, _i64, _i64, _vp]),
+    "gs_ipca_update_resident": (_int, [_vp, _vp, _i64, _i64, _vp]),
     "gs_ipca_state_nbytes": (_i64, [_vp]),
     "gs_ipca_state_export": (_int, [_vp, _vp, _vp]),
     "gs_ipca_state_import": (_int, [_vp, _vp, _vp]),

@@ -580,7 +580,9 @@ static GramGeom gram_geometry(const GramWorkspace &ws, int64_t n, bool aligned16
     static const bool no_wide = getenv("GS_GRAM_NO_WIDE") != nullptr;
     // (launches below ~20 000 rows - the 10 000-row block of the faithful loop - stay with the tiled kernel: the 71 MB of
     //  slabs of 128 pairs, or the long chunks of fewer pairs, cost more than its panel re-reads: 28 vs 21 us)
-    if (ws.precision == GS_PREC_BF16X3 && ws.d == 512 && aligned16 && !no_wide && n >= 20000) {
+    static const bool no_wide_f32 = getenv("GS_GRAM_NO_WIDE_F32") != nullptr;
+    const bool wide_prec = ws.precision == GS_PREC_BF16X3 || (ws.precision == GS_PREC_F32 && !no_wide_f32);
+    if (wide_prec && ws.d == 512 && aligned16 && !no_wide && n >= 20000) {
         // pairs of workgroups, each pair one chunk of <= 1024 rows (float32 accumulation span) and one 0.56 MB slab
         // (upper triangle): more pairs shorten the matrix work per pair (~108 clk per row), fewer pairs write and
         // fold fewer slabs (~5 TB/s) - pick the multiple of 8 that minimises the sum
@@ -594,7 +596,10 @@ static GramGeom gram_geometry(const GramWorkspace &ws, int64_t n, bool aligned16
         for (int np = 8; np <= 128; np += 8) {
             if ((int64_t)np * 4 > units && np > 8) break;                      // at least 64 rows per pair
             if (ceil_div(units, (int64_t)np) * kRowUnit > kMaxChunkRows) continue;
-            const double t = (double)n / np * 108.0 / 2.4e9 + 2.0 * np * 0.557e6 / 5e12;   // 102 clk per row and pair ideal, 18 / 17 imbalance
+            // matrix work per row and pair: 136 sub-tiles x 3 bf16 MFMAs x 32 clk (resp. x 1/2 f32 MFMA x 64 clk)
+            // over 8 SIMDs, 18 / 17 imbalance
+            const double clk_row = ws.precision == GS_PREC_F32 ? 576.0 : 108.0;
+            const double t = (double)n / np * clk_row / 2.4e9 + 2.0 * np * 0.557e6 / 5e12;
             if (t < best_t) {
                 best_t = t;
                 best = np;
@@ -719,8 +724,14 @@ static void launch_partial(const GramWorkspace &ws, const GramGeom &g, int buf, 
         return;
     }
     if (g.wide) {
-        (void)launch_gram_bf16_wide(g.grid, fold.P != nullptr ? 64 : 0, Xb, n, ld, shift, ws.partial[buf],
-                                    ws.colsum_partial[buf], g.nchunks, g.plan, fj, stream);
+        // (fold workgroups of the previous launch's slabs: the compute workgroups occupy every CU, so they run once
+        //  those retire - a whole round of them, up to 128 slabs of 0.56 MB are waiting)
+        if (ws.precision == GS_PREC_F32)
+            (void)launch_gram_f32_wide(g.grid, fold.P != nullptr ? 256 : 0, Xb, n, ld, shift, ws.partial[buf],
+                                       ws.colsum_partial[buf], g.nchunks, g.plan, fj, stream);
+        else
+            (void)launch_gram_bf16_wide(g.grid, fold.P != nullptr ? 256 : 0, Xb, n, ld, shift, ws.partial[buf],
+                                        ws.colsum_partial[buf], g.nchunks, g.plan, fj, stream);
         return;
     }
     if (ws.precision != GS_PREC_F32) {

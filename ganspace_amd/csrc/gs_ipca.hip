@@ -52,6 +52,12 @@ struct gs_ipca {
     double *Bk = nullptr;        // [k*k]   FAITHFUL: Vk Gc Vk^T (diag(lam) unless pending_diag)
     double *T = nullptr;         // [k*dp]  FAITHFUL: Bk Vk
     bool pending_diag = false;   // FAITHFUL: (Vk, Bk) is an undiagonalised basis; lam / outs / comp32 are stale
+    // EXACT, gs_ipca_update_resident: rows the caller keeps valid until the next finalize - contiguous calls are
+    // merged and contracted in launches of kResidentRows rows (the d = 512 kernels want long launches: one slab per
+    // workgroup pair per launch)
+    const float *res_ptr = nullptr;
+    int64_t res_rows = 0, res_ld = 0;
+    bool res_acc = false;        // the accumulators already hold earlier blocks (first launch overwrites otherwise)
     double *scal = nullptr;      // [8]     device scalars: [0]=trace
     double *outs = nullptr;      // [3*k]   sv, ev, evr
     float *comp32 = nullptr;     // [k*d]
@@ -417,8 +423,27 @@ int faithful_materialize(gs_ipca *h, hipStream_t stream) {
     return GS_OK;
 }
 
+constexpr int64_t kResidentRows = 131072;
+
+// contract the resident rows that are still pending: whole launches of kResidentRows, and the rest if `all`
+int resident_flush(gs_ipca *h, bool all, hipStream_t stream) {
+    while (h->res_rows > 0 && (all || h->res_rows >= kResidentRows)) {
+        const int64_t n = h->res_rows < kResidentRows ? h->res_rows : kResidentRows;
+        int rc = gram_update(h->gws, h->res_ptr, n, h->res_ld, h->d, h->shift, h->G64, h->S1, h->res_acc, /*defer=*/true,
+                             stream);
+        if (rc != GS_OK) return rc;
+        h->res_acc = true;
+        h->res_ptr += n * h->res_ld;
+        h->res_rows -= n;
+    }
+    if (h->res_rows == 0) h->res_ptr = nullptr;
+    return GS_OK;
+}
+
 int exact_solve(gs_ipca *h, hipStream_t stream) {
     const int d = (int)h->d, dp = (int)h->dp;
+    int rcr = resident_flush(h, /*all=*/true, stream);
+    if (rcr != GS_OK) return rcr;
     int rcf = gram_flush(h->gws, h->G64, h->S1, stream);
     if (rcf != GS_OK) return rcf;
     GS_HIP_CHECK(hipMemsetAsync(h->scal, 0, sizeof(double) * 8, stream));
@@ -564,6 +589,9 @@ int gs_ipca_reset(gs_ipca_t *h) {
     h->ss.sws.inv_ratio1 = 0.0;
     h->ss.w_state = false;
     h->pending_diag = false;
+    h->res_ptr = nullptr;
+    h->res_rows = 0;
+    h->res_acc = false;
     return GS_OK;
 }
 
@@ -607,9 +635,12 @@ int gs_ipca_update(gs_ipca_t *h, const float *X, int64_t rows, int64_t ld, void 
         if (rc != GS_OK) return rc;
     }
     if (h->mode == GS_MODE_EXACT) {
-        // the fold of this block's slabs rides on the spare workgroups of the NEXT block's launch
-        int rc = gram_update(h->gws, X, rows, ld, d, h->shift, h->G64, h->S1, h->n_seen > 0, /*defer=*/true, stream);
+        int rc = resident_flush(h, /*all=*/true, stream);      // (rows promised earlier come first)
         if (rc != GS_OK) return rc;
+        // the fold of this block's slabs rides on the spare workgroups of the NEXT block's launch
+        rc = gram_update(h->gws, X, rows, ld, d, h->shift, h->G64, h->S1, h->res_acc, /*defer=*/true, stream);
+        if (rc != GS_OK) return rc;
+        h->res_acc = true;
         h->n_seen += rows;
         h->blocks += 1;
         h->finalized = false;
@@ -654,6 +685,34 @@ int gs_ipca_update(gs_ipca_t *h, const float *X, int64_t rows, int64_t ld, void 
     return GS_OK;
 }
 
+int gs_ipca_update_resident(gs_ipca_t *h, const float *X, int64_t rows, int64_t ld, void *stream_) {
+    GS_REQUIRE(h != nullptr && X != nullptr, GS_EINVAL, "gs_ipca_update_resident: NULL argument");
+    if (h->mode != GS_MODE_EXACT) return gs_ipca_update(h, X, rows, ld, stream_);   // the recurrences need the block now
+    GS_REQUIRE(rows >= 1 && ld >= h->d, GS_EINVAL, "gs_ipca_update: need rows >= 1 and ld >= d");
+    hipStream_t stream = (hipStream_t)stream_;
+    const int d = (int)h->d, dp = (int)h->dp;
+    if (h->n_seen == 0) {
+        GS_REQUIRE(h->k <= rows, GS_EINVAL,
+                   "n_components must be less or equal to the batch number of samples for the first "
+                   "partial_fit call");
+        int rc = column_means_f32(X, rows, ld, d, dp, h->shift, h->vec, stream);
+        if (rc != GS_OK) return rc;
+    }
+    if (h->res_rows > 0 && (ld != h->res_ld || X != h->res_ptr + h->res_rows * h->res_ld)) {
+        int rc = resident_flush(h, /*all=*/true, stream);       // not the continuation of the pending rows
+        if (rc != GS_OK) return rc;
+    }
+    if (h->res_rows == 0) {
+        h->res_ptr = X;
+        h->res_ld = ld;
+    }
+    h->res_rows += rows;
+    h->n_seen += rows;
+    h->blocks += 1;
+    h->finalized = false;
+    return resident_flush(h, /*all=*/false, stream);
+}
+
 int64_t gs_ipca_state_nbytes(const gs_ipca_t *h) {
     if (!h) return GS_EINVAL;
     return (int64_t)sizeof(double) * (1 + h->d + h->d * h->d);
@@ -686,6 +745,9 @@ int gs_ipca_state_import(gs_ipca_t *h, const double *state, void *stream_) {
     GS_HIP_CHECK(hipStreamSynchronize(stream));
     GS_REQUIRE(n >= 0 && n == std::floor(n), GS_EINVAL, "gs_ipca_state_import: bad sample count");
     h->gws.pend_valid = false;  // the imported state replaces everything accumulated so far
+    h->res_ptr = nullptr;
+    h->res_rows = 0;
+    h->res_acc = n > 0;
     hipLaunchKernelGGL(state_import_kernel, dim3((unsigned)ceil_div(dp, 256), (unsigned)dp), dim3(256), 0,
                        stream, state, h->G64, h->S1, h->shift, d, dp);
     GS_HIP_CHECK(hipGetLastError());

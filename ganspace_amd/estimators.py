@@ -58,6 +58,7 @@ class _DeviceIncrementalPCA:
         self._mode = mode
         self._device = device
         self._h = None
+        self._resident_refs = []        # tensors handed over with resident=True, released once their rows are contracted
         self._d = None
         self._cache = None
         self._lib = _lib.load()
@@ -108,16 +109,26 @@ class _DeviceIncrementalPCA:
             X = X.contiguous()
         return X
 
-    def partial_fit(self, X, y=None, check_input=True):
-        """One block; ``X`` may be a host ndarray or a device tensor ``[m, d]`` float32."""
+    def partial_fit(self, X, y=None, check_input=True, resident=False):
+        """One block; ``X`` may be a host ndarray or a device tensor ``[m, d]`` float32.
+
+        ``resident=True`` (device tensors only) promises that the rows stay valid and unchanged until the results are
+        read - slices of a resident latent array, for instance.  The exact mode then merges contiguous blocks into
+        long Gram launches (``gs_ipca_update_resident``); a reference to the tensor is kept until then."""
         if self.n_components > np.shape(X)[1]:
             raise ValueError(
                 f"n_components={self.n_components} invalid for n_features={np.shape(X)[1]}, need more rows "
                 "than columns for IncrementalPCA processing")
         Xd = self._as_device_rows(X)
         self._ensure(Xd.shape[1])
-        rc = self._lib.gs_ipca_update(self._h, C.c_void_p(Xd.data_ptr()), Xd.shape[0], Xd.stride(0),
-                                      _lib.current_stream_ptr())
+        torch = _torch()
+        if resident and torch.is_tensor(X) and Xd.data_ptr() == X.data_ptr():
+            self._resident_refs.append(Xd)       # keeps the storage alive until the next _results()
+            rc = self._lib.gs_ipca_update_resident(self._h, C.c_void_p(Xd.data_ptr()), Xd.shape[0], Xd.stride(0),
+                                                   _lib.current_stream_ptr())
+        else:
+            rc = self._lib.gs_ipca_update(self._h, C.c_void_p(Xd.data_ptr()), Xd.shape[0], Xd.stride(0),
+                                          _lib.current_stream_ptr())
         if rc == _lib.GS_EINVAL:
             raise ValueError(self._lib.gs_last_error().decode())
         _lib.check(rc)
@@ -154,6 +165,7 @@ class _DeviceIncrementalPCA:
             p = lambda a: a.ctypes.data_as(C.c_void_p)
             _lib.check(self._lib.gs_ipca_finalize(self._h, p(comp), p(sv), p(mean), p(var), p(ev), p(evr),
                                                   C.cast(C.byref(n), C.c_void_p), _lib.current_stream_ptr()))
+            self._resident_refs.clear()       # finalize contracted every pending row and synchronised
             self._cache = dict(components_=comp, singular_values_=sv, mean_=mean, var_=var,
                                explained_variance_=ev, explained_variance_ratio_=evr,
                                n_samples_seen_=np.int64(n.value))
@@ -236,9 +248,9 @@ class IPCAEstimator:
     def fit(self, X):
         self.transformer.fit(X)
 
-    def fit_partial(self, X):
+    def fit_partial(self, X, resident=False):
         try:
-            self.transformer.partial_fit(X)
+            self.transformer.partial_fit(X, resident=resident)
             return True
         except ValueError as e:          # estimators.py:74-76
             print(f"\nIPCA error:", e)

@@ -90,6 +90,14 @@ int gs_ipca_reset(gs_ipca_t *h);
  * block (reference: ValueError -> fit_partial returns False).                          */
 int gs_ipca_update(gs_ipca_t *h, const float *X, int64_t rows, int64_t ld, void *stream);
 
+/* Same as gs_ipca_update for rows that STAY VALID AND UNCHANGED until the next gs_ipca_finalize /
+ * gs_ipca_state_export / gs_ipca_reset of this handle (e.g. slices of a resident latent array,
+ * decomposition.py:226-236 keeps all of them).  GS_MODE_EXACT may then postpone the contraction and
+ * merge contiguous calls (X == previous X + previous rows * ld) into launches of 131 072 rows - the
+ * d = 512 kernels hold the whole Gram triangle in registers and write one slab per launch, so long
+ * launches are what makes them pay.  Other modes treat it as gs_ipca_update.                      */
+int gs_ipca_update_resident(gs_ipca_t *h, const float *X, int64_t rows, int64_t ld, void *stream);
+
 /* Sufficient statistics for resume and for the multi-GPU merge (new design):
  * state = float64 [ n | mean(d) | C(d*d) ] with C the centred scatter sum (x-mean)(x-mean)^T
  * (EXACT mode).  export/import move it to/from a caller (torch) buffer so that

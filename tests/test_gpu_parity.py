@@ -675,3 +675,44 @@ def test_faithful_deferred_path_falls_back_when_its_assumptions_break(dev, case)
     np.testing.assert_allclose(est.transformer.singular_values_[live], svo[live], rtol=1e-4)
     np.testing.assert_allclose(est.transformer.singular_values_, svo, atol=5e-4 * svo[0])
     np.testing.assert_allclose(est.transformer.mean_, orc.transformer.mean_, atol=2e-6)
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
+def test_exact_mode_resident_rows_are_merged_and_match_block_by_block(dev, precision):
+    """fit_partial(X, resident=True): the exact mode may postpone the contraction of rows the caller keeps alive and
+    merge contiguous calls into launches of 131 072 rows (d = 512: the wide kernels).  Same statistics as feeding the
+    blocks one by one - also when a call is not the continuation of the previous one, when resident and ordinary
+    calls alternate, and when the state is exported in between."""
+    from ganspace_amd.estimators import IPCAEstimator
+    rng = np.random.default_rng(5)
+    d, k = 512, 24
+    A = rng.standard_normal((64, d)) * (1.25 ** -np.arange(64))[:, None]
+    big = torch.from_numpy((rng.standard_normal((300000, 64)) @ A + 0.05 * rng.standard_normal((300000, d)) + 0.2)
+                           .astype(np.float32)).to(dev)
+    pieces = [(0, 50000), (50000, 120000), (120000, 170000),      # contiguous: one 131 072-row launch + a rest
+              (200000, 260000),                                     # gap: not a continuation
+              (170000, 200000)]                                     # ordinary call in between
+    a = IPCAEstimator(k, "exact", precision=precision)
+    b = IPCAEstimator(k, "exact", precision=precision)
+    for i, (lo, hi) in enumerate(pieces):
+        assert a.fit_partial(big[lo:hi], resident=(i != 4))
+        assert b.fit_partial(big[lo:hi].clone())
+        if i == 2:
+            st = a.transformer.export_state()               # flushes what is pending
+            assert float(st[0].item()) == 170000.0
+    assert a.fit_partial(big[260000:300000], resident=True)   # still pending when the components are read
+    assert b.fit_partial(big[260000:300000].clone())
+    ca, cb = a.get_components()[0], b.get_components()[0]
+    cos = np.abs(O.signed_cosines(ca, cb))
+    assert cos.min() > 1 - (1e-6 if precision == "f32" else 2e-5), cos.min()
+    np.testing.assert_allclose(a.transformer.singular_values_, b.transformer.singular_values_, rtol=2e-6 if precision == "f32" else 1e-4)
+    np.testing.assert_allclose(a.transformer.mean_, b.transformer.mean_, atol=1e-6)
+    np.testing.assert_allclose(a.transformer.var_, b.transformer.var_, rtol=1e-5)
+    assert int(a.transformer.n_samples_seen_) == 300000
+    # against float64 on the host
+    Xh = big.cpu().numpy().astype(np.float64)
+    order = [r for lo, hi in pieces for r in range(lo, hi)] + list(range(260000, 300000))
+    Xc = Xh[order] - Xh[order].mean(0)
+    w, V = np.linalg.eigh(Xc.T @ Xc)
+    ref = V[:, ::-1][:, :k].T
+    assert np.abs(O.signed_cosines(ca, ref)).min() > 1 - (2e-6 if precision == "f32" else 3e-5)
