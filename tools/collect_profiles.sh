@@ -4,7 +4,7 @@
 # usage: tools/collect_profiles.sh <tag>      -> gpurun_out/<tag>/...
 set -u
 TAG=${1:-r1}
-ROWS=${GS_PROBE_ROWS:-50000}
+ROWS=${GS_PROBE_ROWS:-131072}
 export GS_PROBE_ROWS=$ROWS
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/$TAG

@@ -8,7 +8,7 @@ import os
 import sys
 
 root = sys.argv[1]
-PROBE_ROWS = int(os.environ.get("GS_PROBE_ROWS", "50000"))
+PROBE_ROWS = int(os.environ.get("GS_PROBE_ROWS", "131072"))
 print(f"# rocprofv3 summary ({root})\n")
 ks = os.path.join(root, "bench_trace", "b_kernel_stats.csv")
 if os.path.exists(ks):
@@ -52,7 +52,7 @@ if len(sys.argv) > 2:
             continue
         acc = collections.defaultdict(list)
         for r in csv.DictReader(open(p)):
-            if "gram_partial_kernel" in r["Kernel_Name"]:
+            if "gram_f32_wide_kernel" in r["Kernel_Name"] or "gram_partial_kernel" in r["Kernel_Name"]:
                 acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
         for c, x in acc.items():
             vals[c] = (sum(x) / len(x), len(x))
@@ -61,7 +61,8 @@ if len(sys.argv) > 2:
     alg = PROBE_ROWS * 512 * 4
     rd, wr = int(fetch[0] * 2 * 1024), int(write[0] * 1024)
     out = {
-        "kernel": "gram_partial_kernel", "rows_per_launch": PROBE_ROWS, "launches": fetch[1],
+        "kernel": "gram_f32_wide_kernel (d = 512, >= 20 000 rows) / gram_partial_kernel", "rows_per_launch": PROBE_ROWS,
+        "launches": fetch[1],
         "FETCH_SIZE_KiB_raw": round(fetch[0], 1),
         "hbm_read_bytes_per_launch_corrected_x2": rd,
         "WRITE_SIZE_KiB_raw": round(write[0], 1), "hbm_write_bytes_per_launch": wr,
