@@ -5,8 +5,9 @@
 // 3 row chunks x 10 tiles on its 32 CUs, and the 4 diagonal tiles of a chunk have 3/4 of the per-SIMD matrix work:
 // 27 of 32 CU slots do useful work (84 %), which together with the ~15 % of prologue / epilogue per short chunk is
 // why that kernel stops at 0.55 of the f32-MFMA peak.  Here the 136 sub-tiles (32 x 32) of the upper triangle are
-// split over the two workgroups of a pair (68 each: waves 0-5 a 4 x 2 rectangle, waves 6-7 the 10 upper sub-tiles of
-// a diagonal 128-column block; 16 / 16 / 18 / 18 sub-tiles per SIMD = 94 % balance), every workgroup stages each
+// split over the two workgroups of a pair (68 each: waves 0-5 a 4 x 2 rectangle, waves 6-7 the upper sub-tiles of
+// a diagonal 128-column block - one of its ten handed to a rectangle wave that already holds that block's fragment,
+// so that every SIMD carries 17 sub-tiles), every workgroup stages each
 // 16-row k-step of all 512 columns once (four float4 loads per thread, shift subtracted, ds_write_b128) and every CU of
 // the chip does the same amount of work.  v_mfma_f32_32x32x2_f32: lane l supplies column (l & 31) of its 32-column
 // block for row 2 kk + (l >> 5) - a ds_read_b32 straight out of the row-major image (rows 544 floats apart, so the
@@ -26,7 +27,10 @@ constexpr int kFRowFloats = 512 + 32;                 // row stride of the LDS i
 constexpr int kFStageFloats = 16 * kFRowFloats;       // one k-step: 16 rows
 constexpr int kFStageBytes = kFStageFloats * 4;
 
-template <bool DIAGROLE>
+// XOP: rectangle waves - operand index (0-3 = A fragment, 4-5 = B fragment) whose diagonal sub-tile this wave computes
+// on top of its eight (-1: none).  SKIP: diagonal waves - index (in the a <= b enumeration) of the sub-tile it leaves to
+// a rectangle wave.
+template <bool DIAGROLE, int XOP, int SKIP>
 __device__ __forceinline__ void gram_f32_wide_body(const float *__restrict__ X, int64_t ld, const float *__restrict__ shift,
                                                    float *__restrict__ P, float *__restrict__ CS, int chunk, int64_t r0,
                                                    int64_t r1, int half, int wave, float *lds, int ablate) {
@@ -43,7 +47,7 @@ __device__ __forceinline__ void gram_f32_wide_body(const float *__restrict__ X, 
         ablk0 = I * 4;
         bblk0 = J * 4 + sub * 2;
     }
-    constexpr int NT = DIAGROLE ? 10 : 8;
+    constexpr int NT = DIAGROLE ? 9 : (XOP >= 0 ? 9 : 8);
     f32x16 acc[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[t] = f32x16{0};
@@ -101,13 +105,16 @@ __device__ __forceinline__ void gram_f32_wide_body(const float *__restrict__ X, 
         };
         auto fma = [&](const float (&o)[NOP]) {
             if (DIAGROLE) {
-                int idx = 0;
+                int idx = 0, full = 0;
 #pragma unroll
                 for (int a = 0; a < 4; ++a)
 #pragma unroll
                     for (int b = a; b < 4; ++b) {
-                        acc[idx] = __builtin_amdgcn_mfma_f32_32x32x2f32(o[a], o[b], acc[idx], 0, 0, 0);
-                        ++idx;
+                        if (full != SKIP) {
+                            acc[idx] = __builtin_amdgcn_mfma_f32_32x32x2f32(o[a], o[b], acc[idx], 0, 0, 0);
+                            ++idx;
+                        }
+                        ++full;
                     }
             } else {
 #pragma unroll
@@ -115,6 +122,8 @@ __device__ __forceinline__ void gram_f32_wide_body(const float *__restrict__ X, 
 #pragma unroll
                     for (int b = 0; b < 2; ++b)
                         acc[a * 2 + b] = __builtin_amdgcn_mfma_f32_32x32x2f32(o[a], o[4 + (DIAGROLE ? 0 : b)], acc[a * 2 + b], 0, 0, 0);
+                if (XOP >= 0)
+                    acc[NT - 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(o[XOP < 0 ? 0 : XOP], o[XOP < 0 ? 0 : XOP], acc[NT - 1], 0, 0, 0);
             }
         };
         rd(cur, 0);
@@ -160,15 +169,18 @@ __device__ __forceinline__ void gram_f32_wide_body(const float *__restrict__ X, 
     float *Pc = P + (int64_t)chunk * dp * dp;
     const int cc = lane & 31, hh = lane >> 5;
     if (DIAGROLE) {
-        int idx = 0;
+        int idx = 0, full = 0;
 #pragma unroll
         for (int a = 0; a < 4; ++a)
 #pragma unroll
             for (int b = a; b < 4; ++b) {
-                float *dst = Pc + (int64_t)((ablk0 + a) * 32 + 4 * hh) * dp + (ablk0 + b) * 32 + cc;
+                if (full != SKIP) {
+                    float *dst = Pc + (int64_t)((ablk0 + a) * 32 + 4 * hh) * dp + (ablk0 + b) * 32 + cc;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) dst[(int64_t)((r & 3) + 8 * (r >> 2)) * dp] = acc[idx][r];
-                ++idx;
+                    for (int r = 0; r < 16; ++r) dst[(int64_t)((r & 3) + 8 * (r >> 2)) * dp] = acc[idx][r];
+                    ++idx;
+                }
+                ++full;
             }
     } else {
 #pragma unroll
@@ -179,6 +191,12 @@ __device__ __forceinline__ void gram_f32_wide_body(const float *__restrict__ X, 
 #pragma unroll
                 for (int r = 0; r < 16; ++r) dst[(int64_t)((r & 3) + 8 * (r >> 2)) * dp] = acc[a * 2 + b][r];
             }
+        if (XOP >= 0) {
+            const int xblk = XOP < 4 ? ablk0 + XOP : bblk0 + (XOP - 4);
+            float *dst = Pc + (int64_t)(xblk * 32 + 4 * hh) * dp + xblk * 32 + cc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dst[(int64_t)((r & 3) + 8 * (r >> 2)) * dp] = acc[NT - 1][r];
+        }
     }
     // column sums: the four row-quad threads of a column quad meet in LDS (the two halves computed the same numbers)
     {
@@ -208,10 +226,23 @@ __global__ __launch_bounds__(kFThreads, 1) void gram_f32_wide_kernel(
     int64_t r0, r1;
     chunk_range(plan, chunk, rows, r0, r1);
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-    if (wave < 6)
-        gram_f32_wide_body<false>(X, ld, shift, P, CS, chunk, r0, r1, half, wave, ldsf, ablate);
-    else
-        gram_f32_wide_body<true>(X, ld, shift, P, CS, chunk, r0, r1, half, wave, ldsf, ablate);
+    // The sub-tile a diagonal wave hands over, and who takes it (waves w and w + 4 share a SIMD: 9 + 8 everywhere):
+    //   half 0:  wave 6 (blocks 0-3) gives (3,3) to wave 0 (A fragment 3);  wave 7 (4-7) gives (7,7) to wave 1 (B fragment 1)
+    //   half 1:  wave 6 (8-11) gives (9,9) to wave 0 (B fragment 1);  wave 7 (12-15) gives (15,15) to wave 5 (B fragment 1)
+#define GS_WIDE_ARGS X, ld, shift, P, CS, chunk, r0, r1, half, wave, ldsf, ablate
+    if (wave >= 6) {
+        if (half == 1 && wave == 6)
+            gram_f32_wide_body<true, -1, 4>(GS_WIDE_ARGS);
+        else
+            gram_f32_wide_body<true, -1, 9>(GS_WIDE_ARGS);
+    } else if (half == 0 && wave == 0) {
+        gram_f32_wide_body<false, 3, -1>(GS_WIDE_ARGS);
+    } else if ((half == 0 && wave == 1) || (half == 1 && (wave == 0 || wave == 5))) {
+        gram_f32_wide_body<false, 5, -1>(GS_WIDE_ARGS);
+    } else {
+        gram_f32_wide_body<false, -1, -1>(GS_WIDE_ARGS);
+    }
+#undef GS_WIDE_ARGS
 }
 
 int launch_gram_f32_wide(int grid, int nfold, const float *X, int64_t n, int64_t ld, const float *shift, float *P,
