@@ -383,7 +383,10 @@ __device__ __forceinline__ void split4(const float (&v)[4], uint2 (&planes)[2]) 
     planes[1] = make_uint2(mid[0], mid[1]);
 }
 
-template <bool DIAGROLE, bool MMA_FIRST>
+// XOP: rectangle waves - fragment index (0-3 = A block, 4-5 = B block) whose diagonal sub-tile this wave computes on
+// top of its eight (-1: none).  SKIP: diagonal waves - index (a <= b enumeration) of the sub-tile left to a rectangle
+// wave.  With that every SIMD carries 17 sub-tiles (see gs_gram_wide.hip).
+template <bool DIAGROLE, int XOP, int SKIP>
 __device__ __forceinline__ void gram_wide_body(const float *__restrict__ X, int64_t ld, const float *__restrict__ shift,
                                                float *__restrict__ P, float *__restrict__ CS, int chunk, int64_t r0,
                                                int64_t r1, int half, int wave, unsigned char *lds, int ablate) {
@@ -400,7 +403,7 @@ __device__ __forceinline__ void gram_wide_body(const float *__restrict__ X, int6
         ablk0 = I * 4;
         bblk0 = J * 4 + sub * 2;
     }
-    constexpr int NT = DIAGROLE ? 10 : 8;
+    constexpr int NT = 9 - ((!DIAGROLE && XOP < 0) ? 1 : 0);
     f32x16 acc[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[t] = f32x16{0};
@@ -461,13 +464,16 @@ __device__ __forceinline__ void gram_wide_body(const float *__restrict__ X, int6
                 for (int q = 0; q < 4; ++q) F[pl][q] = frag(buf, pl, ablk0 + q);
 #pragma unroll
             for (int t = 0; t < 3; ++t) {
-                int idx = 0;
+                int idx = 0, full = 0;
 #pragma unroll
                 for (int a = 0; a < 4; ++a)
 #pragma unroll
                     for (int b = a; b < 4; ++b) {
-                        acc[idx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F[PA[t]][a], F[PB[t]][b], acc[idx], 0, 0, 0);
-                        ++idx;
+                        if (full != SKIP) {
+                            acc[idx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F[PA[t]][a], F[PB[t]][b], acc[idx], 0, 0, 0);
+                            ++idx;
+                        }
+                        ++full;
                     }
             }
         } else {
@@ -480,17 +486,24 @@ __device__ __forceinline__ void gram_wide_body(const float *__restrict__ X, int6
                 for (int q = 0; q < 2; ++q) B[pl][q] = frag(buf, pl, bblk0 + q);
             }
 #pragma unroll
-            for (int t = 0; t < 3; ++t)
+            for (int t = 0; t < 3; ++t) {
 #pragma unroll
                 for (int a = 0; a < 4; ++a)
 #pragma unroll
                     for (int b = 0; b < 2; ++b)
                         acc[a * 2 + b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[PA[t]][a], B[PB[t]][b], acc[a * 2 + b], 0, 0, 0);
+                if (XOP >= 0) {
+                    constexpr int xo = XOP < 0 ? 0 : XOP;
+                    const bf16x8 xa = xo < 4 ? A[PA[t]][xo & 3] : B[PA[t]][(xo - 4) & 1];
+                    const bf16x8 xb = xo < 4 ? A[PB[t]][xo & 3] : B[PB[t]][(xo - 4) & 1];
+                    acc[NT - 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa, xb, acc[NT - 1], 0, 0, 0);
+                }
+            }
         }
     };
 
     // ---- pipeline: loads of k-step s + 2 | MFMA on k-step s | split + write k-step s + 1 | barrier ----
-    // (MMA_FIRST = false - split / write before the MFMAs - exists for the ordering experiments of the launcher)
+    // (the split / write phase before the MFMAs, in all or in half of the waves, measured 2-13 % slower)
     const int64_t nrows = r1 - r0;
     const int nst = (int)((nrows + 15) / 16);
     float4 f0[4], f1[4];
@@ -503,13 +516,8 @@ __device__ __forceinline__ void gram_wide_body(const float *__restrict__ X, int6
         const int buf = s & 1;
         if (!(ablate & 4)) fetch(fnext2, r0 + (int64_t)(s + 2) * 16);
         __builtin_amdgcn_sched_barrier(0);          // the loads go out first: two k-steps of latency cover
-        if (MMA_FIRST) {
-            if (!(ablate & 1)) mma(buf);
-            if (!(ablate & 2)) stash(fnext1, buf ^ 1, r0 + (int64_t)(s + 1) * 16);
-        } else {
-            if (!(ablate & 2)) stash(fnext1, buf ^ 1, r0 + (int64_t)(s + 1) * 16);
-            if (!(ablate & 1)) mma(buf);
-        }
+        if (!(ablate & 1)) mma(buf);
+        if (!(ablate & 2)) stash(fnext1, buf ^ 1, r0 + (int64_t)(s + 1) * 16);
         __syncthreads();
         ++s;
     };
@@ -525,29 +533,31 @@ __device__ __forceinline__ void gram_wide_body(const float *__restrict__ X, int6
     // the upper triangle through LDS so the slab is exactly symmetric
     float *Pc = P + (int64_t)chunk * dp * dp;
     const int cc = lane & 31, hh = lane >> 5;
-    if (DIAGROLE) {
-        float *t = reinterpret_cast<float *>(lds) + (wave - 6) * (32 * 33);
-        constexpr int diag_idx[4] = {0, 4, 7, 9};
+    float *t = reinterpret_cast<float *>(lds + 32768) + wave * (32 * 33);      // behind the column-sum scratch
+    auto mirror = [&](f32x16 &a) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int r = 0; r < 16; ++r) t[((r & 3) + 8 * (r >> 2) + 4 * hh) * 33 + cc] = a[r];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) t[((r & 3) + 8 * (r >> 2) + 4 * hh) * 33 + cc] = acc[diag_idx[q]][r];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;
-                const float m = t[cc * 33 + row];
-                if (row > cc) acc[diag_idx[q]][r] = m;
-            }
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;
+            const float m = t[cc * 33 + row];
+            if (row > cc) a[r] = m;
         }
-        int idx = 0;
+    };
+    if (DIAGROLE) {
+        int idx = 0, full = 0;
 #pragma unroll
         for (int a = 0; a < 4; ++a)
 #pragma unroll
             for (int b = a; b < 4; ++b) {
-                float *dst = Pc + (int64_t)((ablk0 + a) * 32 + 4 * hh) * dp + (ablk0 + b) * 32 + cc;
+                if (full != SKIP) {
+                    if (a == b) mirror(acc[idx]);
+                    float *dst = Pc + (int64_t)((ablk0 + a) * 32 + 4 * hh) * dp + (ablk0 + b) * 32 + cc;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) dst[(int64_t)((r & 3) + 8 * (r >> 2)) * dp] = acc[idx][r];
-                ++idx;
+                    for (int r = 0; r < 16; ++r) dst[(int64_t)((r & 3) + 8 * (r >> 2)) * dp] = acc[idx][r];
+                    ++idx;
+                }
+                ++full;
             }
     } else {
 #pragma unroll
@@ -558,6 +568,13 @@ __device__ __forceinline__ void gram_wide_body(const float *__restrict__ X, int6
 #pragma unroll
                 for (int r = 0; r < 16; ++r) dst[(int64_t)((r & 3) + 8 * (r >> 2)) * dp] = acc[a * 2 + b][r];
             }
+        if (XOP >= 0) {
+            const int xblk = XOP < 4 ? ablk0 + XOP : bblk0 + (XOP - 4);
+            mirror(acc[NT - 1]);
+            float *dst = Pc + (int64_t)(xblk * 32 + 4 * hh) * dp + xblk * 32 + cc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dst[(int64_t)((r & 3) + 8 * (r >> 2)) * dp] = acc[NT - 1][r];
+        }
     }
     // column sums: the four row-quad threads of a column quad meet in LDS (the two halves computed the same numbers)
     {
@@ -589,20 +606,21 @@ __global__ __launch_bounds__(kWThreads, 1) void gram_bf16_wide_kernel(
     chunk_range(plan, chunk, rows, r0, r1);
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     // waves w and w + 4 share a SIMD: 0-3 run MFMA then split / write, 4-7 the other way round
-    // GS_GRAM_ABLATE bit 3: waves 4-7 run split / write before MFMA; bit 4: odd waves do (experiments on which waves
-    // share a SIMD - neither order beat "MFMA first" everywhere)
-    const bool second = ((ablate & 8) && wave >= 4) || ((ablate & 16) && (wave & 1));
-    if (wave < 6) {
-        if (second)
-            gram_wide_body<false, false>(X, ld, shift, P, CS, chunk, r0, r1, half, wave, lds, ablate);
+    // who takes the sub-tile a diagonal wave hands over: see gram_f32_wide_kernel (gs_gram_wide.hip)
+#define GS_WIDE_ARGS X, ld, shift, P, CS, chunk, r0, r1, half, wave, lds, ablate
+    if (wave >= 6) {
+        if (half == 1 && wave == 6)
+            gram_wide_body<true, -1, 4>(GS_WIDE_ARGS);
         else
-            gram_wide_body<false, true>(X, ld, shift, P, CS, chunk, r0, r1, half, wave, lds, ablate);
+            gram_wide_body<true, -1, 9>(GS_WIDE_ARGS);
+    } else if (half == 0 && wave == 0) {
+        gram_wide_body<false, 3, -1>(GS_WIDE_ARGS);
+    } else if ((half == 0 && wave == 1) || (half == 1 && (wave == 0 || wave == 5))) {
+        gram_wide_body<false, 5, -1>(GS_WIDE_ARGS);
     } else {
-        if (second)
-            gram_wide_body<true, false>(X, ld, shift, P, CS, chunk, r0, r1, half, wave, lds, ablate);
-        else
-            gram_wide_body<true, true>(X, ld, shift, P, CS, chunk, r0, r1, half, wave, lds, ablate);
+        gram_wide_body<false, -1, -1>(GS_WIDE_ARGS);
     }
+#undef GS_WIDE_ARGS
 }
 
 int launch_gram_bf16_wide(int grid, int nfold, const float *X, int64_t n, int64_t ld, const float *shift, float *P,
