@@ -30,10 +30,11 @@ def shard_range(n_items: int, rank: int, world: int):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def _recenter(state, d, new_mean):
-    """``C += n (mean-new)(mean-new)^T ; mean = new`` in place on a state vector."""
+def _recenter(state, d, new_mean, n_local=None):
+    """``C += n (mean-new)(mean-new)^T ; mean = new`` in place on a state vector.  ``n_local`` = the state's sample
+    count when the caller knows it on the host (saves a device round trip)."""
     import torch
-    if float(state[0]) <= 0:
+    if (float(state[0]) if n_local is None else n_local) <= 0:
         state[1:1 + d] = new_mean.to(state.dtype)       # an empty state has no scatter to move
         return state
     if state.is_cuda:
@@ -66,40 +67,49 @@ def merge_states(states, d):
 PACK_MAX_FEATURES = 4096     # beyond this the index tensors of the packing cost more than the bytes they save
 
 
+_TRIU = {}
+
+
+def _triu_flat(d, device):
+    """Flat indices (into the row-major d*d buffer) of the upper triangle and of its mirror image, cached."""
+    import torch
+    key = (int(d), str(device))
+    if key not in _TRIU:
+        iu = torch.triu_indices(d, d, device=device)
+        _TRIU[key] = (iu[0] * d + iu[1], iu[1] * d + iu[0])
+    return _TRIU[key]
+
+
 def pack_upper(scatter, d):
     """Row-major upper triangle (diagonal included) of a symmetric ``d x d`` matrix stored flat: d(d+1)/2 values."""
-    import torch
-    iu = torch.triu_indices(d, d, device=scatter.device)
-    return scatter.view(d, d)[iu[0], iu[1]].contiguous()
+    up, _ = _triu_flat(d, scatter.device)
+    return scatter.reshape(-1)[up]
 
 
 def unpack_upper(packed, d, out):
     """Inverse of :func:`pack_upper` into the flat ``d*d`` buffer ``out`` (both triangles filled)."""
-    import torch
-    iu = torch.triu_indices(d, d, device=packed.device)
-    m = out.view(d, d)
-    m.zero_()
-    m[iu[0], iu[1]] = packed
-    diag = m.diagonal().clone()
-    m.add_(m.T.clone())
-    m.diagonal().copy_(diag)
+    up, lo = _triu_flat(d, packed.device)
+    flat = out.reshape(-1)
+    flat[lo] = packed
+    flat[up] = packed
     return out
 
 
-def allreduce_state(state, d, group=None):
+def allreduce_state(state, d, group=None, n_local=None):
     """In-place global merge of every rank's exported state: a sum all-reduce of ``[n | n mean]``, the Chan
-    re-centring about the global mean, then a sum all-reduce of the (packed) centred scatter."""
+    re-centring about the global mean, then a sum all-reduce of the (packed) centred scatter.  ``n_local``: this
+    rank's sample count if known on the host (no device round trip then)."""
     import torch
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()):
         return state
     hdr = torch.cat([state[:1], state[0] * state[1:1 + d]])
     dist.all_reduce(hdr, op=dist.ReduceOp.SUM, group=group)
-    total = float(hdr[0])
-    if total <= 0:
-        return state                              # nobody has seen a sample
+    if n_local is None or n_local <= 0:
+        if float(hdr[0]) <= 0:
+            return state                          # nobody has seen a sample
     mean = hdr[1:] / hdr[0]
-    _recenter(state, d, mean)
+    _recenter(state, d, mean, n_local)
     scatter = state[1 + d:]
     if d <= PACK_MAX_FEATURES:
         packed = pack_upper(scatter, d)
@@ -120,6 +130,6 @@ def allreduce_estimator(estimator, group=None, d=None):
             raise RuntimeError("allreduce_estimator: this rank fitted no block; pass d= so that it can join with "
                                "an empty state")
         t._ensure(int(d))
-    st = allreduce_state(t.export_state(), t._d, group)
+    st = allreduce_state(t.export_state(), t._d, group, n_local=getattr(t, "_n_host", None))
     t.import_state(st, t._d)
     return estimator

@@ -59,6 +59,7 @@ class _DeviceIncrementalPCA:
         self._device = device
         self._h = None
         self._resident_refs = []        # tensors handed over with resident=True, released once their rows are contracted
+        self._n_host = 0                # samples fed through this object (None once a state was imported)
         self._d = None
         self._cache = None
         self._lib = _lib.load()
@@ -132,6 +133,8 @@ class _DeviceIncrementalPCA:
         if rc == _lib.GS_EINVAL:
             raise ValueError(self._lib.gs_last_error().decode())
         _lib.check(rc)
+        if self._n_host is not None:
+            self._n_host += int(Xd.shape[0])
         # a temporary device copy of a host block is released to torch's caching allocator here;
         # reuse is stream-ordered behind the kernels just enqueued on the current stream
         self._cache = None
@@ -141,6 +144,8 @@ class _DeviceIncrementalPCA:
         """sklearn ``IncrementalPCA.fit``: batches of ``batch_size`` (last one merged if < k)."""
         if self._h is not None:
             _lib.check(self._lib.gs_ipca_reset(self._h))
+            self._n_host = 0
+            self._resident_refs.clear()
         n = np.shape(X)[0]
         bs, k = self.batch_size, self.n_components
         start = 0
@@ -224,7 +229,8 @@ class _DeviceIncrementalPCA:
             self._ensure(d)
         st = state.to(device=self._device, dtype=torch.float64).contiguous()
         _lib.check(self._lib.gs_ipca_state_import(self._h, C.c_void_p(st.data_ptr()), _lib.current_stream_ptr()))
-        torch.cuda.current_stream().synchronize()
+        # (the import reads the sample count on the host and has synchronised the stream: `st` may be released)
+        self._n_host = None
         self._cache = None
         return self
 
