@@ -75,7 +75,7 @@ def make_blocks(n_blocks, dev, rank=0, world=1):
     steps = [flat[starts[i] - row0:starts[i] - row0 + BLOCKS_PER_STEP * NB] for i in range(0, len(starts), BLOCKS_PER_STEP)]
     global RESIDENT_ROWS
     RESIDENT_ROWS = flat[starts[0] - row0:starts[-1] - row0 + NB]     # this rank's rows, contiguous
-    return blocks, steps, time.perf_counter() - t0
+    return blocks, steps, time.perf_counter() - t0, model
 
 
 def gram_kernel_us(lib, _lib, est, block, iters=50):
@@ -95,6 +95,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-blocks", type=int, default=16)
     ap.add_argument("--no-wide", action="store_true", help="skip the cfg3/cfg5-shape small-side timings")
+    ap.add_argument("--wide-cpu-budget-s", type=float, default=45.0,
+                    help="host seconds per wide shape for the scikit-learn baseline (>= 2 blocks are always timed)")
+    ap.add_argument("--wide-cpu-threads", type=int, default=32, help="BLAS threads of that baseline")
     ap.add_argument("--no-extras", action="store_true", help="headline + roofline only (profiling runs)")
     args = ap.parse_args()
 
@@ -103,13 +106,21 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+    # test hooks (tests/test_gpu_distributed.py runs two ranks on the ONE GPU of a test box): transport and device
+    # placement only - everything measured and computed is the same code
+    backend = os.environ.get("GS_BENCH_BACKEND", "nccl")
+    if os.environ.get("GS_BENCH_ONE_DEVICE"):
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1 or "RANK" in os.environ:      # launched by torch.distributed.run (also with one rank)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     from ganspace_amd import _lib, distributed as gdist
@@ -118,7 +129,7 @@ def main():
 
     K, Wm = args.steps, args.warmup
     n_blocks = K * BLOCKS_PER_STEP
-    blocks, step_views, t_sample = make_blocks(n_blocks, dev, rank, world)
+    blocks, step_views, t_sample, model = make_blocks(n_blocks, dev, rank, world)
     log(f"rank {rank}: {len(blocks)} blocks of {NB} W-space rows resident ({t_sample:.1f} s: z stream + mapping network)")
 
     def barrier():
@@ -159,6 +170,8 @@ def main():
         dt = float(tmax.item())
     samples = K * BLOCKS_PER_STEP * NB * world
     value = samples / dt
+    if rank == 0 and os.environ.get("GS_BENCH_DUMP"):       # test hook: the components the timed job produced
+        np.save(os.environ["GS_BENCH_DUMP"], est.get_components()[0])
 
     # ---- split of the job: update loop vs finalize ----------------------------------------------
     est2 = IPCAEstimator(K_COMP, args.mode)
@@ -209,7 +222,8 @@ def main():
                 "algorithmic_flops_per_launch": flops, "algorithmic_bytes_per_launch": bytes_,
                 "hbm_achieved_GBs": round(ach_gbs, 1), "hbm_frac_of_8TBs": round(ach_gbs / PEAK_HBM_GBS, 4),
                 "clock_note": "peak = 2.4 GHz x 256 CU x 4 SIMD x 64 flop/clk; the s_memtime traces of this kernel "
-                              "(DESIGN.md 5) show ~2.05 GHz under load, i.e. ~134 TF is what the clock allows"}
+                              "(DESIGN.md 5) show ~2.05 GHz under ITS load (MFMA + LDS + VALU mix) - a property of the "
+                              "kernel's power draw, not a chip limit (a pure MFMA loop holds 155 TF, MI355X_MICROARCH.md)"}
 
     out = {
         "metric": "latent samples/sec into PCA (n=1e6) + top-20 component cos-sim vs reference",
@@ -236,14 +250,82 @@ def main():
         from oracle.ipca import signed_cosines
         nb = min(args.cpu_blocks, n_blocks)
         host_blocks = [b.cpu().numpy() for b in blocks[:nb]]
-        ref, t_cpu, n_cpu = reference_cpu.time_reference_fit(host_blocks, K_COMP)
-        cores = reference_cpu.host_threads()
-        out["cpu_baseline"] = {"value": round(n_cpu / t_cpu, 1), "unit": "samples/s", "cores": cores,
+        # BLAS thread count: more threads than the (k + NB + 1) x 512 SVD can feed make LAPACK slower, so a few settings
+        # are tried on two steady-state blocks each and the fastest is used (and stated) - the baseline is the best
+        # the host does, not an accident of the default
+        threads, tried = reference_cpu.pick_blas_threads(host_blocks[:3], K_COMP)
+        with reference_cpu.blas_threads(threads):
+            ref, per_block = reference_cpu.time_reference_fit(host_blocks, K_COMP, per_block=True)
+        t_cpu, n_cpu = float(sum(per_block)), nb * NB
+        steady = float(np.mean(per_block[1:])) if nb > 1 else per_block[0]
+        # whole cfg2 job on the CPU (100 blocks per 1e6 samples): first block (float32 SVD, sklearn's dtype behaviour)
+        # + steady-state blocks, extrapolated linearly (cost per block is constant after block 1)
+        job_blocks = K * BLOCKS_PER_STEP
+        t_job_cpu = per_block[0] + (job_blocks - 1) * steady
+        out["cpu_baseline"] = {"value": round(job_blocks * NB / t_job_cpu, 1), "unit": "samples/s", "cores": threads,
                                "kind": "reference",
-                               "sample": f"first {nb} of the {n_blocks} blocks ({n_cpu} samples, {t_cpu:.1f} s): "
-                                         "sklearn IncrementalPCA.partial_fit configured as "
-                                         "estimators.py:59 (the arithmetic the reference executes), "
-                                         f"host cpu_count={os.cpu_count()}"}
+                               "sample": f"first {nb} of the {n_blocks} blocks ({n_cpu} samples, {t_cpu:.1f} s) timed: "
+                                         "sklearn IncrementalPCA.partial_fit configured as estimators.py:59 (the "
+                                         "arithmetic the reference executes); value = the whole job extrapolated "
+                                         "from the first block + steady-state blocks",
+                               "first_block_s": round(per_block[0], 4), "steady_block_s": round(steady, 4),
+                               "steady_samples_per_s": round(NB / steady, 1),
+                               "measured_sample_samples_per_s": round(n_cpu / t_cpu, 1),
+                               "blas_threads_tried_s_per_block": tried, "host_cpu_count": os.cpu_count()}
+        # ---- the TIMED estimator (131 072-row launches of the wide kernel, all K x 5 blocks) against a float64 exact
+        #      PCA of the very rows it consumed: plain torch float64 matmuls on the device, LAPACK eigh on the host
+        from oracle.ipca import flip_rows_largest_abs_positive
+        rows_all = RESIDENT_ROWS[:n_blocks * NB]
+        pilot = rows_all[:NB].double().mean(0)
+        G = torch.zeros((D, D), dtype=torch.float64, device=dev)
+        s1 = torch.zeros(D, dtype=torch.float64, device=dev)
+        for lo in range(0, rows_all.shape[0], 100_000):
+            c = rows_all[lo:lo + 100_000].double() - pilot
+            G += c.T @ c
+            s1 += c.sum(0)
+        n_all = rows_all.shape[0]
+        Cc = (G - torch.outer(s1, s1) / n_all).cpu().numpy()
+        w_ref, V_ref = np.linalg.eigh(Cc)
+        V_ref = V_ref[:, ::-1][:, :K_COMP].T
+        V_ref = V_ref * flip_rows_largest_abs_positive(V_ref)[:, None]
+        sv_ref = np.sqrt(np.maximum(w_ref[::-1][:K_COMP], 0.0))
+        if args.mode == "exact":
+            ct = signed_cosines(est.get_components()[0], V_ref)
+            out["timed_estimator_check"] = {
+                "against": "float64 exact PCA of the same %d rows (torch float64 on the device + LAPACK eigh)" % n_all,
+                "top20_min_signed_cos": round(float(ct[:20].min()), 9), "all80_min_signed_cos": round(float(ct.min()), 9),
+                "singular_values_max_rel_err": float(np.abs(est.transformer.singular_values_ / sv_ref - 1).max()),
+                "mean_max_abs_err": float(np.abs(est.transformer.mean_ - (pilot + s1 / n_all).cpu().numpy()).max())}
+        # ---- T_sample / T_total: the reference's pre-sampling phase (decomposition.py:232-236: one
+        #      sample_latent per batch = per-batch-seeded MT19937 normals on one core, models/wrappers.py:167-174, then
+        #      the mapping network) timed on the host for two batches and extrapolated to the job's n_lat // B batches
+        from oracle import synth
+        Wm_, bm_ = (model.model.style.weight.detach().cpu().numpy(), model.model.style.bias.detach().cpu().numpy())
+        n_batches_job = (job_blocks * NB + NB - 1) // NB + 1
+        t_z, t_map = [], []
+        for seed in (1791095845, 2135392491):
+            t0 = time.perf_counter()
+            z = np.random.RandomState(seed).standard_normal(512 * NB).reshape(NB, 512).astype(np.float32)
+            t_z.append(time.perf_counter() - t0)
+            with reference_cpu.blas_threads(threads):
+                t0 = time.perf_counter()
+                synth.mapping_network(z, Wm_, bm_, lr_mul=0.01, dtype=np.float32)
+                t_map.append(time.perf_counter() - t0)
+        cpu_sample = n_batches_job * (min(t_z) + min(t_map))
+        gpu_total = t_sample + dt
+        out["end_to_end"] = {
+            "gpu": {"T_sample_s": round(t_sample, 3), "T_fit_s": round(dt, 5), "T_total_s": round(gpu_total, 3),
+                    "samples_per_s": round(samples / gpu_total, 1),
+                    "note": "T_sample = z stream on host worker processes + pinned H2D + HIP mapping network; T_fit = the "
+                            "timed region of `value`"},
+            "cpu": {"T_sample_s": round(cpu_sample, 2), "T_fit_s": round(t_job_cpu, 2),
+                    "T_total_s": round(cpu_sample + t_job_cpu, 2),
+                    "samples_per_s": round(job_blocks * NB / (cpu_sample + t_job_cpu), 1),
+                    "z_s_per_batch": round(min(t_z), 4), "mapping_s_per_batch": round(min(t_map), 4),
+                    "kind": "port (NumPy float32 mapping network of oracle/synth.py; the reference runs it on its "
+                            "torch device) + the reference's own RNG calls",
+                    "sample": f"2 of the {n_batches_job} batches of {NB} latents, extrapolated"},
+            "speedup_total": round((cpu_sample + t_job_cpu) / gpu_total, 1)}
         cos = {}
         for mode in ("exact", "faithful"):
             e = IPCAEstimator(K_COMP, mode)
@@ -323,42 +405,96 @@ def main():
             out["split_bf16_modes"] = split
 
     # ---- the wide-feature BASELINE shapes (cfg3 d = 32 768, cfg5 d = 131 072; NB = 2 000, k = 80): PCA-only
-    #      throughput of the small-side recurrence on synthetic low-rank-plus-noise device buffers -----------
+    #      throughput of the small-side recurrence on the synthetic low-rank-plus-noise blocks of SURVEY.md 8d item 5,
+    #      checked in the same run against a float64 restatement of the recurrence (oracle/smallside_torch.py) and timed
+    #      next to scikit-learn on the host ------------------------------------------------------------------------
     if extras and not args.no_wide:
+        from oracle import reference_cpu
+        from oracle.ipca import signed_cosines
+        from oracle.smallside_torch import SmallSideTorchOracle, lowrank_plus_noise_blocks
         wide = {}
+        n_wide = 12
         for name, dd in (("cfg3_shape_d32768", 32768), ("cfg5_shape_d131072", 131072)):
-            entry = {"block_rows": 2000, "mode": "ipca (small-side, sklearn-faithful)"}
-            for prec in ("f32", "bf16x6"):
-                g = torch.Generator(device=dev).manual_seed(7)
-                A = torch.randn(128, dd, device=dev, generator=g) * (1.03 ** -torch.arange(128, device=dev))[:, None]
-                e = IPCAEstimator(K_COMP, "faithful", precision=prec)
-                ts = []
-                for i in range(12):
-                    X = torch.randn(2000, 128, device=dev, generator=g) @ A + 0.05 * torch.randn(2000, dd, device=dev, generator=g) + 0.3
+            entry = {"block_rows": 2000, "mode": "ipca (small-side, sklearn-faithful)", "blocks": n_wide}
+            ests = {p_: IPCAEstimator(K_COMP, "faithful", precision=p_) for p_ in ("f32", "bf16x6")}
+            ts = {p_: [] for p_ in ests}
+            # pass 1: timing only (a host-side step between the blocks - the oracle's LAPACK eigh takes a second -
+            # lets the GPU drop its clocks and the next block pays the wake-up)
+            for p_, e in ests.items():
+                for X in lowrank_plus_noise_blocks(dd, n_wide, rows=2000, device=dev):
                     torch.cuda.synchronize()
                     t0 = time.perf_counter()
                     e.fit_partial(X)
                     torch.cuda.synchronize()
-                    ts.append(time.perf_counter() - t0)
+                    ts[p_].append(time.perf_counter() - t0)
                     del X
+            # pass 2: the float64 oracle on the same (regenerated) blocks
+            orc = SmallSideTorchOracle(K_COMP)
+            host_blocks = []
+            cpu_keep = 6 if not args.no_cpu_baseline else 0      # first block + up to five steady-state blocks
+            for i, X in enumerate(lowrank_plus_noise_blocks(dd, n_wide, rows=2000, device=dev)):
+                orc.partial_fit(X)
+                if i < cpu_keep:
+                    host_blocks.append(X.cpu().numpy())
+                del X
+            r_ = K_COMP + 2000 + 1
+            # executed work of a steady-state block, triangle convention (as the headline's roofline): T = M M^T over its
+            # upper triangle r (r + 1) d, W = Q^T M 2 k r d;  SURVEY.md 8d's per-sample figure 2 d (m + 2k) counts
+            # the full products X X^T and V X^T (listed separately, not comparable with the headline's convention)
+            flops_tri = float(r_) * (r_ + 1) * dd + 2.0 * K_COMP * r_ * dd
+            flops_survey = 2000 * 2.0 * dd * (2000 + 2 * K_COMP)
+            for p_, e in ests.items():
                 # blocks 2-4: Rayleigh-Ritz solve per block; from the fifth block on the recurrence carries an
                 # undiagonalised basis (steady state of a long fit)
-                early = sum(ts[1:4]) / 3
-                steady = sum(ts[6:]) / len(ts[6:])
-                # algorithmic work of a block: 2 d (m + 2k) flop per sample
-                flops = 2000 * 2.0 * dd * (2000 + 2 * K_COMP)
-                entry[prec] = {"ms_per_block": round(steady * 1e3, 2), "samples_per_s": round(2000 / steady, 1),
-                               "useful_TFLOPs": round(flops / steady / 1e12, 1),
-                               "ms_per_block_first_blocks": round(early * 1e3, 2)}
-                if prec == "f32":
-                    comp_ref = e.get_components()[0].copy()
-                else:
-                    c = np.abs(np.sum(e.get_components()[0].astype(np.float64) * comp_ref.astype(np.float64), axis=1))
-                    entry[prec]["top20_min_abs_cos_vs_f32_contraction"] = round(float(c[:20].min()), 7)
-                del e, A
+                early = sum(ts[p_][1:4]) / 3
+                steady = sum(ts[p_][6:]) / len(ts[p_][6:])
+                c = signed_cosines(e.get_components()[0], orc.components_)
+                peak = PEAK_F32_MFMA_TFLOPS if p_ == "f32" else PEAK_BF16_MFMA_TFLOPS / 6.0
+                entry[p_] = {"ms_per_block": round(steady * 1e3, 2), "samples_per_s": round(2000 / steady, 1),
+                             "executed_TFLOPs_triangle_convention": round(flops_tri / steady / 1e12, 1),
+                             "frac_of_peak_whole_block": round(flops_tri / steady / 1e12 / peak, 3),
+                             "survey_convention_full_product_TFLOPs": round(flops_survey / steady / 1e12, 1),
+                             "ms_per_block_first_blocks": round(early * 1e3, 2),
+                             "vs_float64_oracle_all80_min_signed_cos": round(float(c.min()), 8),
+                             "vs_float64_oracle_top20_min_signed_cos": round(float(c[:20].min()), 8),
+                             "singular_values_max_rel_err": float(np.abs(e.transformer.singular_values_ /
+                                                                         orc.singular_values_ - 1).max())}
+            del ests, orc
+            if host_blocks:
+                # scikit-learn (the reference's arithmetic) on the host: first block + steady-state blocks until five are
+                # timed or the budget is spent; the n = 1e6 job (500 blocks) is extrapolated
+                sk = reference_cpu.make_reference_ipca(K_COMP)
+                per, spent = [], 0.0
+                with reference_cpu.blas_threads(args.wide_cpu_threads):
+                    for hb in host_blocks:
+                        if len(per) >= 2 and spent + per[-1] > args.wide_cpu_budget_s:
+                            break
+                        t0 = time.perf_counter()
+                        sk.partial_fit(hb)
+                        per.append(time.perf_counter() - t0)
+                        spent += per[-1]
+                nb_cpu = len(per)
+                e = IPCAEstimator(K_COMP, "faithful")
+                for hb in host_blocks[:nb_cpu]:
+                    e.fit_partial(torch.from_numpy(hb).to(dev))
+                c = signed_cosines(e.get_components()[0], sk.components_)
+                steady_cpu = float(np.mean(per[1:]))
+                t_job = per[0] + 499 * steady_cpu
+                entry["cpu_baseline"] = {"value": round(1e6 / t_job, 2), "unit": "samples/s", "kind": "reference",
+                                         "cores": args.wide_cpu_threads, "first_block_s": round(per[0], 2),
+                                         "steady_block_s": round(steady_cpu, 2), "steady_blocks_timed": nb_cpu - 1,
+                                         "sample": f"{nb_cpu} blocks of 2000 x {dd} (sklearn IncrementalPCA.partial_fit), "
+                                                   "n = 1e6 (500 blocks) extrapolated"}
+                entry["vs_sklearn_at_reduced_n"] = {"n": nb_cpu * 2000,
+                                                    "all80_min_signed_cos": round(float(c.min()), 8),
+                                                    "top20_min_signed_cos": round(float(c[:20].min()), 8)}
+                entry["vs_cpu_baseline"] = round(entry["f32"]["samples_per_s"] / entry["cpu_baseline"]["value"], 1)
+                del e, sk
+            del host_blocks
             entry["ms_per_block"] = entry["f32"]["ms_per_block"]
             entry["samples_per_s"] = entry["f32"]["samples_per_s"]
             wide[name] = entry
+            torch.cuda.empty_cache()
         out["wide_feature_shapes"] = wide
 
     if rank == 0:

@@ -17,7 +17,7 @@ ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIBDIR = os.path.join(PKG, "lib")
 LIBNAME = "libganspace_hip.so"
-SOURCES = ["gs_gram.hip", "gs_eigh.hip", "gs_ipca.hip", "gs_linear.hip", "gs_smallside.hip", "gs_subspace.hip", "gs_topk.hip", "gs_gram_bf16.hip", "gs_gram_wide.hip"]
+SOURCES = ["gs_collective.hip", "gs_gram.hip", "gs_eigh.hip", "gs_ipca.hip", "gs_linear.hip", "gs_smallside.hip", "gs_subspace.hip", "gs_topk.hip", "gs_gram_bf16.hip", "gs_gram_wide.hip"]
 
 
 def lib_path() -> str:
@@ -56,18 +56,25 @@ def build(force: bool = False, verbose: bool = True) -> str:
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     headers.append(os.path.join(ROOT, "include", "ganspace_hip.h"))
     newest_header = max(os.path.getmtime(h) for h in headers)
-    objs = []
+    objs, jobs = [], []
     for src in SOURCES:
         path = os.path.join(CSRC, src)
         obj = os.path.join(LIBDIR, src.replace(".hip", ".o"))
         objs.append(obj)
         if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(path), newest_header):
             continue
-        cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", *extra,
-               "-I", os.path.join(ROOT, "include"), "-I", CSRC, path, "-o", obj]
+        jobs.append([_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", *extra,
+                     "-I", os.path.join(ROOT, "include"), "-I", CSRC, path, "-o", obj])
+
+    def compile_one(cmd):
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
+
+    if jobs:      # the translation units are independent: compile them side by side
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 1)) as pool:
+            list(pool.map(compile_one, jobs))
     cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", out]
     if verbose:
         print(" ".join(cmd), flush=True)

@@ -32,6 +32,11 @@ SIGNATURES = {
     "gs_ipca_state_export": (_int, [_vp, _vp, _vp]),
     "gs_ipca_state_import": (_int, [_vp, _vp, _vp]),
     "gs_state_recenter": (_int, [_vp, _i64, _vp, _vp]),
+    "gs_ipca_lowrank_nbytes": (_i64, [_vp]),
+    "gs_ipca_lowrank_export": (_int, [_vp, _vp, _vp]),
+    "gs_ipca_lowrank_merge": (_int, [_vp, _vp, _int, _vp]),
+    "gs_ipca_info": (_int, [_vp, _vp, _vp, _vp, _vp]),
+    "gs_ipca_allreduce": (_int, [_vp, _vp, _vp]),
     "gs_ipca_finalize": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gs_ipca_last_sweeps": (_int, [_vp]),
     "gs_ipca_last_mults": (_int, [_vp]),

@@ -29,6 +29,9 @@ class ICAEstimator:
         self.n_components = n_components
         self.maxiter = 10000
         self.whiten = True
+        # the reference passes whiten=True (estimators.py:26), which the scikit-learn of its era read as
+        # "arbitrary-variance"; current releases only accept the named variants.  The difference is a per-component
+        # scale, removed by the row normalisation in fit() below.
         self.transformer = FastICA(n_components, random_state=0, whiten="unit-variance", max_iter=self.maxiter)
         self.batch_support = False
         self.stdev = np.zeros((n_components,))

@@ -193,6 +193,7 @@ struct SmallSide {
     int precision = 0;       // GS_PREC_*: contraction of T = M M^T (f32 MFMA, or split-bf16 MFMA)
     int *tile_order = nullptr;   // [nmt][2] upper-triangle tiles of T in 4 x 4 blocks (XCD-local panel reuse)
     int order_T = 0;             // tile count per side the table was built for
+    int order_cap = 0;           // entries the table can hold
     float *M = nullptr;      // [rp][d]  stacked matrix
     double *T = nullptr;     // [rp][rp] M M^T, then its Jacobi-rotated columns
     double *slab = nullptr;  // [nsplit][rp][rp]

@@ -691,10 +691,7 @@ static void launch_partial(const GramWorkspace &ws, const GramGeom &g, int buf, 
                            int64_t ld, int64_t d, const float *shift, const FoldJob &fold, hipStream_t stream) {
     const bool vec = (ld % 4 == 0) && (d % 4 == 0) && ((reinterpret_cast<uintptr_t>(Xb) & 15) == 0);
     const int dp = (int)ws.dp;
-    static const int ablate = []() {
-        const char *e = getenv("GS_GRAM_ABLATE");
-        return e ? atoi(e) : 0;
-    }();
+    const int ablate = gram_ablate_mask();
     // spare workgroups for the piggy-backed fold: the CUs the compute grid leaves idle (at least 8)
     int nfold = 0;
     if (fold.P != nullptr) {

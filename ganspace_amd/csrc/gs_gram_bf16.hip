@@ -635,10 +635,7 @@ int launch_gram_bf16_wide(int grid, int nfold, const float *X, int64_t n, int64_
         attr = true;
     }
     // measurement only (results wrong by design): GS_GRAM_ABLATE bit 0 no MFMA, bit 1 no split / LDS writes, bit 2 no loads
-    static const int ablate = []() {
-        const char *e = getenv("GS_GRAM_ABLATE");
-        return e ? atoi(e) : 0;
-    }();
+    const int ablate = gram_ablate_mask();
     hipLaunchKernelGGL(gram_bf16_wide_kernel, dim3((unsigned)(grid + nfold)), dim3(kWThreads), lds_bytes, stream, X, n, ld,
                        shift, P, CS, nchunks, plan, grid, fold, ablate);
     return GS_OK;
@@ -652,10 +649,7 @@ int launch_gram_bf16(int precision, int grid, int nfold, const float *X, int64_t
 #define GS_BF16_ARGS lds_bytes, grid, nfold, X, n, ld, d, shift, P, CS, dp, nchunks, plan, nmt, T, fold, stream
 #ifdef GS_GRAM_ABLATE_BUILD
     // measurement builds only (results are wrong): 1 no MFMA/LDS reads, 2 no split, 3 no global loads, 4 MFMA from registers
-    static const int ablate = []() {
-        const char *e = getenv("GS_GRAM_ABLATE");
-        return e ? atoi(e) : 0;
-    }();
+    const int ablate = gram_ablate_mask();
     if (precision == GS_PREC_BF16X3) {
         switch (ablate) {
             case 1: return launch_variant<3, 1>(GS_BF16_ARGS);

@@ -2,7 +2,23 @@
 #pragma once
 #include "gs_common.h"
 
+#include <cstdlib>
+
 namespace gs {
+
+// Measurement-only ablation mask (results wrong by design).  The production library ignores the environment: only a
+// build with -DGS_GRAM_ABLATE_BUILD (GS_HIPCC_FLAGS of ganspace_amd/_build.py) reads GS_GRAM_ABLATE.
+inline int gram_ablate_mask() {
+#ifdef GS_GRAM_ABLATE_BUILD
+    static const int mask = []() {
+        const char *e = getenv("GS_GRAM_ABLATE");
+        return e ? atoi(e) : 0;
+    }();
+    return mask;
+#else
+    return 0;
+#endif
+}
 
 // Rows of one launch are dealt to the chunks in units of kRowUnit rows, as evenly as possible: chunk c covers
 // q (+1 if c < rem) units, so chunk lengths differ by at most one unit and only the launch's last chunk can end

@@ -257,10 +257,7 @@ int launch_gram_f32_wide(int grid, int nfold, const float *X, int64_t n, int64_t
         attr = true;
     }
     // measurement only (results wrong by design): GS_GRAM_ABLATE bit 0 no MFMA, bit 1 no LDS writes, bit 2 no loads
-    static const int ablate = []() {
-        const char *e = getenv("GS_GRAM_ABLATE");
-        return e ? atoi(e) : 0;
-    }();
+    const int ablate = gram_ablate_mask();
     hipLaunchKernelGGL(gram_f32_wide_kernel, dim3((unsigned)(grid + nfold)), dim3(kFThreads), lds_bytes, stream, X, n, ld,
                        shift, P, CS, nchunks, plan, grid, fold, ablate);
     return GS_OK;

@@ -424,6 +424,7 @@ int faithful_materialize(gs_ipca *h, hipStream_t stream) {
 }
 
 constexpr int64_t kResidentRows = 131072;
+constexpr int64_t kSmallSideMaxRows = 16384;   // r = k + rows + 1 of one small-side block (T is r x r float64)
 
 // contract the resident rows that are still pending: whole launches of kResidentRows, and the rest if `all`
 int resident_flush(gs_ipca *h, bool all, hipStream_t stream) {
@@ -452,6 +453,133 @@ int exact_solve(gs_ipca *h, hipStream_t stream) {
                        (double)h->n_seen);
     return GS_OK;
 }
+
+
+// ---- low-rank state (FAITHFUL / SMALLSIDE): export and multi-rank merge ---------------------------------------
+// state (float64) = [ n | mean(d) | m2(d) | lam(k) | V(k x d) ]: what sklearn's IncrementalPCA carries between two
+// partial_fit calls (n_samples_seen_, mean_, var_ * n, singular_values_^2, components_).
+__global__ void lowrank_export_kernel(const double *__restrict__ mean, const double *__restrict__ m2,
+                                      const double *__restrict__ lam, const double *__restrict__ Vk64, int64_t ldv,
+                                      const float *__restrict__ V32, double *__restrict__ state, int64_t d, int k,
+                                      double n) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int t = blockIdx.y;                     // 0 .. k-1: component rows, k: the vectors
+    if (j >= d) return;
+    double *V = state + 1 + 2 * d + k;
+    if (t < k) {
+        V[(int64_t)t * d + j] = Vk64 ? Vk64[(int64_t)t * ldv + j] : (double)V32[(int64_t)t * d + j];
+    } else {
+        state[1 + j] = mean[j];
+        state[1 + d + j] = m2[j];
+        if (j < k) state[1 + 2 * d + j] = lam[j];
+        if (j == 0) state[0] = n;
+    }
+}
+
+// mean = sum_r n_r mean_r / n ;  m2 = sum_r (m2_r + n_r (mean_r - mean)^2)          (Chan et al., P-way)
+__global__ void lowrank_merge_stats_kernel(const double *__restrict__ states, int64_t len, int P, int64_t d,
+                                           double *__restrict__ mean, double *__restrict__ m2) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= d) return;
+    double n = 0, s = 0;
+    for (int r = 0; r < P; ++r) {
+        const double nr = states[(int64_t)r * len];
+        n += nr;
+        s += nr * states[(int64_t)r * len + 1 + j];
+    }
+    const double mu = n > 0 ? s / n : 0.0;
+    double q = 0;
+    for (int r = 0; r < P; ++r) {
+        const double nr = states[(int64_t)r * len];
+        if (nr <= 0) continue;
+        const double dl = states[(int64_t)r * len + 1 + j] - mu;
+        q += states[(int64_t)r * len + 1 + d + j] + nr * dl * dl;
+    }
+    mean[j] = mu;
+    m2[j] = q;
+}
+
+// stacked matrix of the merge step (the vstack of sklearn _incremental_pca.py:347-362 with every rank's state as a
+// pre-compressed batch):  rows r (k + 1) + t = sqrt(lam_r[t]) V_r[t],  row r (k + 1) + k = sqrt(n_r) (mean_r - mean)
+__global__ void lowrank_stack_kernel(const double *__restrict__ states, int64_t len, int P, int64_t d, int k,
+                                     const double *__restrict__ mean, double *__restrict__ M) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int row = blockIdx.y;
+    if (j >= d) return;
+    const int r = row / (k + 1), t = row - r * (k + 1);
+    const double *st = states + (int64_t)r * len;
+    const double nr = st[0];
+    double v = 0.0;
+    if (nr > 0) {
+        if (t < k) {
+            const double l = st[1 + 2 * d + t];
+            v = (l > 0 ? sqrt(l) : 0.0) * st[1 + 2 * d + k + (int64_t)t * d + j];
+        } else {
+            v = sqrt(nr) * (st[1 + j] - mean[j]);
+        }
+    }
+    M[(int64_t)row * d + j] = v;
+}
+
+__global__ void symmetrize_full_kernel(double *__restrict__ T, int n, int64_t ld) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = blockIdx.y;
+    if (j >= n || j <= i) return;
+    const double v = 0.5 * (T[(int64_t)i * ld + j] + T[(int64_t)j * ld + i]);
+    T[(int64_t)i * ld + j] = v;
+    T[(int64_t)j * ld + i] = v;
+}
+
+// rows of V (k x ldv, first d entries valid) -> unit norm, sklearn's sign convention; a direction whose eigenvalue is
+// numerically zero (lam <= 1e-26 lam_max^2 ... i.e. no variance left) becomes a zero row with lam = 0
+__global__ __launch_bounds__(256) void normalize_signfix_rows_kernel(double *__restrict__ V, int64_t ldv, int64_t d,
+                                                                      double *__restrict__ lam, int k) {
+    __shared__ double s_sum[256], s_best[256], s_val[256];
+    __shared__ long long s_idx[256];
+    const int r = blockIdx.x, tid = threadIdx.x;
+    double *row = V + (int64_t)r * ldv;
+    double acc = 0, best = -1.0, bestv = 0.0;
+    long long bi = 0x7fffffffffffffffLL;
+    for (int64_t e = tid; e < d; e += 256) {
+        const double v = row[e], a = fabs(v);
+        acc += v * v;
+        if (a > best) {
+            best = a;
+            bestv = v;
+            bi = e;
+        }
+    }
+    s_sum[tid] = acc;
+    s_best[tid] = best;
+    s_val[tid] = bestv;
+    s_idx[tid] = bi;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) {
+            s_sum[tid] += s_sum[tid + o];
+            if (s_best[tid + o] > s_best[tid] || (s_best[tid + o] == s_best[tid] && s_idx[tid + o] < s_idx[tid])) {
+                s_best[tid] = s_best[tid + o];
+                s_val[tid] = s_val[tid + o];
+                s_idx[tid] = s_idx[tid + o];
+            }
+        }
+        __syncthreads();
+    }
+    const double nrm2 = s_sum[0];
+    const bool dead = !(lam[r] > lam[0] * 1e-26) || !(nrm2 > 0.0);
+    const double sc = dead ? 0.0 : (s_val[0] < 0 ? -1.0 : 1.0) / sqrt(nrm2);
+    for (int64_t e = tid; e < ldv; e += 256) row[e] = (e < d) ? row[e] * sc : 0.0;
+    __syncthreads();
+    if (tid == 0 && dead) lam[r] = 0.0;
+}
+
+__global__ void f64_rows_to_f32_kernel(const double *__restrict__ src, int64_t lds_, float *__restrict__ dst, int64_t d) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int t = blockIdx.y;
+    if (j < d) dst[(int64_t)t * d + j] = (float)src[(int64_t)t * lds_ + j];
+}
+
+int64_t lowrank_len(const gs_ipca *h) { return 1 + 2 * h->d + h->k + (int64_t)h->k * h->d; }
 
 }  // namespace
 
@@ -607,9 +735,17 @@ int gs_ipca_update(gs_ipca_t *h, const float *X, int64_t rows, int64_t ld, void 
                    "partial_fit call");
     }
     if (h->mode == GS_MODE_SMALLSIDE) {
-        GS_REQUIRE(h->k + rows + 1 <= 4096, GS_ENOTIMPL,
-                   "small-side mode supports n_components + rows + 1 <= 4096 per block");
+        GS_REQUIRE(h->k + rows + 1 <= kSmallSideMaxRows, GS_ENOTIMPL,
+                   "small-side mode supports n_components + rows + 1 <= 16384 per block");
         if (h->ss.M == nullptr || rows > h->ss.m_cap) {
+            // A block taller than any before (sklearn's fit() merges a short tail into the last batch: up to
+            // batch_size + k - 1 rows) needs larger buffers.  A deferred state (comp32 = W = Q^T M, lam stale) refers
+            // to the M and Bk about to be freed: fold the pending diagonalisation back into (V, lam) first.
+            if (h->ss.M != nullptr && h->ss.w_state) {
+                int rcm = smallside_materialize(h->ss, h->comp32, h->lam, &h->last_sweeps, stream);
+                if (rcm != GS_OK) return rcm;
+                h->pending_diag = false;
+            }
             GS_HIP_CHECK(hipStreamSynchronize(stream));
             h->ss.precision = h->prec;
             int rc = smallside_alloc(h->ss, h->d, h->k, (int)rows);
@@ -999,6 +1135,129 @@ int gs_eigh_topk(const double *A, int n, int k, const double *V0, int k0, double
     eigh_workspace_free(ews);
     if (W) (void)hipFree(W);
     return rc;
+}
+
+
+int gs_ipca_info(const gs_ipca_t *h, int64_t *d, int *k, int *mode, int64_t *n_seen) {
+    GS_REQUIRE(h != nullptr, GS_EINVAL, "gs_ipca_info: NULL handle");
+    if (d) *d = h->d;
+    if (k) *k = h->k;
+    if (mode) *mode = h->mode;
+    if (n_seen) *n_seen = h->n_seen;
+    return GS_OK;
+}
+
+int64_t gs_ipca_lowrank_nbytes(const gs_ipca_t *h) {
+    if (!h) return GS_EINVAL;
+    return (int64_t)sizeof(double) * lowrank_len(h);
+}
+
+int gs_ipca_lowrank_export(gs_ipca_t *h, double *state, void *stream_) {
+    GS_REQUIRE(h && state, GS_EINVAL, "gs_ipca_lowrank_export: NULL argument");
+    GS_REQUIRE(h->mode == GS_MODE_FAITHFUL || h->mode == GS_MODE_SMALLSIDE, GS_ESTATE,
+               "the low-rank state belongs to GS_MODE_FAITHFUL / GS_MODE_SMALLSIDE (GS_MODE_EXACT: gs_ipca_state_export)");
+    hipStream_t stream = (hipStream_t)stream_;
+    if (h->n_seen == 0) {
+        GS_HIP_CHECK(hipMemsetAsync(state, 0, (size_t)gs_ipca_lowrank_nbytes(h), stream));
+        return GS_OK;
+    }
+    // a deferred diagonalisation is folded back first: the state leaves as unit components + eigenvalues
+    if (h->pending_diag && h->mode == GS_MODE_SMALLSIDE) {
+        int rc = smallside_materialize(h->ss, h->comp32, h->lam, &h->last_sweeps, stream);
+        if (rc != GS_OK) return rc;
+        hipLaunchKernelGGL(derive_outputs_kernel, dim3(1), dim3(256), 0, stream, h->lam, h->m2, (int)h->d, h->outs, h->k,
+                           (double)h->n_seen);
+        h->pending_diag = false;
+    } else if (h->pending_diag) {
+        int rc = faithful_materialize(h, stream);
+        if (rc != GS_OK) return rc;
+    }
+    const bool ss = h->mode == GS_MODE_SMALLSIDE;
+    hipLaunchKernelGGL(lowrank_export_kernel, dim3((unsigned)ceil_div(h->d, 256), (unsigned)(h->k + 1)), dim3(256), 0,
+                       stream, h->mean, h->m2, h->lam, ss ? (const double *)nullptr : h->Vk, h->dp,
+                       ss ? h->comp32 : (const float *)nullptr, state, h->d, h->k, (double)h->n_seen);
+    GS_HIP_CHECK(hipGetLastError());
+    return GS_OK;
+}
+
+int gs_ipca_lowrank_merge(gs_ipca_t *h, const double *states, int nstates, void *stream_) {
+    GS_REQUIRE(h && states && nstates >= 1, GS_EINVAL, "gs_ipca_lowrank_merge: bad argument");
+    GS_REQUIRE(h->mode == GS_MODE_FAITHFUL || h->mode == GS_MODE_SMALLSIDE, GS_ESTATE,
+               "gs_ipca_lowrank_merge: GS_MODE_FAITHFUL / GS_MODE_SMALLSIDE handles only");
+    hipStream_t stream = (hipStream_t)stream_;
+    const int64_t d = h->d, len = lowrank_len(h);
+    const int k = h->k, P = nstates, R = P * (k + 1);
+    // sample counts on the host
+    std::vector<double> ns(P);
+    GS_HIP_CHECK(hipMemcpy2DAsync(ns.data(), sizeof(double), states, sizeof(double) * (size_t)len, sizeof(double), P,
+                                  hipMemcpyDeviceToHost, stream));
+    GS_HIP_CHECK(hipStreamSynchronize(stream));
+    double n = 0;
+    for (int r = 0; r < P; ++r) {
+        GS_REQUIRE(ns[r] >= 0 && ns[r] == std::floor(ns[r]), GS_EINVAL, "gs_ipca_lowrank_merge: bad sample count");
+        n += ns[r];
+    }
+    int rc = gs_ipca_reset(h);
+    if (rc != GS_OK) return rc;
+    if (n == 0) return GS_OK;
+    double *M = nullptr, *T = nullptr, *Uk = nullptr, *V64 = nullptr;
+    EighWorkspace ews;
+    const int64_t Rp = round_up(R, 16), ldv = (h->mode == GS_MODE_FAITHFUL) ? h->dp : d;
+    auto cleanup = [&]() {
+        (void)hipStreamSynchronize(stream);
+        for (double *p : {M, T, Uk}) if (p) (void)hipFree(p);
+        if (V64 && h->mode == GS_MODE_SMALLSIDE) (void)hipFree(V64);
+        eigh_workspace_free(ews);
+    };
+    rc = eigh_workspace_alloc(ews, R + 2);
+    if (rc == GS_OK && (hipMalloc(&M, sizeof(double) * (size_t)R * d) != hipSuccess ||
+                        hipMalloc(&T, sizeof(double) * (size_t)R * Rp) != hipSuccess ||
+                        hipMalloc(&Uk, sizeof(double) * (size_t)k * Rp) != hipSuccess))
+        rc = GS_ENOMEM;
+    if (rc == GS_OK && h->mode == GS_MODE_SMALLSIDE && hipMalloc(&V64, sizeof(double) * (size_t)k * d) != hipSuccess) rc = GS_ENOMEM;
+    if (rc != GS_OK) {
+        set_error("gs_ipca_lowrank_merge: out of device memory");
+        cleanup();
+        return rc;
+    }
+    if (h->mode == GS_MODE_FAITHFUL) V64 = h->Vk;
+    const unsigned gd = (unsigned)ceil_div(d, 256);
+    hipLaunchKernelGGL(lowrank_merge_stats_kernel, dim3(gd), dim3(256), 0, stream, states, len, P, d, h->mean, h->m2);
+    hipLaunchKernelGGL(lowrank_stack_kernel, dim3(gd, (unsigned)R), dim3(256), 0, stream, states, len, P, d, k, h->mean, M);
+    // T = M M^T (R x R, float64), eigen-decomposition by the full Jacobi solver (R = P (k + 1) <= a few hundred)
+    gemm_f64(R, R, (int)d, M, d, 1, M, 1, d, T, Rp, stream, 1.0, 0.0, GemmEpilogue(), true, false);
+    hipLaunchKernelGGL(symmetrize_full_kernel, dim3((unsigned)ceil_div(R, 64), (unsigned)R), dim3(64), 0, stream, T, R, Rp);
+    rc = eigh_jacobi(ews, T, R, Rp, &h->last_sweeps, stream);
+    if (rc == GS_OK) rc = rank_columns(ews, R, stream);
+    if (rc != GS_OK) {
+        cleanup();
+        return rc;
+    }
+    hipLaunchKernelGGL(select_topk_kernel, dim3((unsigned)ceil_div(R, 4)), dim3(256), 0, stream, T, ews.norms, ews.rank, Uk,
+                       h->lam, R, Rp, (int)Rp, k);
+    // V' = U_k^T M, rows normalised (their norms are sqrt(lam) up to rounding) and sign-fixed
+    gemm_f64(k, (int)d, R, Uk, Rp, 1, M, d, 1, V64, ldv, stream, 1.0, 0.0, GemmEpilogue(), false);
+    hipLaunchKernelGGL(normalize_signfix_rows_kernel, dim3((unsigned)k), dim3(256), 0, stream, V64, ldv, d, h->lam, k);
+    if (h->mode == GS_MODE_SMALLSIDE) {
+        hipLaunchKernelGGL(f64_rows_to_f32_kernel, dim3(gd, (unsigned)k), dim3(256), 0, stream, V64, ldv, h->comp32, d);
+        hipLaunchKernelGGL(to_f32_kernel, dim3(gd, 1), dim3(256), 0, stream, (const double *)nullptr, h->mean,
+                           (float *)nullptr, h->mean32, (int)d, (int)d, 0);
+    } else {
+        hipLaunchKernelGGL(set_diag_kernel, dim3((unsigned)ceil_div(k, 64), (unsigned)k), dim3(64), 0, stream, h->Bk, h->lam, k);
+        hipLaunchKernelGGL(mean_to_shift_kernel, dim3((unsigned)ceil_div(h->dp, 256)), dim3(256), 0, stream, h->mean,
+                           h->shift, (int)d, (int)h->dp);
+        hipLaunchKernelGGL(to_f32_kernel, dim3(gd, (unsigned)(k + 1)), dim3(256), 0, stream, h->Vk, h->mean, h->comp32,
+                           h->mean32, (int)d, (int)h->dp, k);
+    }
+    h->n_seen = (int64_t)n;
+    h->blocks = P;
+    hipLaunchKernelGGL(derive_outputs_kernel, dim3(1), dim3(256), 0, stream, h->lam, h->m2, (int)d, h->outs, k, n);
+    const bool launch_ok = hipGetLastError() == hipSuccess;
+    h->finalized = true;
+    h->pending_diag = false;
+    cleanup();
+    GS_REQUIRE(launch_ok, GS_EHIP, "gs_ipca_lowrank_merge: kernel launch failed");
+    return GS_OK;
 }
 
 }  // extern "C"

@@ -665,7 +665,11 @@ int smallside_alloc(SmallSide &ss, int64_t d, int k, int m) {
     if (rc == GS_OK) rc = alloc((void **)&ss.Ct, sizeof(float) * (size_t)ss.rp * ss.kp);
     if (rc == GS_OK) rc = alloc((void **)&ss.Vtmp, sizeof(float) * (size_t)ss.kp * d);
     if (rc == GS_OK) rc = alloc((void **)&ss.colsq, sizeof(double) * d);
-    if (rc == GS_OK) rc = alloc((void **)&ss.tile_order, sizeof(int) * 2 * 1024);
+    {
+        const int Tcap = ss.rp / kRT;
+        ss.order_cap = Tcap * (Tcap + 1) / 2;
+    }
+    if (rc == GS_OK) rc = alloc((void **)&ss.tile_order, sizeof(int) * 2 * (size_t)ss.order_cap);
     if (rc == GS_OK) rc = eigh_workspace_alloc(ss.ews, ss.rp + 2);
     if (rc == GS_OK) rc = alloc((void **)&ss.Uk, sizeof(double) * (size_t)k * ss.rp);
     if (rc == GS_OK) rc = alloc((void **)&ss.wk, sizeof(double) * (size_t)k);
@@ -720,7 +724,7 @@ int smallside_update(SmallSide &ss, const float *X, int64_t rows, int64_t ldx, d
                         ord.push_back(i);
                         ord.push_back(j);
                     }
-        GS_REQUIRE((int)ord.size() == 2 * nmt && nmt <= 1024, GS_ESTATE, "smallside: tile table overflow");
+        GS_REQUIRE((int)ord.size() == 2 * nmt && nmt <= ss.order_cap, GS_ESTATE, "smallside: tile table overflow");
         GS_HIP_CHECK(hipMemcpyAsync(ss.tile_order, ord.data(), sizeof(int) * ord.size(), hipMemcpyHostToDevice, stream));
         GS_HIP_CHECK(hipStreamSynchronize(stream));      // `ord` is a host temporary
         ss.order_T = Tt;

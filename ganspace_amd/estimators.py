@@ -235,6 +235,38 @@ class _DeviceIncrementalPCA:
         return self
 
 
+    # -- multi-GPU / resume: low-rank state (FAITHFUL / SMALLSIDE modes) ---------------------------------
+    def lowrank_len(self):
+        """Length (float64 elements) of the low-rank state ``[n | mean(d) | m2(d) | lam(k) | V(k x d)]``."""
+        return 1 + 2 * self._d + self.n_components * (1 + self._d)
+
+    def export_lowrank(self):
+        """What sklearn's IncrementalPCA carries between two ``partial_fit`` calls, as one float64 device tensor."""
+        torch = _torch()
+        if self._h is None:
+            raise RuntimeError("nothing fitted yet")
+        st = torch.empty(self._lib.gs_ipca_lowrank_nbytes(self._h) // 8, dtype=torch.float64, device=self._device)
+        _lib.check(self._lib.gs_ipca_lowrank_export(self._h, C.c_void_p(st.data_ptr()), _lib.current_stream_ptr()))
+        self._cache = None
+        return st
+
+    def merge_lowrank(self, states):
+        """Replace this estimator's state by the merge of ``states`` (``[P, lowrank_len]`` float64, e.g. the
+        all-gathered states of P ranks): one more step of the recurrence with every state as a pre-compressed batch
+        (``gs_ipca_lowrank_merge``)."""
+        torch = _torch()
+        st = states.to(device=self._device, dtype=torch.float64).contiguous()
+        if st.dim() != 2 or st.shape[1] != self.lowrank_len():
+            raise ValueError(f"expected [P, {self.lowrank_len()}] states, got {tuple(st.shape)}")
+        _lib.check(self._lib.gs_ipca_lowrank_merge(self._h, C.c_void_p(st.data_ptr()), int(st.shape[0]),
+                                                   _lib.current_stream_ptr()))
+        torch.cuda.current_stream().synchronize()        # `st` may be released
+        self._n_host = None
+        self._cache = None
+        self._resident_refs.clear()
+        return self
+
+
 class IPCAEstimator:
     """Drop-in for the reference ``IPCAEstimator`` (estimators.py:55-81)."""
 

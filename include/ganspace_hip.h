@@ -49,7 +49,7 @@ enum {
  *                  stacked matrix (one eigensolve per block) - reproduces ALL k components
  *                  of the reference, signs included.
  * GS_MODE_SMALLSIDE the same recurrence as FAITHFUL handled from the small side of the stacked
- *                  matrix (r = k + rows + 1 <= 4096) for feat_dim >> block rows (BigGAN gen_z
+ *                  matrix (r = k + rows + 1 <= 16384) for feat_dim >> block rows (BigGAN gen_z
  *                  d = 32 768, conv features d = 131 072): T = M M^T, eigh(T), V' = S^-1 U^T M.
  *                  Needs feat_dim % 4 == 0.                                                    */
 enum { GS_MODE_EXACT = 0, GS_MODE_FAITHFUL = 1, GS_MODE_SMALLSIDE = 2 };
@@ -107,6 +107,33 @@ int64_t gs_ipca_state_nbytes(const gs_ipca_t *h);
 int     gs_ipca_state_export(gs_ipca_t *h, double *state, void *stream);
 int     gs_ipca_state_import(gs_ipca_t *h, const double *state, void *stream);
 int     gs_state_recenter(double *state, int64_t d, const double *new_mean, void *stream);
+
+/* Low-rank state of a FAITHFUL / SMALLSIDE handle - what sklearn's IncrementalPCA carries from one partial_fit to the
+ * next (_incremental_pca.py:329-378: n_samples_seen_, mean_, var_, singular_values_, components_), as float64
+ *   [ n | mean(d) | m2(d) = var * n | lam(k) = singular_values^2 | V(k x d) unit rows ]
+ * - for resume and for sharding the reference's default estimator (`--est=ipca`, config.py:59) over GPUs (new design,
+ * SURVEY 8e): every rank runs the recurrence on its share of the blocks, the states are gathered and
+ * gs_ipca_lowrank_merge performs ONE more step of the same recurrence with every state as a pre-compressed batch: the
+ * stack [ sqrt(lam_r) V_r ; sqrt(n_r) (mean_r - mean) ] over all ranks (P (k + 1) rows - the vstack of
+ * _incremental_pca.py:347-362 with the Chan mean-correction rows taken about the global mean), top-k of its SVD from
+ * the small side (float64), svd_flip signs, Chan merge of mean / var.  The handle then holds the merged state and can
+ * be updated further.  `states` = nstates consecutive exported states; ranks that saw nothing contribute zeros.   */
+int64_t gs_ipca_lowrank_nbytes(const gs_ipca_t *h);
+int     gs_ipca_lowrank_export(gs_ipca_t *h, double *state, void *stream);
+int     gs_ipca_lowrank_merge(gs_ipca_t *h, const double *states, int nstates, void *stream);
+
+/* feature count, n_components, GS_MODE_* and samples seen of a handle (outputs may be NULL) */
+int gs_ipca_info(const gs_ipca_t *h, int64_t *d_host, int *k_host, int *mode_host, int64_t *n_seen_host);
+
+/* The one exchange step of a multi-GPU fit (north_star: "RCCL all-reduce the Gram/mean over xGMI before the
+ * eigensolve"; the reference is single-process) for hosts WITHOUT torch.distributed: `rccl_comm` is an ncclComm_t
+ * (one rank per GPU, created by the caller with ncclCommInitRank) passed as void*; RCCL is resolved at run time from
+ * the process (dlsym) or librccl.so - the library does not link against it.
+ *   GS_MODE_EXACT               all-reduce [n | n mean], Chan re-centring of the local scatter about the global
+ *                               mean, all-reduce of the centred scatter (d*d float64), import.
+ *   GS_MODE_FAITHFUL/SMALLSIDE  all-gather of the low-rank states + gs_ipca_lowrank_merge on every rank.
+ * Collectives are enqueued on `stream`; the call synchronises it (the merged sample count is read on the host).     */
+int gs_ipca_allreduce(gs_ipca_t *h, void *rccl_comm, void *stream);
 
 /* Replaces IPCAEstimator.get_components (estimators.py:78-81) and the attribute reads
  * transformer.mean_/components_/explained_variance_/... (decomposition.py:289-293).

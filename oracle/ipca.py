@@ -250,3 +250,43 @@ def signed_cosines(A: np.ndarray, B: np.ndarray) -> np.ndarray:
     B = np.asarray(B, dtype=np.float64)
     num = np.sum(A * B, axis=1)
     return num / (np.linalg.norm(A, axis=1) * np.linalg.norm(B, axis=1))
+
+
+# ---- multi-rank merge of the sklearn-faithful recurrence (new design) -------------------------------
+def pack_lowrank_state(t) -> np.ndarray:
+    """Low-rank state of a fitted recurrence oracle / sklearn ``IncrementalPCA`` ``t`` in the layout of
+    ``gs_ipca_lowrank_export``: float64 ``[n | mean(d) | m2(d) | lam(k) | V(k x d)]`` with ``m2 = var_ * n`` and
+    ``lam = singular_values_ ** 2``."""
+    n = float(t.n_samples_seen_)
+    mean = np.asarray(t.mean_, dtype=np.float64)
+    V = np.asarray(t.components_, dtype=np.float64)
+    return np.concatenate([[n], mean, np.asarray(t.var_, dtype=np.float64) * n,
+                           np.asarray(t.singular_values_, dtype=np.float64) ** 2, V.ravel()])
+
+
+def merge_lowrank_states(states, k: int, d: int):
+    """ONE more step of ``IncrementalPCA.partial_fit`` (``_incremental_pca.py:335-378``) with every rank's state as a
+    pre-compressed batch: the vstack of :347-362 becomes ``[sqrt(lam_r) V_r ; sqrt(n_r) (mean_r - mean)]`` over all
+    ranks - the scatter about the global mean decomposes exactly into the per-rank scatters (here: their rank-k
+    truncations ``V_r^T diag(lam_r) V_r``) plus ``n_r (mean_r - mean)(mean_r - mean)^T`` (Chan et al.; P = 2 gives
+    sklearn's own correction row ``sqrt(n0 m / n1) (mean0 - mean1)`` split over the two means) - then thin SVD,
+    ``svd_flip(u_based_decision=False)``, truncation.  Returns a dict with sklearn's attribute names."""
+    states = [np.asarray(s, dtype=np.float64) for s in states]
+    ns = np.array([s[0] for s in states])
+    n = ns.sum()
+    means = np.stack([s[1:1 + d] for s in states])
+    mean = (ns[:, None] * means).sum(0) / n
+    m2 = sum(s[1 + d:1 + 2 * d] + nr * (mu - mean) ** 2 for s, nr, mu in zip(states, ns, means) if nr > 0)
+    rows = []
+    for s, nr, mu in zip(states, ns, means):
+        if nr <= 0:
+            continue
+        lam = np.maximum(s[1 + 2 * d:1 + 2 * d + k], 0.0)
+        V = s[1 + 2 * d + k:].reshape(k, d)
+        rows.append(np.sqrt(lam)[:, None] * V)
+        rows.append(np.sqrt(nr) * (mu - mean)[None, :])
+    stack = np.vstack(rows)
+    _, S, Vt = scipy.linalg.svd(stack, full_matrices=False, check_finite=False)
+    Vt = Vt * flip_rows_largest_abs_positive(Vt)[:, None]
+    return dict(components_=Vt[:k], singular_values_=S[:k], mean_=mean, var_=m2 / n, n_samples_seen_=int(n),
+                explained_variance_=S[:k] ** 2 / (n - 1), explained_variance_ratio_=S[:k] ** 2 / m2.sum())

@@ -18,22 +18,49 @@ def make_reference_ipca(n_components: int):
     return IncrementalPCA(n_components, whiten=False, batch_size=max(100, 2 * n_components))
 
 
-def time_reference_fit(blocks, n_components: int):
+def time_reference_fit(blocks, n_components: int, per_block: bool = False):
     """Run the reference "Fitting batches" arithmetic on host float32 blocks.
 
-    Returns ``(ipca, seconds, samples)``; ``seconds`` covers the partial_fit calls only
-    (decomposition.py:263-264), the blocks being already in host memory.
+    Returns ``(ipca, seconds, samples)`` - or ``(ipca, [seconds per block])`` with ``per_block`` -; the time covers
+    the partial_fit calls only (decomposition.py:263-264), the blocks being already in host memory.
     """
     ipca = make_reference_ipca(n_components)
-    t = 0.0
+    times = []
     n = 0
     for X in blocks:
         t0 = time.perf_counter()
         ipca.partial_fit(X)
         ipca.n_samples_seen_ = np.int64(ipca.n_samples_seen_)
-        t += time.perf_counter() - t0
+        times.append(time.perf_counter() - t0)
         n += X.shape[0]
-    return ipca, t, n
+    if per_block:
+        return ipca, times
+    return ipca, float(sum(times)), n
+
+
+def blas_threads(n):
+    """Context manager limiting the BLAS / LAPACK pools to ``n`` threads (no-op without threadpoolctl)."""
+    try:
+        from threadpoolctl import threadpool_limits
+        return threadpool_limits(limits=int(n), user_api="blas")
+    except Exception:
+        import contextlib
+        return contextlib.nullcontext()
+
+
+def pick_blas_threads(blocks, n_components: int, candidates=(8, 16, 32, 64)):
+    """Steady-state seconds per block of the reference arithmetic for a few BLAS thread counts (each: one warm-up
+    block, then the remaining ``blocks``): returns ``(fastest count, {count: seconds per block})``."""
+    import os
+    top = max(1, min(host_threads(), os.cpu_count() or 1))
+    cands = sorted({c for c in candidates if c <= top} | {top})
+    tried = {}
+    for c in cands:
+        with blas_threads(c):
+            _, times = time_reference_fit(blocks, n_components, per_block=True)
+        tried[str(c)] = round(float(np.mean(times[1:])) if len(times) > 1 else times[0], 4)
+    best = min(tried, key=tried.get)
+    return int(best), tried
 
 
 def host_threads():

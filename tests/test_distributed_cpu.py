@@ -160,3 +160,67 @@ def test_sharded_presample_reads_the_same_z_rows():
         for gi in starts:                         # the rows block gi consumes (decomposition.py:246-247)
             assert torch.equal(part[gi - r0:gi - r0 + plan.NB], full[gi:gi + plan.NB])
         np.testing.assert_array_equal(np.random.get_state()[1], state_after)
+
+
+# ---- the sklearn-faithful estimator sharded: per-rank recurrence + low-rank merge (second bullet) ----
+def _faithful_blocks(n_blocks=12, rows=400, d=96, latent=40, seed=5):
+    rs = np.random.RandomState(seed)
+    A = rs.standard_normal((latent, d)) * (1.18 ** -np.arange(latent))[:, None] * 3.0
+    mu = rs.standard_normal(d)
+    return [(rs.standard_normal((rows, latent)) @ A + mu + 0.05 * rs.standard_normal((rows, d))).astype(np.float32)
+            for _ in range(n_blocks)]
+
+
+def _faithful_worker(rank, world, port, out_dir):
+    from oracle import ipca as O
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    k, blocks = 12, _faithful_blocks()
+    lo, hi = D.shard_range(len(blocks), rank, world)
+    orc = O.SklearnRecurrenceOracle(k)
+    for X in blocks[lo:hi]:
+        orc.partial_fit(X)
+    st = torch.from_numpy(O.pack_lowrank_state(orc))
+    allst = D.gather_lowrank_states(st)                     # the product's collective (gloo here, RCCL on the GPUs)
+    assert allst.shape == (world, st.numel())
+    np.save(os.path.join(out_dir, f"states{rank}.npy"), allst.numpy())
+    dist.destroy_process_group()
+
+
+def test_faithful_lowrank_merge_world_size_2_gloo(tmp_path):
+    """Two ranks run the recurrence on their halves of the block list, all-gather the low-rank states through
+    ``distributed.gather_lowrank_states`` and merge (oracle restatement of ``gs_ipca_lowrank_merge``): every rank holds
+    the same states, and the merged leading components equal those of the sequential single-process fit."""
+    from oracle import ipca as O
+    port = _free_port()
+    mp.spawn(_faithful_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    s0, s1 = np.load(tmp_path / "states0.npy"), np.load(tmp_path / "states1.npy")
+    np.testing.assert_array_equal(s0, s1)
+    k, d, blocks = 12, 96, _faithful_blocks()
+    merged = O.merge_lowrank_states(list(s0), k, d)
+    seq = O.SklearnRecurrenceOracle(k)
+    for X in blocks:
+        seq.partial_fit(X)
+    assert merged["n_samples_seen_"] == seq.n_samples_seen_ == 12 * 400
+    np.testing.assert_allclose(merged["mean_"], seq.mean_, atol=1e-12)
+    np.testing.assert_allclose(merged["var_"], seq.var_, rtol=1e-10)           # Chan merge is exact
+    cos = O.signed_cosines(merged["components_"], seq.components_)
+    assert cos[:8].min() > 0.9999, cos        # truncation order differs: leading components only (SURVEY.md 8e)
+    np.testing.assert_allclose(merged["singular_values_"][:8], seq.singular_values_[:8], rtol=1e-3)
+    # and against the exact PCA of all rows
+    ex = O.exact_pca(blocks, k)
+    assert O.signed_cosines(merged["components_"], ex["components_"])[:8].min() > 0.9999
+
+
+def test_lowrank_merge_of_one_state_is_the_identity():
+    from oracle import ipca as O
+    k, d = 6, 40
+    orc = O.SklearnRecurrenceOracle(k)
+    for X in _faithful_blocks(4, 200, d, 20, seed=9):
+        orc.partial_fit(X)
+    st = O.pack_lowrank_state(orc)
+    empty = np.zeros_like(st)
+    m = O.merge_lowrank_states([st, empty], k, d)
+    assert O.signed_cosines(m["components_"], orc.components_).min() > 1 - 1e-12
+    np.testing.assert_allclose(m["singular_values_"], orc.singular_values_, rtol=1e-12)
+    np.testing.assert_allclose(m["var_"], orc.var_, rtol=1e-12)

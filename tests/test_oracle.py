@@ -175,3 +175,21 @@ def test_parallel_z_generation_is_bit_identical_to_the_serial_protocol(monkeypat
     big = list(_zgen.generate("biggan", seeds[:4], 16, 128, 1.0))
     for s, b in zip(seeds[:4], big):
         np.testing.assert_array_equal(zstream.biggan_z_batch(s, 16), b)
+
+
+def test_smallside_torch_oracle_matches_sklearn_recurrence_oracle():
+    """oracle/smallside_torch.py (float64, r x r side, plain torch matmuls - the checker used at the benchmarked
+    wide-feature shapes) restates the same recurrence as the SVD-form oracle."""
+    torch = pytest.importorskip("torch")
+    from oracle.smallside_torch import SmallSideTorchOracle, lowrank_plus_noise_blocks
+    k = 10
+    a, b = SmallSideTorchOracle(k), O.SklearnRecurrenceOracle(k)
+    for X in lowrank_plus_noise_blocks(600, 6, rows=120, latent=24, decay=1.15, seed=3):
+        a.partial_fit(X)
+        b.partial_fit(X.numpy().astype(np.float64))
+    assert O.signed_cosines(a.components_, b.components_).min() > 1 - 1e-10
+    np.testing.assert_allclose(a.singular_values_, b.singular_values_, rtol=1e-10)
+    np.testing.assert_allclose(a.mean_, b.mean_, atol=1e-12)
+    np.testing.assert_allclose(a.var_, b.var_, rtol=1e-10)
+    np.testing.assert_allclose(a.explained_variance_ratio_, b.explained_variance_ratio_, rtol=1e-10)
+    assert a.n_samples_seen_ == b.n_samples_seen_ == 720
