@@ -4,7 +4,9 @@ The reference draws one seed per mini-batch from the global legacy NumPy stream 
 from a private ``RandomState(seed)`` (``models/wrappers.py:167-174`` for StyleGAN2,
 ``models/biggan/.../utils.py:21-33`` for BigGAN).  MT19937 + the polar Gaussian are serial per seed
 (88 k samples/s/core for 512-d z), i.e. 11 s for n = 1e6 - three orders of magnitude more
-than the PCA on the GPU.  The batches are independent once the seed list is drawn, so they are produced by
+than the PCA on the GPU.  The batches are independent once the seed list is drawn.  StyleGAN latents (plain normals)
+come from the library's native thread pool (``NativeNormalStream`` over ``gs_zgen_*``, csrc/gs_zgen.hip: no interpreter
+start-up, pinned ring buffers); BigGAN's ``scipy.stats.truncnorm`` latents are produced by
 worker *subprocesses* (``python -m ganspace_amd._zgen``: NumPy only, never torch or the HIP runtime; no
 ``multiprocessing`` start-method pitfalls for callers without a ``__main__`` guard) that write straight
 into a shared memory-mapped array, which the parent consumes in order.
@@ -37,10 +39,101 @@ def _one(kind, seed, n, dim, truncation):
     return stylegan_z(seed, n, dim) if kind == "stylegan" else biggan_z(seed, n, dim, truncation)
 
 
+_RING_CACHE = {}        # (n_slots, count, pinned) -> (storage, [ctypes pointers]): pinning host memory is not free
+
+
+class NativeNormalStream:
+    """The StyleGAN z batches for ``seeds`` from the library's thread pool (``gs_zgen_*``: MT19937 + NumPy's legacy
+    polar Gaussian restated in C++, bit-identical to ``RandomState(seed).standard_normal``), written into a ring of
+    batch buffers - pinned host memory when a HIP device is present, so that the consumer can start an asynchronous
+    H2D copy straight out of the slot.
+
+    Iterating yields ``(index, batch)`` with ``batch`` a ``[n, dim]`` float32 view of a ring slot (a torch tensor if
+    the ring is pinned, else a NumPy array).  A slot is recycled once ``release(index + 1)`` has been called - the
+    consumer calls it when it is done with batch ``index`` (after the event of its H2D copy); the iterator itself
+    never releases anything it has handed out."""
+
+    def __init__(self, seeds, n: int, dim: int, threads=None, pinned=None):
+        import ctypes as C
+        from . import _lib
+        self._lib = _lib.load()
+        self._C = C
+        self.seeds = np.asarray([int(s) for s in seeds], dtype=np.uint32)
+        self.n, self.dim = int(n), int(dim)
+        nb = len(self.seeds)
+        env = os.environ.get("GANSPACE_ZGEN_THREADS")
+        if threads is None:
+            threads = int(env) if env else min(64, os.cpu_count() or 1)
+        threads = max(1, min(int(threads), max(nb, 1)))
+        n_slots = min(max(nb, 1), threads + 4)
+        if pinned is None:
+            try:
+                import torch
+                pinned = torch.cuda.is_available()
+            except Exception:
+                pinned = False
+        count = self.n * self.dim
+        key = (n_slots, count, bool(pinned))
+        if key not in _RING_CACHE:
+            if pinned:
+                import torch
+                storage = torch.empty((n_slots, self.n, self.dim), dtype=torch.float32, pin_memory=True)
+                base = storage.data_ptr()
+            else:
+                storage = np.empty((n_slots, self.n, self.dim), dtype=np.float32)
+                base = storage.ctypes.data
+            ptrs = (C.c_void_p * n_slots)(*[base + i * count * 4 for i in range(n_slots)])
+            _RING_CACHE.clear()                    # one ring at a time: a different shape replaces the old buffers
+            _RING_CACHE[key] = (storage, ptrs)
+        self._storage, self._ptrs = _RING_CACHE[key]
+        self._n_slots = n_slots
+        self._h = C.c_void_p()
+        _lib.check(self._lib.gs_zgen_start(self.seeds.ctypes.data_as(C.c_void_p), nb, count,
+                                           C.cast(self._ptrs, C.c_void_p), n_slots, threads, C.byref(self._h)))
+        self.threads = threads
+
+    def __len__(self):
+        return len(self.seeds)
+
+    def __iter__(self):
+        from . import _lib
+        C = self._C
+        for i in range(len(self.seeds)):
+            slot = C.c_void_p()
+            _lib.check(self._lib.gs_zgen_wait(self._h, i, C.byref(slot)))
+            yield i, self._storage[i % self._n_slots]
+
+    def release(self, upto: int):
+        if self._h:
+            self._lib.gs_zgen_release(self._h, int(upto))
+
+    def close(self):
+        if self._h:
+            self._lib.gs_zgen_finish(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def generate(kind: str, seeds, n: int, dim: int, truncation: float = 1.0, workers=None):
-    """Yield the z batches for ``seeds`` in order.  Worker subprocesses are used when the job is large enough
-    to pay for their start-up (or when ``GANSPACE_ZGEN_WORKERS`` forces a worker count)."""
+    """Yield the z batches for ``seeds`` in order (NumPy arrays the caller may keep).  StyleGAN batches come from the
+    library's native generator; BigGAN's ``truncnorm.rvs`` batches from worker subprocesses when the job is large
+    enough to pay for their start-up (or when ``GANSPACE_ZGEN_WORKERS`` forces a worker count)."""
     seeds = [int(s) for s in seeds]
+    if kind == "stylegan" and len(seeds) > 0 and os.environ.get("GANSPACE_ZGEN_WORKERS") is None:
+        stream = NativeNormalStream(seeds, n, dim, pinned=False)
+        try:
+            for i, z in stream:
+                out = np.array(z, copy=True)
+                stream.release(i + 1)
+                yield out
+        finally:
+            stream.close()
+        return
     env = os.environ.get("GANSPACE_ZGEN_WORKERS")
     if workers is None:
         workers = int(env) if env else min(32, os.cpu_count() or 1)

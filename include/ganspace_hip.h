@@ -207,6 +207,25 @@ int gs_eigh_topk(const double *A, int n, int k, const double *V0, int k0, double
 int gs_cholqr(const double *Y, int n, int p, double *Q, double *rdiag, void *stream);
 int gs_jacobi_small(const double *B, int p, double *U, double *theta, int *info_host, void *stream);
 
+/* ---- host-side latent stream -----------------------------------------------------------------------
+ * Replaces the per-batch RNG of StyleGAN2.sample_latent (models/wrappers.py:167-174:
+ * `np.random.RandomState(seed).standard_normal(512 * n).reshape(n, 512)` -> float32), bit for bit: MT19937 with NumPy's
+ * integer seeding, 53-bit doubles, the legacy polar Gaussian with its cached second value.  All pointers are HOST
+ * pointers; no GPU is involved.
+ *   gs_zgen_fill     one stream, synchronously:  out[0..count) = float32(RandomState(seed).standard_normal(count)).
+ *   gs_zgen_start    a pool of `threads` (<= 0: one per hardware thread) std::threads generates batch i from seeds[i]
+ *                    into slots[i % n_slots] (caller-owned buffers of `count` floats, e.g. pinned memory), in order.
+ *   gs_zgen_wait     blocks until batch i is complete and returns its slot.
+ *   gs_zgen_release  tells the pool that batches [0, upto) have been consumed (their slots may be overwritten).
+ *   gs_zgen_finish   cancels what is outstanding, joins the threads, frees the handle.                          */
+typedef struct gs_zgen gs_zgen_t;
+int gs_zgen_fill(uint32_t seed, int64_t count, float *out_host);
+int gs_zgen_start(const uint32_t *seeds_host, int64_t n_batches, int64_t count, float *const *slots_host, int n_slots,
+                  int threads, gs_zgen_t **out);
+int gs_zgen_wait(gs_zgen_t *z, int64_t batch, float **slot_host);
+int gs_zgen_release(gs_zgen_t *z, int64_t upto);
+int gs_zgen_finish(gs_zgen_t *z);
+
 /* z -> w: the StyleGAN2 mapping network `Generator.style` called from
  * models/wrappers.py:177,200 (PixelNorm + L x EqualLinear(dim, dim, lr_mul,
  * activation='fused_lrelu')); in-tree analogue models/stylegan/model.py:190-216.

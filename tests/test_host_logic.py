@@ -117,3 +117,47 @@ def test_parallel_z_generation_is_bit_identical_and_ordered(monkeypatch, kind, d
     for s, z in zip(seeds, got):
         want = zstream.stylegan_z_batch(s, 37, dim) if kind == "stylegan" else zstream.biggan_z_batch(s, 37, dim, 0.8)
         np.testing.assert_array_equal(z, want)
+
+
+def test_native_z_generator_is_bit_identical_to_numpy_randomstate():
+    """csrc/gs_zgen.hip restates MT19937 + NumPy's legacy polar Gaussian (models/wrappers.py:167-174 draws z with
+    ``RandomState(seed).standard_normal``): float32 rows identical bit for bit, for the seeds of the reference's
+    stream (np.random.seed(1) -> 1791095845, ...), edge seeds and odd / even counts (the cached second value)."""
+    import ctypes as C
+    from ganspace_amd import _lib
+    lib = _lib.load()
+    for seed, count in [(1791095845, 4), (2135392491, 512 * 300 + 1), (0, 1), (1, 7), (2 ** 31 - 2, 100_000),
+                        (2 ** 32 - 1, 12_345)]:
+        out = np.empty(count, np.float32)
+        assert lib.gs_zgen_fill(seed, count, out.ctypes.data_as(C.c_void_p)) == 0
+        ref = np.random.RandomState(seed).standard_normal(count).astype(np.float32)
+        assert out.tobytes() == ref.tobytes(), (seed, count)
+    first = np.empty(4, np.float32)
+    lib.gs_zgen_fill(1791095845, 4, first.ctypes.data_as(C.c_void_p))
+    np.testing.assert_allclose(first, [0.76455638, -1.12429114, -0.13731647, 0.52814697], rtol=1e-6)   # SURVEY A.3
+
+
+def test_native_z_stream_ring_backpressure_and_order():
+    """More batches than ring slots, more threads than cores: batches come out in order, each equal to the NumPy
+    stream of its seed, while slots are recycled only after release()."""
+    from ganspace_amd import _zgen
+    seeds = [int(s) for s in np.random.RandomState(5).randint(0, 2 ** 31 - 1, size=37)]
+    stream = _zgen.NativeNormalStream(seeds, 300, 64, threads=6, pinned=False)
+    assert stream._n_slots == 10
+    got = []
+    held = []
+    for i, z in stream:
+        held.append((i, z))
+        if len(held) > 3:                       # keep three batches alive, like a consumer with copies in flight
+            j, zj = held.pop(0)
+            got.append(np.array(zj, copy=True))
+            stream.release(j + 1)
+    for j, zj in held:
+        got.append(np.array(zj, copy=True))
+    stream.close()
+    assert len(got) == 37
+    for s, z in zip(seeds, got):
+        assert z.tobytes() == _zgen.stylegan_z(s, 300, 64).tobytes()
+    # the generator front end used by decomposition._presample on hosts without a GPU
+    out = list(_zgen.generate("stylegan", seeds[:5], 300, 64))
+    assert all(o.tobytes() == _zgen.stylegan_z(s, 300, 64).tobytes() for s, o in zip(seeds, out))
