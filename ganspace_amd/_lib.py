@@ -41,6 +41,8 @@ SIGNATURES = {
     "gs_ipca_last_sweeps": (_int, [_vp]),
     "gs_ipca_last_mults": (_int, [_vp]),
     "gs_ipca_components_device": (_int, [_vp, C.POINTER(_vp), C.POINTER(_vp)]),
+    "gs_randomized_pca": (_int, [_vp, _i64, _i64, _int, _int, _int, _vp, _vp, _vp, _vp]),
+    "gs_column_moments": (_int, [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp]),
     "gs_zgen_fill": (C.c_int, [C.c_uint32, _i64, _vp]),
     "gs_zgen_start": (_int, [_vp, _i64, _i64, _vp, _int, _int, C.POINTER(_vp)]),
     "gs_zgen_wait": (_int, [_vp, _i64, C.POINTER(_vp)]),

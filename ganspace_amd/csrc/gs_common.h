@@ -2,6 +2,9 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
+#include <functional>
+#include <initializer_list>
 #include <string>
 
 #include "ganspace_hip.h"
@@ -29,6 +32,89 @@ void set_error(const std::string &msg);
 
 inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 inline int64_t ceil_div(int64_t x, int64_t m) { return (x + m - 1) / m; }
+
+// ---- launch chains as HIP graphs -----------------------------------------------------------------------------
+// The dense-linear-algebra chains of the eigensolvers are dozens of dependent launches of kernels that last 2 - 60 us
+// each: the CPU's launch rate, not the GPU, bounds them.  A chain whose launches depend only on a small integer key
+// (schedule, sizes - all pointers belong to ONE workspace and never change, coefficients live in device memory) is
+// captured once per key with hipStreamBeginCapture and replayed with one hipGraphLaunch afterwards.
+// `body` must enqueue work on `stream` only - no synchronisation, no host-visible results, no allocation.
+// Replaying a cached graph still walks the host logic of the chain (ring bookkeeping, schedules) with the launches
+// suppressed: g_dry_run is set around that walk.  Every launch of a capturable chain goes through GS_LAUNCH /
+// gs_dry_run().
+extern thread_local bool g_dry_run;
+inline bool gs_dry_run() { return g_dry_run; }
+#define GS_LAUNCH(...)                                         \
+    do {                                                       \
+        if (!::gs::g_dry_run) hipLaunchKernelGGL(__VA_ARGS__); \
+    } while (0)
+inline uint64_t graph_key(std::initializer_list<int64_t> fields) {
+    uint64_t h = 0xcbf29ce484222325ULL;
+    for (int64_t f : fields) {
+        h ^= (uint64_t)f + 0x9e3779b97f4a7c15ULL + (h << 6) + (h >> 2);
+        h *= 0x100000001b3ULL;
+    }
+    return h;
+}
+
+struct GraphCache {
+    struct Entry {
+        uint64_t key;
+        hipGraphExec_t exec;
+    };
+    static constexpr int kMax = 48;
+    Entry entries[kMax];
+    int count = 0;
+    bool enabled = false;      // set by the owner of the workspace (handles of gs_ipca: yes, one-shot test entries: no)
+};
+void graph_cache_free(GraphCache &gc);
+// hipStreamBeginCapture ... EndCapture + instantiate; returns nullptr (and leaves the stream usable) when capture is
+// not possible - the caller then simply runs the body directly
+template <class F>
+inline int run_as_graph(GraphCache &gc, uint64_t key, hipStream_t stream, F &&body) {
+    // Measured on MI355X / ROCm 7.2 (profiles/r03_graphs_vs_streams.md): replaying these chains as graphs is SLOWER than
+    // launching them (exact finalize 2.08 vs 1.88 ms, faithful block 0.34 vs 0.34 ms) - the runtime's graph launch costs
+    // more per node than a stream launch.  The path therefore stays opt-in (GS_USE_GRAPHS=1) until that changes.
+    static const bool opted_in = getenv("GS_USE_GRAPHS") != nullptr;
+    if (!gc.enabled || !opted_in) return body();
+    for (int i = 0; i < gc.count; ++i)
+        if (gc.entries[i].key == key) {
+            g_dry_run = true;
+            const int rcw = body();            // host bookkeeping only
+            g_dry_run = false;
+            if (rcw != GS_OK) return rcw;
+            GS_HIP_CHECK(hipGraphLaunch(gc.entries[i].exec, stream));
+            return GS_OK;
+        }
+    if (gc.count >= GraphCache::kMax) return body();
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &st) != hipSuccess || st != hipStreamCaptureStatusNone) return body();   // nested: plain
+    if (hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+        (void)hipGetLastError();
+        return body();
+    }
+    const int rc = body();
+    hipGraph_t graph = nullptr;
+    const hipError_t e = hipStreamEndCapture(stream, &graph);
+    if (rc != GS_OK || e != hipSuccess || graph == nullptr) {
+        if (graph) (void)hipGraphDestroy(graph);
+        (void)hipGetLastError();
+        if (rc != GS_OK) return rc;
+        gc.enabled = false;           // capture does not work here (e.g. legacy stream): never try again, run directly
+        return body();
+    }
+    hipGraphExec_t exec = nullptr;
+    if (hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess || exec == nullptr) {
+        (void)hipGraphDestroy(graph);
+        (void)hipGetLastError();
+        gc.enabled = false;
+        return body();
+    }
+    (void)hipGraphDestroy(graph);
+    gc.entries[gc.count++] = {key, exec};
+    GS_HIP_CHECK(hipGraphLaunch(exec, stream));
+    return GS_OK;
+}
 
 // ---- Gram (X^T X) accumulation: gs_gram.hip -------------------------------------------
 constexpr int kMacroTile = 128;   // output tile of one workgroup (2x2 waves of 64x64)
@@ -90,6 +176,10 @@ int rank_columns(const EighWorkspace &ws, int n, hipStream_t stream);
 // column sums of X[rows, ld] accumulated (atomically) into out[d] (float64, caller zeroes it)
 int column_sums_f64(const float *X, int64_t rows, int64_t ld, int64_t d, double *out, hipStream_t stream);
 
+// sum[j] += sum_r (x - shift_j), sumsq[j] += sum_r (x - shift_j)^2 over the rows of X, one pass (gs_rangefinder.hip)
+int column_moments(const float *X, int64_t rows, int64_t ld, int64_t d, const double *shift, double *sum, double *sumsq,
+                   hipStream_t stream);
+
 // ---- float64 GEMM with arbitrary element strides: gs_subspace.hip -------------------------------------
 // C[M x N] (row-major, ldc) = beta C + alpha sum_t A(i,t) B(t,j);  A(i,t) = A[i a_i + t a_t], B(t,j) = B[t b_t + j b_j].
 // With an epilogue:  C = coef[0] (A B) + coef[1] E1 + coef[2] E2  (coef: 3 doubles in DEVICE memory; E1 / E2 laid
@@ -145,6 +235,17 @@ struct SubspaceWorkspace {
     double *Rm = nullptr;                                           // [pp][pp] Cholesky factor
     double *Dinv = nullptr;                                         // inverses of its 32 x 32 diagonal blocks
     EighWorkspace ews;
+    GraphCache graphs;             // launch chains of the solves on this workspace (gs_topk.hip)
+    // launches the owner wants at the end of a converged top-k solve (sign convention, float32 copies, ...): enqueued
+    // optimistically inside the solve's last graph, i.e. before the host has seen the residuals - they must only write
+    // what a failed solve's fall-back overwrites anyway.  GS_LAUNCH only; no per-call scalars.
+    std::function<void(hipStream_t)> epilogue;
+    bool epilogue_done = false;    // set by a solve that enqueued the epilogue (the legacy paths do not)
+    // cold solves of same-sized matrices in a row (one exact-mode fit after another): the filter schedule of the last
+    // converged cold solve is tried first, without the planning round trip; the residual test still decides
+    bool cold_plan_valid = false;
+    int cold_plan_p = 0, cold_plan_deg = 1, cold_plan_ncyc = 1;
+    double cold_plan_gain = 0.0;
 };
 int subspace_workspace_alloc(SubspaceWorkspace &ws, int n, int p);
 void subspace_workspace_free(SubspaceWorkspace &ws);
@@ -158,11 +259,16 @@ int eigh_topk_subspace(SubspaceWorkspace &ws, const double *A, int n, int64_t ld
 //                  diagonal blocks, rdiag = diag(R) (0 marks a numerically dependent column)
 //   jacobi_small:  symmetric B (p x p, p % 8 == 0) -> theta descending, eigenvectors as COLUMNS of U; info = {sweeps, limit hit}
 //   orth_fast:     Qout = orth(Y) (CholeskyQR: Gram GEMM, chol_blocked, row-parallel triangular solve), Y: n x p, ld = ws.pp
+int topk_prepare_kernels();     // LDS opt-in of the single-workgroup kernels (before any stream capture)
 int chol_blocked_launch(const double *H, int64_t ldh, int p, double *Rm, int64_t ldr, double *Dinv, double *rdiag,
                         hipStream_t stream);
 int jacobi_small_launch(const double *B, int64_t ldb, int p, double *U, int64_t ldu, double *theta, int *info,
                         hipStream_t stream);
 int orth_fast(SubspaceWorkspace &ws, const double *Y, double *Qout, int n, int p, hipStream_t stream);
+// legacy multi-launch CholeskyQR for 128 < p <= 256 columns (gs_subspace.hip): chol_factor_blocked factors ws.H
+// (p x p, leading dim ws.pp) into ws.Rm / ws.Dinv; cholqr_blocked = Gram GEMM + factor + row-parallel solve
+int chol_factor_blocked(SubspaceWorkspace &ws, int p, hipStream_t stream);
+int cholqr_blocked(SubspaceWorkspace &ws, double *Y, double *Qout, int n, int p, hipStream_t stream);
 // ring management (gs_subspace.hip): zero every slot / take the next slot (clean_out: still zero?)
 int ring_reset(SubspaceWorkspace &ws, hipStream_t stream);
 double *ring_take(SubspaceWorkspace &ws, bool *clean_out);

@@ -26,6 +26,7 @@
 namespace gs {
 static thread_local std::string g_last_error;
 void set_error(const std::string &msg) { g_last_error = msg; }
+thread_local bool g_dry_run = false;
 }  // namespace gs
 
 using namespace gs;
@@ -66,6 +67,11 @@ struct gs_ipca {
     SmallSide ss;
     double *bs = nullptr;        // [d] column sums scratch
     SubspaceWorkspace sws;       // top-k subspace eigensolver (Gram-side modes, when k << d)
+    // The solver chains are replayed as HIP graphs, which cannot be captured on the legacy null stream (what a caller
+    // without streams of its own - torch's default - passes): the work of a call then runs on this handle's own
+    // stream, fenced against the caller's by events at entry and exit (StreamScope).
+    hipStream_t aux = nullptr;
+    hipEvent_t ev_in = nullptr, ev_out = nullptr;
     int last_mults = 0;          // multiplications by A used by the last subspace solve (0 = full Jacobi)
 };
 
@@ -350,22 +356,42 @@ __global__ void add_vec_kernel(const double *__restrict__ src, double *__restric
     if (j < d) dst[j] += src[j];
 }
 
+struct StreamScope {
+    gs_ipca *h;
+    hipStream_t user, work;
+    bool forked = false;
+    StreamScope(gs_ipca *h_, hipStream_t user_, bool enable = true) : h(h_), user(user_), work(user_) {
+        static const bool graphs = getenv("GS_USE_GRAPHS") != nullptr;     // (the only reason to leave the caller's stream)
+        if (graphs && enable && user == nullptr && h->aux != nullptr && hipEventRecord(h->ev_in, user) == hipSuccess &&
+            hipStreamWaitEvent(h->aux, h->ev_in, 0) == hipSuccess) {
+            work = h->aux;
+            forked = true;
+        }
+    }
+    ~StreamScope() {
+        if (forked && hipEventRecord(h->ev_out, h->aux) == hipSuccess) (void)hipStreamWaitEvent(user, h->ev_out, 0);
+    }
+};
+
 // Top-k eigenpairs of the assembled matrix h->W into h->Vk / h->lam (sign-fixed), then the derived
 // outputs.  Subspace iteration when k << n (warm-started from the previous components if `warm`),
 // full Jacobi otherwise or when the residual target is missed.
 int solve_topk(gs_ipca *h, bool warm, const double *total_src, int total_len, hipStream_t stream) {
     const int n = h->n2, dp = (int)h->dp, k = h->k;
     static const bool no_subspace = getenv("GS_EIGH_FULL") != nullptr;
-    bool done = false;
+    bool done = false, epilogue_done = false;
     h->last_mults = 0;
     if (h->sws.Q != nullptr && !no_subspace) {
         int mults = 0, converged = 0;
+        h->sws.epilogue_done = false;
         int rc = eigh_topk_subspace(h->sws, h->W, n, dp, k, warm ? h->Vk : nullptr, warm ? k : 0, dp, h->Vk, dp,
                                     h->lam, &mults, &converged, stream);
         if (rc != GS_OK) return rc;
         if (converged) {
-            hipLaunchKernelGGL(signfix_rows_kernel, dim3((unsigned)ceil_div(k, 4)), dim3(256), 0, stream, h->Vk, n, dp,
-                               k);
+            epilogue_done = h->sws.epilogue_done;     // sign convention / Bk / float32 copies rode on the solve's graph
+            if (!epilogue_done)
+                hipLaunchKernelGGL(signfix_rows_kernel, dim3((unsigned)ceil_div(k, 4)), dim3(256), 0, stream, h->Vk, n,
+                                   dp, k);
             h->last_mults = mults;
             h->last_sweeps = h->sws.last_rr_sweeps;   // Jacobi sweeps of the projection step
             done = true;
@@ -379,15 +405,28 @@ int solve_topk(gs_ipca *h, bool warm, const double *total_src, int total_len, hi
         hipLaunchKernelGGL(select_topk_kernel, dim3((unsigned)ceil_div(n, 4)), dim3(256), 0, stream, h->W,
                            h->ews.norms, h->ews.rank, h->Vk, h->lam, n, (int64_t)dp, dp, k);
     }
-    if (h->Bk) hipLaunchKernelGGL(set_diag_kernel, dim3((unsigned)ceil_div(k, 64), (unsigned)k), dim3(64), 0, stream, h->Bk,
-                                  h->lam, k);
+    if (h->Bk && !epilogue_done)
+        hipLaunchKernelGGL(set_diag_kernel, dim3((unsigned)ceil_div(k, 64), (unsigned)k), dim3(64), 0, stream, h->Bk, h->lam, k);
     h->pending_diag = false;
     hipLaunchKernelGGL(derive_outputs_kernel, dim3(1), dim3(256), 0, stream, h->lam, total_src, total_len, h->outs, k,
                        (double)h->n_seen);
-    hipLaunchKernelGGL(to_f32_kernel, dim3((unsigned)ceil_div(h->d, 256), (unsigned)(k + 1)), dim3(256), 0, stream,
-                       h->Vk, h->mean, h->comp32, h->mean32, (int)h->d, dp, k);
+    if (!epilogue_done)
+        hipLaunchKernelGGL(to_f32_kernel, dim3((unsigned)ceil_div(h->d, 256), (unsigned)(k + 1)), dim3(256), 0, stream,
+                           h->Vk, h->mean, h->comp32, h->mean32, (int)h->d, dp, k);
     GS_HIP_CHECK(hipGetLastError());
     return GS_OK;
+}
+
+// what solve_topk wants behind a converged subspace solve, in the form the solver can put at the end of its last graph
+void install_solver_epilogue(gs_ipca *h) {
+    h->sws.epilogue = [h](hipStream_t stream) {
+        const int k = h->k, dp = (int)h->dp, n = h->n2;
+        GS_LAUNCH(signfix_rows_kernel, dim3((unsigned)ceil_div(k, 4)), dim3(256), 0, stream, h->Vk, n, dp, k);
+        if (h->Bk) GS_LAUNCH(set_diag_kernel, dim3((unsigned)ceil_div(k, 64), (unsigned)k), dim3(64), 0, stream, h->Bk, h->lam, k);
+        GS_LAUNCH(to_f32_kernel, dim3((unsigned)ceil_div(h->d, 256), (unsigned)(k + 1)), dim3(256), 0, stream, h->Vk,
+                  h->mean, h->comp32, h->mean32, (int)h->d, dp, k);
+    };
+    h->sws.graphs.enabled = true;
 }
 
 // FAITHFUL with the diagonalisation deferred: (Vk, Bk) -> eigenpairs of Bk rotate the basis into the components
@@ -624,6 +663,13 @@ int gs_ipca_create(int64_t d, int k, int mode, int precision, int device, gs_ipc
     h->prec = precision;
     h->device = device;
     h->n2 = (int)d;
+    if (hipStreamCreateWithFlags(&h->aux, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_in, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_out, hipEventDisableTiming) != hipSuccess) {
+        (void)hipGetLastError();          // no private stream: calls on the null stream simply run without graphs
+        if (h->aux) (void)hipStreamDestroy(h->aux);
+        h->aux = nullptr;
+    }
     int rc = GS_OK;
     auto alloc = [&](void **p, size_t bytes) {
         if (rc != GS_OK) return;
@@ -660,7 +706,10 @@ int gs_ipca_create(int64_t d, int k, int mode, int precision, int device, gs_ipc
     // columns of one block's solve are good guards for the next
     h->sws.reuse_guards = (mode == GS_MODE_FAITHFUL);
     // ... and the matrix of every block after the first has rank <= k + rows with a cliff behind lambda_k
-    h->sws.guards = (mode == GS_MODE_FAITHFUL) ? 16 : 0;
+    // ... and at d <= 1024 a product costs ~7 us while every orthonormalisation and the Rayleigh-Ritz Jacobi grow with
+    // p^2 / p^3: 16 guards (42 products at p = 96) beat 48 (18 products at p = 128) on the cold exact solve of cfg2,
+    // 1.73 vs 1.88 ms (profiles/r03_graphs_vs_streams.md)
+    h->sws.guards = (mode == GS_MODE_FAITHFUL || d <= 1024) ? 16 : 0;
     h->dp = h->gws.dp;
     const int64_t dp = h->dp;
     alloc((void **)&h->shift, sizeof(float) * dp);
@@ -684,6 +733,7 @@ int gs_ipca_create(int64_t d, int k, int mode, int precision, int device, gs_ipc
         gs_ipca_destroy(h);
         return rc;
     }
+    if (h->sws.Q != nullptr) install_solver_epilogue(h);
     *out = h;
     return GS_OK;
 }
@@ -699,6 +749,12 @@ int gs_ipca_destroy(gs_ipca_t *h) {
                     h->Vk,    h->lam, h->scal, h->outs, h->comp32, h->mean32, h->Bk, h->T};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
+    if (h->aux) {
+        (void)hipStreamSynchronize(h->aux);
+        (void)hipStreamDestroy(h->aux);
+    }
+    if (h->ev_in) (void)hipEventDestroy(h->ev_in);
+    if (h->ev_out) (void)hipEventDestroy(h->ev_out);
     delete h;
     return GS_OK;
 }
@@ -726,7 +782,9 @@ int gs_ipca_reset(gs_ipca_t *h) {
 int gs_ipca_update(gs_ipca_t *h, const float *X, int64_t rows, int64_t ld, void *stream_) {
     GS_REQUIRE(h != nullptr && X != nullptr, GS_EINVAL, "gs_ipca_update: NULL argument");
     GS_REQUIRE(rows >= 1 && ld >= h->d, GS_EINVAL, "gs_ipca_update: need rows >= 1 and ld >= d");
-    hipStream_t stream = (hipStream_t)stream_;
+    // the recurrences close the block with a solver chain (HIP graphs): off the legacy null stream, see StreamScope
+    StreamScope scope(h, (hipStream_t)stream_, h->mode != GS_MODE_EXACT);
+    hipStream_t stream = scope.work;
     const int d = (int)h->d, dp = (int)h->dp;
     if (h->n_seen == 0) {
         // sklearn _incremental_pca.py:306-311: first batch must hold at least k samples
@@ -750,6 +808,7 @@ int gs_ipca_update(gs_ipca_t *h, const float *X, int64_t rows, int64_t ld, void 
             h->ss.precision = h->prec;
             int rc = smallside_alloc(h->ss, h->d, h->k, (int)rows);
             if (rc != GS_OK) return rc;
+            h->ss.sws.graphs.enabled = true;
         }
         int rc = smallside_update(h->ss, X, rows, ld, (double)h->n_seen, h->comp32, h->lam, h->mean, h->m2, h->vec,
                                   h->bs, &h->last_sweeps, stream);
@@ -758,7 +817,8 @@ int gs_ipca_update(gs_ipca_t *h, const float *X, int64_t rows, int64_t ld, void 
         h->n_seen += rows;
         h->blocks += 1;
         h->pending_diag = h->ss.w_state;    // comp32 holds W, lam is stale: gs_ipca_finalize materialises
-        hipLaunchKernelGGL(derive_outputs_kernel, dim3(1), dim3(256), 0, stream, h->lam, h->m2, (int)h->d, h->outs,
+        // (sum of m2 left behind the second moments by ss_m2_kernel)
+        hipLaunchKernelGGL(derive_outputs_kernel, dim3(1), dim3(256), 0, stream, h->lam, h->ss.colsq + h->d, 1, h->outs,
                            h->k, (double)h->n_seen);
         hipLaunchKernelGGL(to_f32_kernel, dim3((unsigned)ceil_div(h->d, 256), 1), dim3(256), 0, stream,
                            (const double *)nullptr, h->mean, (float *)nullptr, h->mean32, d, d, 0);
@@ -909,7 +969,8 @@ int gs_ipca_finalize(gs_ipca_t *h, float *components_host, double *singular_valu
                      double *explained_variance_ratio_host, int64_t *n_seen_host, void *stream_) {
     GS_REQUIRE(h != nullptr, GS_EINVAL, "gs_ipca_finalize: NULL handle");
     GS_REQUIRE(h->n_seen >= 2, GS_ESTATE, "gs_ipca_finalize: fewer than 2 samples seen");
-    hipStream_t stream = (hipStream_t)stream_;
+    StreamScope scope(h, (hipStream_t)stream_);
+    hipStream_t stream = scope.work;
     const int d = (int)h->d, k = h->k;
     if (h->mode == GS_MODE_EXACT && !h->finalized) {
         int rc = exact_solve(h, stream);

@@ -455,53 +455,51 @@ __global__ __launch_bounds__(256, 2) void tn_gemm_kernel(const float *__restrict
 
 // ---- assembling M and the per-column statistics ------------------------------------------------------
 // rows [0,k): S_t V_t ; [k, k+m): X - bm ; k+m: mc ; beyond: zero.   vec = [bm | mc | delta] (float64)
-__global__ void ss_build_kernel(const float *__restrict__ X, int64_t ldx, int m, const float *__restrict__ V,
-                                const double *__restrict__ lam, const double *__restrict__ vec, int64_t d,
-                                int k, int rp, double n0, float *__restrict__ M, int w_state) {
-    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void ss_build_kernel(const float *__restrict__ X, int64_t ldx, int m,
+                                                       const float *__restrict__ V, const double *__restrict__ lam,
+                                                       const double *__restrict__ vec, int64_t d, int k, int rp, double n0,
+                                                       float *__restrict__ M, int w_state) {
+    // thread = 4 consecutive features of one row of M (d % 4 == 0, rows 16-byte aligned): 16-byte loads and stores; the 4
+    // features share a 32-column block of the K-blocked layout, so the store is one aligned float4
+    const int64_t j = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     const int t = blockIdx.y;
     if (j >= d) return;
-    float v = 0.f;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (t < k) {
         // w_state: V already holds the rows whose Gram matrix is the truncated operator (W = Q^T M of the last block)
-        if (n0 > 0) v = w_state ? V[(int64_t)t * d + j] : (float)(sqrt(lam[t]) * (double)V[(int64_t)t * d + j]);
-    } else if (t < k + m) {
-        v = (float)((double)X[(int64_t)(t - k) * ldx + j] - vec[j]);
-    } else if (t == k + m) {
-        v = (n0 > 0) ? (float)vec[d + j] : 0.f;
-    }
-    M[mblk(t, j, rp)] = v;
-}
-
-// colsq[j] += sum over the m data rows of M[k + t][j]^2   (float64)
-__global__ __launch_bounds__(256) void ss_colsq_kernel(const float *__restrict__ M, int64_t d, int rp, int k, int m,
-                                                       double *__restrict__ colsq, int rows_per_block) {
-    __shared__ double scr[8][32];
-    const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
-    const int64_t col = (int64_t)blockIdx.x * 32 + cx;
-    const int r0 = blockIdx.y * rows_per_block;
-    const int r1 = (r0 + rows_per_block < m) ? r0 + rows_per_block : m;
-    double s = 0;
-    if (col < d)
-        for (int r = r0 + ry; r < r1; r += 8) {
-            const double v = M[mblk(k + r, col, rp)];
-            s += v * v;
+        if (n0 > 0) {
+            v = *reinterpret_cast<const float4 *>(V + (int64_t)t * d + j);
+            if (!w_state) {
+                const double sq = sqrt(lam[t]);
+                v.x = (float)(sq * (double)v.x);
+                v.y = (float)(sq * (double)v.y);
+                v.z = (float)(sq * (double)v.z);
+                v.w = (float)(sq * (double)v.w);
+            }
         }
-    scr[ry][cx] = s;
-    __syncthreads();
-    if (ry == 0 && col < d) {
-        double t = 0;
-        for (int g = 0; g < 8; ++g) t += scr[g][cx];
-        atomicAdd(colsq + col, t);
+    } else if (t < k + m) {
+        const float4 x = *reinterpret_cast<const float4 *>(X + (int64_t)(t - k) * ldx + j);
+        v.x = (float)((double)x.x - vec[j]);
+        v.y = (float)((double)x.y - vec[j + 1]);
+        v.z = (float)((double)x.z - vec[j + 2]);
+        v.w = (float)((double)x.w - vec[j + 3]);
+    } else if (t == k + m && n0 > 0) {
+        v.x = (float)vec[d + j];
+        v.y = (float)vec[d + j + 1];
+        v.z = (float)vec[d + j + 2];
+        v.w = (float)vec[d + j + 3];
     }
+    *reinterpret_cast<float4 *>(M + mblk(t, j, rp)) = v;
 }
 
+// bs = column sums of the block taken about the OLD running mean (column_moments with shift = mean; about 0 for the
+// first block)
 __global__ void ss_stats_kernel(const double *__restrict__ bs, double *__restrict__ mean,
                                 double *__restrict__ vec, int64_t d, double n0, double m) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= d) return;
     const double n1 = n0 + m;
-    const double bm = bs[i] / m;
+    const double bm = (n0 > 0 ? mean[i] : 0.0) + bs[i] / m;
     vec[i] = bm;
     if (n0 > 0) {
         const double mu = mean[i];
@@ -516,12 +514,30 @@ __global__ void ss_stats_kernel(const double *__restrict__ bs, double *__restric
     }
 }
 
-__global__ void ss_m2_kernel(const double *__restrict__ colsq, const double *__restrict__ vec,
-                             double *__restrict__ m2, int64_t d, double n0, double m) {
+// colsq / bs: second / first moments of the block about the shift of column_moments; the block's sum of squared
+// deviations about ITS mean is colsq - bs^2 / m.  Also leaves sum_i m2[i] in m2sum[0] (zeroed by the caller): the
+// explained-variance ratio needs it, and a d = 131 072 vector is not something one workgroup should add up.
+__global__ __launch_bounds__(256) void ss_m2_kernel(const double *__restrict__ colsq, const double *__restrict__ bs,
+                                                    const double *__restrict__ vec, double *__restrict__ m2, int64_t d,
+                                                    double n0, double m, double *__restrict__ m2sum) {
+    __shared__ double part[256];
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= d) return;
-    const double dl = vec[2 * d + i];
-    m2[i] = (n0 > 0 ? m2[i] : 0.0) + colsq[i] + dl * dl * (n0 * m / (n0 + m));
+    double v = 0.0;
+    if (i < d) {
+        const double dl = vec[2 * d + i];
+        const double b = bs[i];
+        double csq = colsq[i] - b * b / m;
+        csq = csq > 0.0 ? csq : 0.0;
+        v = (n0 > 0 ? m2[i] : 0.0) + csq + dl * dl * (n0 * m / (n0 + m));
+        m2[i] = v;
+    }
+    part[threadIdx.x] = v;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) part[threadIdx.x] += part[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) atomicAdd(m2sum, part[0]);
 }
 
 // Coefficients: column j of W (= w_j u_j, norms[j] = w_j^2) with rank i < k  ->  Ct[t][i] = u_j[t] / sqrt(w_j)
@@ -664,7 +680,7 @@ int smallside_alloc(SmallSide &ss, int64_t d, int k, int m) {
     if (rc == GS_OK) rc = alloc((void **)&ss.slab, sizeof(double) * (size_t)ss.nsplit * ss.rp * ss.rp);
     if (rc == GS_OK) rc = alloc((void **)&ss.Ct, sizeof(float) * (size_t)ss.rp * ss.kp);
     if (rc == GS_OK) rc = alloc((void **)&ss.Vtmp, sizeof(float) * (size_t)ss.kp * d);
-    if (rc == GS_OK) rc = alloc((void **)&ss.colsq, sizeof(double) * d);
+    if (rc == GS_OK) rc = alloc((void **)&ss.colsq, sizeof(double) * (d + 1));     // [d] second moments | sum of m2
     {
         const int Tcap = ss.rp / kRT;
         ss.order_cap = Tcap * (Tcap + 1) / 2;
@@ -695,21 +711,22 @@ int smallside_update(SmallSide &ss, const float *X, int64_t rows, int64_t ldx, d
     const int k = ss.k, m = (int)rows;
     const int r = k + m + 1, rp = ss.rp, kp = ss.kp;
     GS_REQUIRE(r <= ss.r_cap, GS_ESTATE, "smallside_update: block larger than the allocated capacity");
-    // 1. column sums -> block mean, Chan update of the running mean, mean-correction row
+    // 1. ONE pass over X for the per-feature first and second moments (taken about the running mean: no cancellation)
+    //    -> block mean, Chan update of the running mean and of the per-feature sum of squared deviations,
+    //    mean-correction row
+    GS_REQUIRE(ldx % 4 == 0 && (reinterpret_cast<uintptr_t>(X) & 15) == 0, GS_EINVAL,
+               "small-side mode needs 16-byte aligned rows (ld % 4 == 0)");
     GS_HIP_CHECK(hipMemsetAsync(bs, 0, sizeof(double) * d, stream));
-    GS_HIP_CHECK(hipMemsetAsync(ss.colsq, 0, sizeof(double) * d, stream));
-    int rc = column_sums_f64(X, rows, ldx, d, bs, stream);
+    GS_HIP_CHECK(hipMemsetAsync(ss.colsq, 0, sizeof(double) * (d + 1), stream));      // (+ the m2 total behind it)
+    int rc = column_moments(X, rows, ldx, d, n0 > 0 ? mean : nullptr, bs, ss.colsq, stream);
     if (rc != GS_OK) return rc;
     const unsigned gd = (unsigned)ceil_div(d, 256);
     hipLaunchKernelGGL(ss_stats_kernel, dim3(gd), dim3(256), 0, stream, bs, mean, vec, d, n0, (double)m);
+    hipLaunchKernelGGL(ss_m2_kernel, dim3(gd), dim3(256), 0, stream, ss.colsq, bs, vec, m2, d, n0, (double)m, ss.colsq + d);
     // 2. M = [S V ; X - bm ; mc ; 0]
-    hipLaunchKernelGGL(ss_build_kernel, dim3(gd, (unsigned)rp), dim3(256), 0, stream, X, ldx, m, V, lam, vec, d, k,
-                       rp, n0, ss.M, ss.w_state ? 1 : 0);
+    hipLaunchKernelGGL(ss_build_kernel, dim3((unsigned)ceil_div(d, 1024), (unsigned)rp), dim3(256), 0, stream, X, ldx, m, V,
+                       lam, vec, d, k, rp, n0, ss.M, ss.w_state ? 1 : 0);
     ss.last_r = r;
-    // 3. per-feature sum of squared deviations of this block -> variance update
-    hipLaunchKernelGGL(ss_colsq_kernel, dim3((unsigned)ceil_div(d, 32), (unsigned)ceil_div(m, 256)), dim3(256), 0,
-                       stream, ss.M, d, rp, k, m, ss.colsq, 256);
-    hipLaunchKernelGGL(ss_m2_kernel, dim3(gd), dim3(256), 0, stream, ss.colsq, vec, m2, d, n0, (double)m);
     // 4. T = M M^T
     const int Tt = (int)ceil_div(r, kRT), nmt = Tt * (Tt + 1) / 2;
     const int64_t kchunk = round_up(ceil_div(d, ss.nsplit), kRK);

@@ -164,22 +164,27 @@ void gemm_f64(int M, int N, int K, const double *A, int64_t a_i, int64_t a_t, co
     const int64_t tiles = ceil_div(M, TMv) * ceil_div(N, TMv);
     // split K (atomic epilogue) when the output alone cannot cover the chip and K is long enough
     int splits = 1;
+    // experiment knob: workgroups a split-K launch aims for
+    static const int target_wgs = []() {
+        const char *e = getenv("GS_GEMM_TARGET_WGS");
+        return e ? atoi(e) : 160;
+    }();
     if (allow_split && beta == 0.0 && tiles < 128 && K >= 256) {
-        splits = (int)ceil_div(160, tiles);
+        splits = (int)ceil_div(target_wgs, tiles);
         if (splits > K / 64) splits = K / 64;
         if (splits < 1) splits = 1;
     }
     const int kchunk = (int)round_up(ceil_div(K, splits), kTK);
     splits = (int)ceil_div(K, kchunk);
     if (splits > 1 && !c_is_zero)
-        hipLaunchKernelGGL(zero_rows_kernel, dim3((unsigned)ceil_div(N, 256), (unsigned)M), dim3(256), 0, stream, C, M, N,
+        GS_LAUNCH(zero_rows_kernel, dim3((unsigned)ceil_div(N, 256), (unsigned)M), dim3(256), 0, stream, C, M, N,
                            ldc);
     dim3 grid((unsigned)ceil_div(N, TMv), (unsigned)ceil_div(M, TMv), (unsigned)splits);
     if (small_tiles)
-        hipLaunchKernelGGL((gemm_f64_kernel<32, 32>), grid, dim3(256), 0, stream, M, N, K, A, a_i, a_t, B, b_t, b_j, C,
+        GS_LAUNCH((gemm_f64_kernel<32, 32>), grid, dim3(256), 0, stream, M, N, K, A, a_i, a_t, B, b_t, b_j, C,
                            ldc, alpha, beta, kchunk, epi);
     else
-        hipLaunchKernelGGL((gemm_f64_kernel<64, 64>), grid, dim3(256), 0, stream, M, N, K, A, a_i, a_t, B, b_t, b_j, C,
+        GS_LAUNCH((gemm_f64_kernel<64, 64>), grid, dim3(256), 0, stream, M, N, K, A, a_i, a_t, B, b_t, b_j, C,
                            ldc, alpha, beta, kchunk, epi);
 }
 
@@ -311,7 +316,7 @@ __global__ __launch_bounds__(512) void trsm_rows_kernel(const double *__restrict
 int trsm_rows_launch(const double *Y, double *Qout, int64_t ld, int n, int p, const double *Rm, const double *Dinv,
                      hipStream_t stream) {
     GS_REQUIRE(p >= 1 && p <= 256, GS_EINVAL, "trsm_rows: p must be in [1, 256]");
-    hipLaunchKernelGGL(trsm_rows_kernel, dim3((unsigned)ceil_div(n, 16)), dim3(512), 0, stream, Y, Qout, ld, n, p, Rm,
+    GS_LAUNCH(trsm_rows_kernel, dim3((unsigned)ceil_div(n, 16)), dim3(512), 0, stream, Y, Qout, ld, n, p, Rm,
                        Dinv);
     GS_HIP_CHECK(hipGetLastError());
     return GS_OK;
@@ -363,6 +368,33 @@ __global__ __launch_bounds__(64) void rdiag_stats_kernel(const double *__restric
 // trailing updates as float64 GEMMs),  Qout = Y R^-1 (one row-parallel kernel).
 // (A single-workgroup fused factorisation was tried: 3 launches instead of 16, but 220 us against ~170 us - every
 // phase of it is a latency-bound dependent chain, and one CU does not hide that better than the launch queue.)
+int chol_factor_blocked(SubspaceWorkspace &ws, int p, hipStream_t stream) {
+    GS_REQUIRE(p >= 1 && p <= 256 && p <= ws.pp, GS_EINVAL, "chol_factor_blocked: p must be in [1, 256]");
+    const int64_t ld = ws.pp;
+    double *H = ws.H, *Rm = ws.Rm;
+    for (int j0 = 0, J = 0; j0 < p; j0 += kCB, ++J) {
+        const int nb = (p - j0 < kCB) ? p - j0 : kCB;
+        const int j1 = j0 + nb, rem = p - j1;
+        double *Dinv = ws.Dinv + (size_t)J * kCB * kCB;
+        GS_LAUNCH(chol_diag_kernel, dim3(1), dim3(64), 0, stream, H, ld, p, j0, nb, Rm, Dinv, ws.theta + 2 * ws.pp);
+        if (rem > 0) {
+            gemm_f64(nb, rem, nb, Dinv, 1, kCB, H + (int64_t)j0 * ld + j1, ld, 1, Rm + (int64_t)j0 * ld + j1, ld, stream);
+            gemm_f64(rem, rem, nb, Rm + (int64_t)j0 * ld + j1, 1, ld, Rm + (int64_t)j0 * ld + j1, ld, 1,
+                     H + (int64_t)j1 * ld + j1, ld, stream, -1.0, 1.0);
+        }
+    }
+    GS_HIP_CHECK(hipGetLastError());
+    return GS_OK;
+}
+
+int cholqr_blocked(SubspaceWorkspace &ws, double *Y, double *Qout, int n, int p, hipStream_t stream) {
+    const int64_t ld = ws.pp;
+    gemm_f64(p, p, n, Y, 1, ld, Y, ld, 1, ws.H, ld, stream);  // H = Y^T Y
+    int rc = chol_factor_blocked(ws, p, stream);
+    if (rc != GS_OK) return rc;
+    return trsm_rows_launch(Y, Qout, ld, n, p, ws.Rm, ws.Dinv, stream);
+}
+
 static int cholqr(SubspaceWorkspace &ws, double *Y, double *Qout, int n, int p, hipStream_t stream) {
     const int64_t ld = ws.pp;
     double *H = ws.H, *Rm = ws.Rm;
@@ -371,7 +403,7 @@ static int cholqr(SubspaceWorkspace &ws, double *Y, double *Qout, int n, int p, 
         const int nb = (p - j0 < kCB) ? p - j0 : kCB;
         const int j1 = j0 + nb, rem = p - j1;
         double *Dinv = ws.Dinv + (size_t)J * kCB * kCB;
-        hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(64), 0, stream, H, ld, p, j0, nb, Rm, Dinv, ws.theta + 2 * ws.pp);
+        GS_LAUNCH(chol_diag_kernel, dim3(1), dim3(64), 0, stream, H, ld, p, j0, nb, Rm, Dinv, ws.theta + 2 * ws.pp);
         if (rem > 0) {
             // panel  R[J, rest] = R_JJ^-T H[J, rest]
             gemm_f64(nb, rem, nb, Dinv, 1, kCB, H + (int64_t)j0 * ld + j1, ld, 1, Rm + (int64_t)j0 * ld + j1, ld, stream);
@@ -380,7 +412,7 @@ static int cholqr(SubspaceWorkspace &ws, double *Y, double *Qout, int n, int p, 
                      H + (int64_t)j1 * ld + j1, ld, stream, -1.0, 1.0);
         }
     }
-    hipLaunchKernelGGL(trsm_rows_kernel, dim3((unsigned)ceil_div(n, 16)), dim3(512), 0, stream, Y, Qout, ld, n, p, Rm,
+    GS_LAUNCH(trsm_rows_kernel, dim3((unsigned)ceil_div(n, 16)), dim3(512), 0, stream, Y, Qout, ld, n, p, Rm,
                        ws.Dinv);
     GS_HIP_CHECK(hipGetLastError());
     return GS_OK;
@@ -464,10 +496,18 @@ int subspace_workspace_alloc(SubspaceWorkspace &ws, int n, int p) {
     if (rc == GS_OK) rc = alloc(&ws.Dinv, (size_t)(ws.pp / 16 + 1) * kCB * kCB);
     if (rc == GS_OK && hipMemset(ws.Rm, 0, sizeof(double) * ppp) != hipSuccess) rc = GS_EHIP;
     if (rc == GS_OK) rc = eigh_workspace_alloc(ws.ews, ws.pp + 2);
+    if (rc == GS_OK) rc = topk_prepare_kernels();
     return rc;
 }
 
+void graph_cache_free(GraphCache &gc) {
+    for (int i = 0; i < gc.count; ++i)
+        if (gc.entries[i].exec) (void)hipGraphExecDestroy(gc.entries[i].exec);
+    gc.count = 0;
+}
+
 void subspace_workspace_free(SubspaceWorkspace &ws) {
+    graph_cache_free(ws.graphs);
     double *ptrs[] = {ws.pool, ws.G, ws.H, ws.B, ws.U, ws.theta, ws.Rm, ws.Dinv};
     for (double *p : ptrs)
         if (p) (void)hipFree(p);
@@ -476,7 +516,7 @@ void subspace_workspace_free(SubspaceWorkspace &ws) {
 }
 
 int ring_reset(SubspaceWorkspace &ws, hipStream_t stream) {
-    GS_HIP_CHECK(hipMemsetAsync(ws.pool, 0, sizeof(double) * ws.pool_elems, stream));
+    if (!g_dry_run) GS_HIP_CHECK(hipMemsetAsync(ws.pool, 0, sizeof(double) * ws.pool_elems, stream));
     for (int i = 0; i < ws.ring_n; ++i) ws.ring_clean[i] = true;
     for (int i = 0; i < SubspaceWorkspace::kHRing; ++i) ws.h_clean[i] = true;
     ws.ring_next = 0;
@@ -534,9 +574,9 @@ int eigh_topk_subspace(SubspaceWorkspace &ws, const double *A, int n, int64_t ld
     double *Q = ws.Q, *Y = ws.Y, *Z = ws.Z;
     const dim3 gnp((unsigned)ceil_div(p, 64), (unsigned)n), b64(64);
     const bool warm = (k0 > 0);   // V0 == nullptr with k0 > 0 seeds with the first k0 unit vectors
-    hipLaunchKernelGGL(subspace_init_kernel, gnp, b64, 0, stream, Y, n, p, ld, 0);
+    GS_LAUNCH(subspace_init_kernel, gnp, b64, 0, stream, Y, n, p, ld, 0);
     if (warm)
-        hipLaunchKernelGGL(subspace_seed_kernel, dim3((unsigned)ceil_div(k0, 64), (unsigned)n), b64, 0, stream, Y, n,
+        GS_LAUNCH(subspace_seed_kernel, dim3((unsigned)ceil_div(k0, 64), (unsigned)n), b64, 0, stream, Y, n,
                            ld, V0, k0, ldv0);
     int rc = cholqr(ws, Y, Q, n, p, stream);
     if (rc != GS_OK) return rc;
@@ -584,7 +624,7 @@ int eigh_topk_subspace(SubspaceWorkspace &ws, const double *A, int n, int64_t ld
                 if (mults >= next_rr || mults >= max_mults) break;
                 continue;
             }
-            hipLaunchKernelGGL(rdiag_stats_kernel, dim3(1), dim3(64), 0, stream, ws.Rm, ld, p, k, stats);
+            GS_LAUNCH(rdiag_stats_kernel, dim3(1), dim3(64), 0, stream, ws.Rm, ld, p, k, stats);
             GS_HIP_CHECK(hipMemcpyAsync(host.data(), stats, sizeof(double) * 6, hipMemcpyDeviceToHost, stream));
             GS_HIP_CHECK(hipStreamSynchronize(stream));
             const double r1 = host[0], rk = host[1], rp = host[2], dmax = host[3], dmin = host[4];
@@ -623,11 +663,11 @@ int eigh_topk_subspace(SubspaceWorkspace &ws, const double *A, int n, int64_t ld
         rc = eigh_jacobi(ws.ews, ws.B, p, ld, &sweeps, stream);   // columns of B -> theta_j u_j
         if (rc == GS_OK) rc = rank_columns(ws.ews, p, stream);
         if (rc != GS_OK) return rc;
-        hipLaunchKernelGGL(ritz_vectors_kernel, dim3((unsigned)ceil_div(p, 64), (unsigned)p), b64, 0, stream, ws.B,
+        GS_LAUNCH(ritz_vectors_kernel, dim3((unsigned)ceil_div(p, 64), (unsigned)p), b64, 0, stream, ws.B,
                            ld, ws.ews.norms, ws.ews.rank, p, ws.U, ld, ws.theta);
         gemm_f64(n, p, p, Q, ld, 1, ws.U, ld, 1, Z, ld, stream);     // Z = Q U  : Ritz vectors (all p)
         gemm_f64(n, k, p, Y, ld, 1, ws.U, ld, 1, ws.R, ld, stream);  // R = (A Q) U_k
-        hipLaunchKernelGGL(resid_kernel, dim3((unsigned)k), dim3(256), 0, stream, ws.R, Z, ld, ws.theta, n, k,
+        GS_LAUNCH(resid_kernel, dim3((unsigned)k), dim3(256), 0, stream, ws.R, Z, ld, ws.theta, n, k,
                            ws.theta + ws.pp);
         GS_HIP_CHECK(hipMemcpyAsync(host.data(), ws.theta + ws.pp, sizeof(double) * k, hipMemcpyDeviceToHost, stream));
         GS_HIP_CHECK(hipMemcpyAsync(host.data() + k, ws.theta, sizeof(double), hipMemcpyDeviceToHost, stream));
@@ -643,7 +683,7 @@ int eigh_topk_subspace(SubspaceWorkspace &ws, const double *A, int n, int64_t ld
                 const bool wide = worst <= 1e-4 * tol2 * th1 * th1;
                 ws.warm_mults = (wide && mults > 4) ? mults - 2 : mults;
             }
-            hipLaunchKernelGGL(emit_rows_kernel, dim3((unsigned)ceil_div(n, 256), (unsigned)k), dim3(256), 0, stream,
+            GS_LAUNCH(emit_rows_kernel, dim3((unsigned)ceil_div(n, 256), (unsigned)k), dim3(256), 0, stream,
                                Z, ld, ws.theta, n, k, Vk, ldv, lam);
             GS_HIP_CHECK(hipGetLastError());
             break;

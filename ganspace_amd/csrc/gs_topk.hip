@@ -61,6 +61,14 @@ __device__ __forceinline__ double sum8(double v) {
     return v;
 }
 
+// sum over each aligned group of LP (8 or 16) lanes, result in all of them
+template <int LP>
+__device__ __forceinline__ double sum_group(double v) {
+    v = sum8(v);
+    if (LP == 16) v = dpp_add64<0x140>(v);   // row_mirror
+    return v;
+}
+
 }  // namespace
 
 // =====================================================================================================
@@ -285,8 +293,9 @@ __global__ __launch_bounds__(1024) void chol_blocked_kernel(const double *__rest
 // the eigenvectors as COLUMNS of U (U[t * ldu + rank]); info[0] = sweeps, info[1] = 1 if the sweep limit was hit.
 constexpr int kJacLd = 128;
 constexpr int kJacMaxSweeps = 30;
-template <int NT>
-__global__ __launch_bounds__(512) void jacobi_lds_kernel(const double *__restrict__ B, int64_t ldb, int p,
+constexpr int kJacobiDefaultLP = 8;
+template <int NT, int LP = 8>
+__global__ __launch_bounds__(64 * LP) void jacobi_lds_kernel(const double *__restrict__ B, int64_t ldb, int p,
                                                           double *__restrict__ U, int64_t ldu,
                                                           double *__restrict__ theta, int *__restrict__ info, int debug) {
     const long long dbg_c0 = debug ? clock64() : 0, dbg_w0 = debug ? wall_clock64() : 0;
@@ -298,11 +307,11 @@ __global__ __launch_bounds__(512) void jacobi_lds_kernel(const double *__restric
     int *flag = reinterpret_cast<int *>(umax + 1);           // [1]: a big rotation was seen in this sweep
     const int tid = threadIdx.x, nthr = blockDim.x;
     const int h = p >> 1, m1 = p - 1;
-    const int g = tid >> 3, q = tid & 7;
+    const int g = tid / LP, q = tid % LP;
     const int swz = g & 3;                                   // bank swizzle: permutes blocks of 4 element slots
     const bool act = g < h;
     // ---- load (B symmetric: row j = column j); rows p .. 8 NT of every column are zero padding ----
-    constexpr int PL = 8 * NT;
+    constexpr int PL = LP * NT;
     for (int e = tid; e < p * PL; e += nthr) {
         const int j = e / PL, t = e - j * PL;
         W[j * kJacLd + t] = (t < p) ? B[(int64_t)j * ldb + t] : 0.0;
@@ -321,10 +330,10 @@ __global__ __launch_bounds__(512) void jacobi_lds_kernel(const double *__restric
             double s = 0.0;
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-                const double v = col[q + 8 * t];
+                const double v = col[q + LP * t];
                 s += v * v;
             }
-            s = sum8(s);
+            s = sum_group<LP>(s);
             if (q == 0) {
                 nrm[j] = s;
                 atomicMax(umax, (unsigned long long)__double_as_longlong(s));
@@ -339,8 +348,8 @@ __global__ __launch_bounds__(512) void jacobi_lds_kernel(const double *__restric
 
     // element t of a column sits at  q + 8 (t ^ swz) = (q + 8 ((t & 3) ^ swz)) + 32 (t >> 2): four per-thread
     // offsets, the rest is an immediate of the LDS instruction
-    const int eo0 = q + 8 * (0 ^ swz), eo1 = q + 8 * (1 ^ swz), eo2 = q + 8 * (2 ^ swz), eo3 = q + 8 * (3 ^ swz);
-#define GS_JAC_AT(col, t) ((col)[(((t) & 3) == 0 ? eo0 : ((t) & 3) == 1 ? eo1 : ((t) & 3) == 2 ? eo2 : eo3) + 32 * ((t) >> 2)])
+    const int eo0 = q + LP * (0 ^ swz), eo1 = q + LP * (1 ^ swz), eo2 = q + LP * (2 ^ swz), eo3 = q + LP * (3 ^ swz);
+#define GS_JAC_AT(col, t) ((col)[(((t) & 3) == 0 ? eo0 : ((t) & 3) == 1 ? eo1 : ((t) & 3) == 2 ? eo2 : eo3) + 4 * LP * ((t) >> 2)])
     double x[NT], y[NT];
     const long long dbg_c1 = debug ? clock64() : 0;
     int sweeps = 0;
@@ -382,13 +391,13 @@ __global__ __launch_bounds__(512) void jacobi_lds_kernel(const double *__restric
                         sa[t & 3] += x[t] * x[t];
                         sb[t & 3] += y[t] * y[t];
                     }
-                    alpha = sum8((sa[0] + sa[1]) + (sa[2] + sa[3]));
-                    beta = sum8((sb[0] + sb[1]) + (sb[2] + sb[3]));
+                    alpha = sum_group<LP>((sa[0] + sa[1]) + (sa[2] + sa[3]));
+                    beta = sum_group<LP>((sb[0] + sb[1]) + (sb[2] + sb[3]));
                 } else {
                     alpha = nrm[a];
                     beta = nrm[b];
                 }
-                gamma = sum8(gamma);
+                gamma = sum_group<LP>(gamma);
                 const double ab = alpha * beta, g2 = gamma * gamma;
                 const bool rot = (alpha > floor2) && (beta > floor2) && (g2 > kTolRot2 * ab);
                 if (rot) {
@@ -457,10 +466,10 @@ __global__ __launch_bounds__(512) void jacobi_lds_kernel(const double *__restric
             double s = 0.0;
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-                const double v = col[q + 8 * t];
+                const double v = col[q + LP * t];
                 s += v * v;
             }
-            s = sum8(s);
+            s = sum_group<LP>(s);
             if (q == 0) nrm[j] = s;
         }
     }
@@ -624,34 +633,51 @@ static size_t jacobi_lds_bytes() {
     return sizeof(double) * ((size_t)kJacLd * kJacLd + kJacLd) + sizeof(int) * kJacLd + 32;
 }
 
+// LDS opt-in of the single-workgroup kernels, once per process and BEFORE any of them is launched inside a stream
+// capture (subspace_workspace_alloc calls this)
+int topk_prepare_kernels() {
+    static bool done = false;
+    if (done) return GS_OK;
+    GS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(chol_blocked_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)kCholLdsBytes));
+#define GS_JAC_ATTR(NT, LP)                                                                         \
+    GS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(jacobi_lds_kernel<NT, LP>),    \
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)jacobi_lds_bytes()))
+    GS_JAC_ATTR(4, 8);
+    GS_JAC_ATTR(8, 8);
+    GS_JAC_ATTR(12, 8);
+    GS_JAC_ATTR(16, 8);
+    GS_JAC_ATTR(4, 16);
+    GS_JAC_ATTR(8, 16);
+#undef GS_JAC_ATTR
+    done = true;
+    return GS_OK;
+}
+
 int chol_blocked_launch(const double *H, int64_t ldh, int p, double *Rm, int64_t ldr, double *Dinv, double *rdiag,
                         hipStream_t stream) {
     GS_REQUIRE(p >= 1 && p <= kCholP, GS_EINVAL, "chol_blocked: p must be in [1, 128]");
-    static bool attr_set = false;
-    if (!attr_set) {
-        GS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(chol_blocked_kernel),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)kCholLdsBytes));
-        attr_set = true;
+    {
+        int rcp = topk_prepare_kernels();
+        if (rcp != GS_OK) return rcp;
     }
     static const int debug = getenv("GS_TOPK_DEBUG") ? 1 : 0;
-    hipLaunchKernelGGL(chol_blocked_kernel, dim3(1), dim3(1024), kCholLdsBytes, stream, H, ldh, p, Rm, ldr, Dinv,
+    GS_LAUNCH(chol_blocked_kernel, dim3(1), dim3(1024), kCholLdsBytes, stream, H, ldh, p, Rm, ldr, Dinv,
                        rdiag, debug);
     GS_HIP_CHECK(hipGetLastError());
     return GS_OK;
 }
 
-template <int NT>
+template <int NT, int LP>
 static int jacobi_launch_nt(const double *B, int64_t ldb, int p, double *U, int64_t ldu, double *theta, int *info,
                             hipStream_t stream) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        GS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(jacobi_lds_kernel<NT>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)jacobi_lds_bytes()));
-        attr_set = true;
+    {
+        int rcp = topk_prepare_kernels();
+        if (rcp != GS_OK) return rcp;
     }
     static const int debug = getenv("GS_TOPK_DEBUG") ? 1 : 0;
-    hipLaunchKernelGGL(jacobi_lds_kernel<NT>, dim3(1), dim3(4 * p), jacobi_lds_bytes(), stream, B, ldb, p, U, ldu,
-                       theta, info, debug);
+    GS_LAUNCH((jacobi_lds_kernel<NT, LP>), dim3(1), dim3((p / 2) * LP), jacobi_lds_bytes(), stream, B, ldb, p, U, ldu,
+              theta, info, debug);
     GS_HIP_CHECK(hipGetLastError());
     return GS_OK;
 }
@@ -659,11 +685,23 @@ static int jacobi_launch_nt(const double *B, int64_t ldb, int p, double *U, int6
 int jacobi_small_launch(const double *B, int64_t ldb, int p, double *U, int64_t ldu, double *theta, int *info,
                         hipStream_t stream) {
     GS_REQUIRE(p >= 8 && p <= kJacLd && (p % 8) == 0, GS_EINVAL, "jacobi_small: p must be a multiple of 8 in [8, 128]");
+    // lanes per column pair: 8 (4 p threads, p / 8 rows per lane) or 16 (8 p threads, twice the waves per SIMD to hide
+    // the LDS round trips of a round behind the other waves' rotations); GS_JACOBI_LP overrides
+    static const int lp_env = []() {
+        const char *e = getenv("GS_JACOBI_LP");
+        return e ? atoi(e) : 0;
+    }();
+    const int lp = lp_env == 8 || lp_env == 16 ? lp_env : kJacobiDefaultLP;
+    if (lp == 16 && p >= 32) {
+        const int nt = (((p + 15) >> 4) + 3) & ~3;
+        if (nt == 4) return jacobi_launch_nt<4, 16>(B, ldb, p, U, ldu, theta, info, stream);
+        return jacobi_launch_nt<8, 16>(B, ldb, p, U, ldu, theta, info, stream);
+    }
     const int nt = ((p >> 3) + 3) & ~3;
-    if (nt == 4) return jacobi_launch_nt<4>(B, ldb, p, U, ldu, theta, info, stream);
-    if (nt == 8) return jacobi_launch_nt<8>(B, ldb, p, U, ldu, theta, info, stream);
-    if (nt == 12) return jacobi_launch_nt<12>(B, ldb, p, U, ldu, theta, info, stream);
-    return jacobi_launch_nt<16>(B, ldb, p, U, ldu, theta, info, stream);
+    if (nt == 4) return jacobi_launch_nt<4, 8>(B, ldb, p, U, ldu, theta, info, stream);
+    if (nt == 8) return jacobi_launch_nt<8, 8>(B, ldb, p, U, ldu, theta, info, stream);
+    if (nt == 12) return jacobi_launch_nt<12, 8>(B, ldb, p, U, ldu, theta, info, stream);
+    return jacobi_launch_nt<16, 8>(B, ldb, p, U, ldu, theta, info, stream);
 }
 
 // Q_out = orth(Y) by CholeskyQR in three launches: H = Y^T Y (GEMM), blocked Cholesky in one workgroup,
@@ -750,67 +788,86 @@ int invsub_iterate(SubspaceWorkspace &ws, const double *A, int n, int64_t lda, i
         ws.inv_plan = 0;
         return GS_OK;
     }
-    int rcr = ring_reset(ws, stream);     // every block below comes out of the zeroed ring
-    if (rcr != GS_OK) return rcr;
-    double *Qc = ring_take(ws, nullptr);
-    hipLaunchKernelGGL(topk_seed_kernel, dim3((unsigned)ceil_div(k, 64), (unsigned)n), dim3(64), 0, stream, Qc, n, ld,
-                       identity_start ? (const double *)nullptr : Vk, k, ldv);
+    double *Qc = nullptr;
     int used = 0;
     const int P0 = P;
     std::vector<double> host(3 * (size_t)ws.pp);
     double *Bm = nullptr;
     for (int attempt = 0; attempt < 3; ++attempt) {
-        int rem = P, jj_last = 1;
-        while (rem > 0) {
-            const int jj = j < rem ? j : rem;
-            double *cur = Qc;
-            for (int s = 0; s < jj; ++s) {
-                bool clean = false;
-                double *nxt = ring_take(ws, &clean);
-                gemm_f64(n, k, n, A, lda, 1, cur, ld, 1, nxt, ld, stream, 1.0, 0.0, none, true, clean);
-                cur = nxt;
-                ++used;
+        int jj_last = 1;
+        // expected loss of orthogonality of the last CholeskyQR pass: cond(Y)^2 eps (unknown spectrum: assume the worst)
+        {
+            int rem = P, jl = 1;
+            while (rem > 0) {
+                jl = j < rem ? j : rem;
+                rem -= jl;
             }
-            double *o = ring_take(ws, nullptr);
-            int rc = orth_fast(ws, cur, o, n, k, stream);   // R diagonal -> theta + 2 pp
-            if (rc != GS_OK) return rc;
-            Qc = o;
-            rem -= jj;
-            jj_last = jj;
+            jj_last = jl;
         }
-        // a second pass when the first one cannot have left the basis orthonormal to ~1e-12 (cond^2 eps)
-        // expected loss of orthogonality of the pass above: cond(Y)^2 eps (unknown spectrum: assume the worst)
         const double e_est = ws.inv_ratio1 > 1.0 ? std::pow(ws.inv_ratio1, 2.0 * jj_last) * 1e-16 : 1.0;
         const bool pass2 = e_est > 1e-12;
-        if (pass2) {
-            bool clean = false;
-            double *H = hring_take(ws, &clean);
-            double *o = ring_take(ws, nullptr);
-            gemm_f64(k, k, n, Qc, 1, ld, Qc, ld, 1, H, ld, stream, 1.0, 0.0, none, true, clean);
-            if (e_est <= 1e-7) {
-                // E = Q^T Q - I is tiny: one step of the symmetric (Loewdin / Newton-Schulz) correction
-                // Q <- Q (I - E / 2) leaves E^2 - a GEMM with a k x k matrix instead of a second single-workgroup
-                // Cholesky + triangular solve (56 -> 13 us); any orthonormal basis of the same span will do here
-                hipLaunchKernelGGL(invsub_loewdin_kernel, dim3((unsigned)ceil_div(k, 64), (unsigned)k), dim3(64), 0, stream, H,
-                                   ld, k);
-                gemm_f64(n, k, k, Qc, ld, 1, H, ld, 1, o, ld, stream, 1.0, 0.0, none, false);
-            } else {
-                int rc = chol_blocked_launch(H, ld, k, ws.Rm, ld, ws.Dinv, ws.theta, stream);   // keeps theta + 2 pp
-                if (rc != GS_OK) return rc;
-                rc = trsm_rows_launch(Qc, o, ld, n, k, ws.Rm, ws.Dinv, stream);
-                if (rc != GS_OK) return rc;
+        const bool loewdin = pass2 && e_est <= 1e-7;
+        // ---- the whole attempt (products, CholeskyQR steps, Rayleigh quotient, residuals) as ONE graph -------------
+        auto segment = [&]() -> int {
+            if (attempt == 0) {
+                int rcr = ring_reset(ws, stream);     // every block below comes out of the zeroed ring
+                if (rcr != GS_OK) return rcr;
+                Qc = ring_take(ws, nullptr);
+                GS_LAUNCH(topk_seed_kernel, dim3((unsigned)ceil_div(k, 64), (unsigned)n), dim3(64), 0, stream, Qc, n, ld,
+                          identity_start ? (const double *)nullptr : Vk, k, ldv);
             }
-            Qc = o;
-        }
-        bool cleany = false, cleanb = false;
-        double *Yb = ring_take(ws, &cleany), *Zb = ring_take(ws, nullptr);
-        Bm = hring_take(ws, &cleanb);
-        gemm_f64(n, k, n, A, lda, 1, Qc, ld, 1, Yb, ld, stream, 1.0, 0.0, none, true, cleany);     // Y = A Q
-        ++used;
-        gemm_f64(k, k, n, Qc, 1, ld, Yb, ld, 1, Bm, ld, stream, 1.0, 0.0, none, true, cleanb);     // B = Q^T Y
-        gemm_f64(n, k, k, Qc, ld, 1, Bm, ld, 1, Zb, ld, stream, 1.0, 0.0, none, false);            // Z = Q B
-        hipLaunchKernelGGL(invsub_resid_kernel, dim3((unsigned)k), dim3(256), 0, stream, Yb, Zb, ld, Bm, ld, n,
-                           ws.theta + ws.pp, ws.theta);
+            int rem = P;
+            while (rem > 0) {
+                const int jj = j < rem ? j : rem;
+                double *cur = Qc;
+                for (int s2 = 0; s2 < jj; ++s2) {
+                    bool clean = false;
+                    double *nxt = ring_take(ws, &clean);
+                    gemm_f64(n, k, n, A, lda, 1, cur, ld, 1, nxt, ld, stream, 1.0, 0.0, none, true, clean);
+                    cur = nxt;
+                    ++used;
+                }
+                double *o = ring_take(ws, nullptr);
+                int rc = orth_fast(ws, cur, o, n, k, stream);   // R diagonal -> theta + 2 pp
+                if (rc != GS_OK) return rc;
+                Qc = o;
+                rem -= jj;
+            }
+            // a second pass when the first one cannot have left the basis orthonormal to ~1e-12 (cond^2 eps)
+            if (pass2) {
+                bool clean = false;
+                double *H = hring_take(ws, &clean);
+                double *o = ring_take(ws, nullptr);
+                gemm_f64(k, k, n, Qc, 1, ld, Qc, ld, 1, H, ld, stream, 1.0, 0.0, none, true, clean);
+                if (loewdin) {
+                    // E = Q^T Q - I is tiny: one step of the symmetric (Loewdin / Newton-Schulz) correction
+                    // Q <- Q (I - E / 2) leaves E^2 - a GEMM with a k x k matrix instead of a second single-workgroup
+                    // Cholesky + triangular solve (56 -> 13 us); any orthonormal basis of the same span will do here
+                    GS_LAUNCH(invsub_loewdin_kernel, dim3((unsigned)ceil_div(k, 64), (unsigned)k), dim3(64), 0, stream, H, ld, k);
+                    gemm_f64(n, k, k, Qc, ld, 1, H, ld, 1, o, ld, stream, 1.0, 0.0, none, false);
+                } else {
+                    int rc = chol_blocked_launch(H, ld, k, ws.Rm, ld, ws.Dinv, ws.theta, stream);   // keeps theta + 2 pp
+                    if (rc != GS_OK) return rc;
+                    rc = trsm_rows_launch(Qc, o, ld, n, k, ws.Rm, ws.Dinv, stream);
+                    if (rc != GS_OK) return rc;
+                }
+                Qc = o;
+            }
+            bool cleany = false, cleanb = false;
+            double *Yb = ring_take(ws, &cleany), *Zb = ring_take(ws, nullptr);
+            Bm = hring_take(ws, &cleanb);
+            gemm_f64(n, k, n, A, lda, 1, Qc, ld, 1, Yb, ld, stream, 1.0, 0.0, none, true, cleany);     // Y = A Q
+            ++used;
+            gemm_f64(k, k, n, Qc, 1, ld, Yb, ld, 1, Bm, ld, stream, 1.0, 0.0, none, true, cleanb);     // B = Q^T Y
+            gemm_f64(n, k, k, Qc, ld, 1, Bm, ld, 1, Zb, ld, stream, 1.0, 0.0, none, false);            // Z = Q B
+            GS_LAUNCH(invsub_resid_kernel, dim3((unsigned)k), dim3(256), 0, stream, Yb, Zb, ld, Bm, ld, n, ws.theta + ws.pp,
+                      ws.theta);
+            return GS_OK;
+        };
+        const int rcs = run_as_graph(ws.graphs, graph_key({3, attempt, P, j, pass2 ? (loewdin ? 1 : 2) : 0, identity_start,
+                                                           n, k, ws.ring_next, ws.h_next, lda, ldv, (int64_t)(intptr_t)A,
+                                                           (int64_t)(intptr_t)Vk, (int64_t)(intptr_t)Qc}), stream, segment);
+        if (rcs != GS_OK) return rcs;
         GS_HIP_CHECK(hipMemcpyAsync(host.data(), ws.theta, sizeof(double) * 3 * ws.pp, hipMemcpyDeviceToHost, stream));
         GS_HIP_CHECK(hipStreamSynchronize(stream));
         const double *bdiag = host.data(), *resid = host.data() + ws.pp, *rdiag = host.data() + 2 * ws.pp;
@@ -839,7 +896,7 @@ int invsub_iterate(SubspaceWorkspace &ws, const double *A, int n, int64_t lda, i
                     blocks_seen, attempt, P, j, (int)pass2, used, rel, ratio1, lamk / th1);
         if (rel <= 1.0) {
             *converged = 1;
-            hipLaunchKernelGGL(invsub_emit_kernel, dim3((unsigned)ceil_div((int)(ldv > k ? ldv : k), 256), (unsigned)k),
+            GS_LAUNCH(invsub_emit_kernel, dim3((unsigned)ceil_div((int)(ldv > k ? ldv : k), 256), (unsigned)k),
                                dim3(256), 0, stream, Qc, ld, n, k, Vk, ldv, Bm, ld, Bk, ldbk);
             GS_HIP_CHECK(hipGetLastError());
             if (attempt == 0) {
@@ -881,51 +938,60 @@ int eigh_topk_cheb(SubspaceWorkspace &ws, const double *A, int n, int64_t lda, i
     *converged = 0;
     int mults = 0;
 
-    // ---- start basis -------------------------------------------------------------------------------------
-    int rcr = ring_reset(ws, stream);     // every n x p block below comes out of the zeroed ring
-    if (rcr != GS_OK) return rcr;
-    double *Qc = ring_take(ws, nullptr);  // current orthonormal basis Q
-    hipLaunchKernelGGL(topk_init_kernel, gnp, b64, 0, stream, Qc, n, p, ld);
-    if (warm) {
-        hipLaunchKernelGGL(topk_seed_kernel, dim3((unsigned)ceil_div(k0, 64), (unsigned)n), b64, 0, stream, Qc, n, ld,
-                           V0, k0, ldv0);
-        const bool prev_basis = ws.reuse_guards && ws.guards_valid && ws.guards_n == n && ws.guards_p == p && k0 < p;
-        if (prev_basis) {
-            // [previous components | previous guard Ritz vectors] is the previous solve's Ritz basis up to signs:
-            // orthonormal already, the estimate cycle below re-orthonormalises A times it anyway
-            hipLaunchKernelGGL(topk_copycols_kernel, dim3((unsigned)ceil_div(p - k0, 64), (unsigned)n), b64, 0, stream,
-                               Qc, ws.G, ld, k0, p);
-        } else {
-            double *o = ring_take(ws, nullptr);
-            int rc = orth_fast(ws, Qc, o, n, p, stream);
+    // ---- segment A: start basis + estimate cycles, one graph ------------------------------------------------
+    double *Qc = nullptr;                  // current orthonormal basis Q
+    const int est_cycles = warm ? 1 : 2;
+    const bool prev_basis = warm && ws.reuse_guards && ws.guards_valid && ws.guards_n == n && ws.guards_p == p && k0 < p;
+    auto segment_a = [&]() -> int {
+        int rcr = ring_reset(ws, stream);     // every n x p block below comes out of the zeroed ring
+        if (rcr != GS_OK) return rcr;
+        Qc = ring_take(ws, nullptr);
+        GS_LAUNCH(topk_init_kernel, gnp, b64, 0, stream, Qc, n, p, ld);
+        if (warm) {
+            GS_LAUNCH(topk_seed_kernel, dim3((unsigned)ceil_div(k0, 64), (unsigned)n), b64, 0, stream, Qc, n, ld, V0, k0,
+                      ldv0);
+            if (prev_basis) {
+                // [previous components | previous guard Ritz vectors] is the previous solve's Ritz basis up to signs:
+                // orthonormal already, the estimate cycle below re-orthonormalises A times it anyway
+                GS_LAUNCH(topk_copycols_kernel, dim3((unsigned)ceil_div(p - k0, 64), (unsigned)n), b64, 0, stream, Qc,
+                          ws.G, ld, k0, p);
+            } else {
+                double *o = ring_take(ws, nullptr);
+                int rc = orth_fast(ws, Qc, o, n, p, stream);
+                if (rc != GS_OK) return rc;
+                Qc = o;
+            }
+        }
+        // (cold: a uniform random block is well conditioned - no orthonormalisation needed)
+        // estimate phase: single products (robust for lambda_1 / lambda_p up to ~1e6)
+        for (int c = 0; c < est_cycles; ++c) {
+            bool clean = false;
+            double *y = ring_take(ws, &clean), *o = ring_take(ws, nullptr);
+            gemm_f64(n, p, n, A, lda, 1, Qc, ld, 1, y, ld, stream, 1.0, 0.0, none, true, clean);
+            ++mults;
+            int rc = orth_fast(ws, y, o, n, p, stream);
             if (rc != GS_OK) return rc;
             Qc = o;
         }
+        GS_LAUNCH(cheb_setup_kernel, dim3(1), dim3(64), 0, stream, ws.theta + 2 * ws.pp, p, k, 1, stats, coef);
+        return GS_OK;
+    };
+    {
+        const int rca = run_as_graph(ws.graphs, graph_key({1, warm, prev_basis, n, p, k, k0, lda, ldv0, (int64_t)(intptr_t)A,
+                                                           (int64_t)(intptr_t)V0}), stream, segment_a);
+        if (rca != GS_OK) return rca;
     }
-    // (cold: a uniform random block is well conditioned - no orthonormalisation needed)
-    // ---- estimate phase: single products (robust for lambda_1 / lambda_p up to ~1e6) ------------------------
-    const int est_cycles = warm ? 1 : 2;
-    for (int c = 0; c < est_cycles; ++c) {
-        bool clean = false;
-        double *y = ring_take(ws, &clean), *o = ring_take(ws, nullptr);
-        gemm_f64(n, p, n, A, lda, 1, Qc, ld, 1, y, ld, stream, 1.0, 0.0, none, true, clean);
-        ++mults;
-        int rc = orth_fast(ws, y, o, n, p, stream);
-        if (rc != GS_OK) return rc;
-        Qc = o;
-    }
-    hipLaunchKernelGGL(cheb_setup_kernel, dim3(1), dim3(64), 0, stream, ws.theta + 2 * ws.pp, p, k, 1, stats, coef);
 
     // ---- plan ---------------------------------------------------------------------------------------------
     int deg = 1, ncyc = 1;
     double gain = 0.0;
     std::vector<double> host(k + 16);
     const bool reuse_plan = warm && ws.plan_valid && ws.plan_p == p;
-    if (reuse_plan) {
-        deg = ws.plan_deg;
-        ncyc = ws.plan_ncyc;
-        gain = ws.plan_gain;
-    } else {
+    // a cold solve right after a converged cold solve of a same-sized matrix (one fit after another): try that solve's
+    // schedule first - the coefficients still come from THIS matrix's estimates, the residual test still decides
+    const bool reuse_cold = !warm && ws.cold_plan_valid && ws.cold_plan_p == p;
+    auto plan_from_stats = [&](bool *no_gap) -> int {
+        *no_gap = false;
         GS_HIP_CHECK(hipMemcpyAsync(host.data(), stats, sizeof(double) * 8, hipMemcpyDeviceToHost, stream));
         GS_HIP_CHECK(hipStreamSynchronize(stream));
         const double rk = host[1], ndead = host[5], lam1 = host[6], b = host[7];
@@ -933,81 +999,114 @@ int eigh_topk_cheb(SubspaceWorkspace &ws, const double *A, int n, int64_t lda, i
             deg = 1;            // plain products (cheb_setup chose them too): the basis spans the numerical range
             ncyc = 2;
             gain = 0.0;
-        } else {
-            const double x1 = 2.0 * lam1 / b - 1.0, xk = 2.0 * rk / b - 1.0;
-            if (!(xk > 1.02)) {
-                // no usable gap between lambda_k and the guard columns (white-noise like): the filter cannot
-                // separate them - leave it to the full Jacobi solver right away
-                if (iters_out) *iters_out = mults;
-                return GS_OK;
+            return GS_OK;
+        }
+        const double x1 = 2.0 * lam1 / b - 1.0, xk = 2.0 * rk / b - 1.0;
+        if (!(xk > 1.02)) {
+            // no usable gap between lambda_k and the guard columns (white-noise like): the filter cannot
+            // separate them - leave it to the full Jacobi solver right away
+            *no_gap = true;
+            return GS_OK;
+        }
+        // CholeskyQR is invariant under column scaling, and the filtered block is the (roughly Ritz-ordered)
+        // previous basis times diag(T_m(x_i)): amplification up to ~1e11 leaves it orthonormal to rounding
+        // on the spectra tried; 1e9 keeps two digits of margin to the first dead pivot
+        deg = 1;
+        for (int m = 6; m >= 2; --m)
+            if (cheb_T(m, x1) <= 1e9) {
+                deg = m;
+                break;
             }
-            // CholeskyQR is invariant under column scaling, and the filtered block is the (roughly Ritz-ordered)
-            // previous basis times diag(T_m(x_i)): amplification up to ~1e11 leaves it orthonormal to rounding
-            // on the spectra tried; 1e9 keeps two digits of margin to the first dead pivot
-            deg = 1;
-            for (int m = 6; m >= 2; --m)
-                if (cheb_T(m, x1) <= 1e9) {
-                    deg = m;
-                    break;
-                }
-            // the edge estimate is a little low: components just above b grow like T(1.12)
-            gain = cheb_T(deg, xk) / cheb_T(deg, 1.12);
-            if (!(gain > 2.0)) {
-                if (iters_out) *iters_out = mults;
-                return GS_OK;
-            }
-            double resid0 = std::pow(b / rk, (double)est_cycles);
-            if (!(resid0 < 1.0)) resid0 = 1.0;
-            double need = std::log(resid0 / (tol_rel / 3.0)) / std::log(gain);
-            if (!(need > 0.0)) need = 0.0;
-            ncyc = (int)std::ceil(need);
-            if (ncyc < 1) ncyc = 1;
-            if (ncyc > 8) ncyc = 8;
+        // the edge estimate is a little low: components just above b grow like T(1.12)
+        gain = cheb_T(deg, xk) / cheb_T(deg, 1.12);
+        if (!(gain > 2.0)) {
+            *no_gap = true;
+            return GS_OK;
+        }
+        double resid0 = std::pow(b / rk, (double)est_cycles);
+        if (!(resid0 < 1.0)) resid0 = 1.0;
+        double need = std::log(resid0 / (tol_rel / 3.0)) / std::log(gain);
+        if (!(need > 0.0)) need = 0.0;
+        ncyc = (int)std::ceil(need);
+        if (ncyc < 1) ncyc = 1;
+        if (ncyc > 8) ncyc = 8;
+        return GS_OK;
+    };
+    if (reuse_plan) {
+        deg = ws.plan_deg;
+        ncyc = ws.plan_ncyc;
+        gain = ws.plan_gain;
+    } else if (reuse_cold) {
+        deg = ws.cold_plan_deg;
+        ncyc = ws.cold_plan_ncyc;
+        gain = ws.cold_plan_gain;
+    } else {
+        bool no_gap = false;
+        int rcp = plan_from_stats(&no_gap);
+        if (rcp != GS_OK) return rcp;
+        if (no_gap) {
+            if (iters_out) *iters_out = mults;
+            return GS_OK;
         }
     }
 
     for (int attempt = 0; attempt < 3; ++attempt) {
-        // ---- filter cycles -------------------------------------------------------------------------------
-        for (int c = 0; c < ncyc; ++c) {
-            bool clean = false;
-            double *prev = Qc, *cur = ring_take(ws, &clean);
-            GemmEpilogue e1;
-            e1.coef = coef;
-            e1.E1 = Qc;
-            gemm_f64(n, p, n, A, lda, 1, Qc, ld, 1, cur, ld, stream, 1.0, 0.0, e1, true, clean);
-            ++mults;
-            for (int s = 2; s <= deg; ++s) {
-                GemmEpilogue e2;
-                e2.coef = coef + 3;
-                e2.E1 = cur;
-                e2.E2 = prev;
-                double *nxt = ring_take(ws, &clean);
-                gemm_f64(n, p, n, A, lda, 1, cur, ld, 1, nxt, ld, stream, 1.0, 0.0, e2, true, clean);
+        // ---- segment B: filter cycles + Rayleigh-Ritz + residuals (+ the optimistic emit), one graph -------------
+        double *Zb = nullptr;
+        auto segment_b = [&]() -> int {
+            for (int c = 0; c < ncyc; ++c) {
+                bool clean = false;
+                double *prev = Qc, *cur = ring_take(ws, &clean);
+                GemmEpilogue e1;
+                e1.coef = coef;
+                e1.E1 = Qc;
+                gemm_f64(n, p, n, A, lda, 1, Qc, ld, 1, cur, ld, stream, 1.0, 0.0, e1, true, clean);
                 ++mults;
-                prev = cur;
-                cur = nxt;
+                for (int s2 = 2; s2 <= deg; ++s2) {
+                    GemmEpilogue e2;
+                    e2.coef = coef + 3;
+                    e2.E1 = cur;
+                    e2.E2 = prev;
+                    double *nxt = ring_take(ws, &clean);
+                    gemm_f64(n, p, n, A, lda, 1, cur, ld, 1, nxt, ld, stream, 1.0, 0.0, e2, true, clean);
+                    ++mults;
+                    prev = cur;
+                    cur = nxt;
+                }
+                double *o = ring_take(ws, nullptr);
+                int rc = orth_fast(ws, cur, o, n, p, stream);
+                if (rc != GS_OK) return rc;
+                Qc = o;
             }
-            double *o = ring_take(ws, nullptr);
-            int rc = orth_fast(ws, cur, o, n, p, stream);
-            if (rc != GS_OK) return rc;
-            Qc = o;
-        }
-        // (no second CholeskyQR pass: a single pass leaves the filtered basis orthonormal to ~1e-14 - see the degree
-        //  cap above; whatever is left shows up in the residuals below, which are computed from the emitted vectors)
-        // ---- Rayleigh-Ritz -------------------------------------------------------------------------------
-        bool cleany = false, cleanb = false;
-        double *Yb = ring_take(ws, &cleany), *Zb = ring_take(ws, nullptr), *Wb = ring_take(ws, nullptr);
-        double *Bm = hring_take(ws, &cleanb);
-        gemm_f64(n, p, n, A, lda, 1, Qc, ld, 1, Yb, ld, stream, 1.0, 0.0, none, true, cleany);   // Y = A Q
-        gemm_f64(p, p, n, Qc, 1, ld, Yb, ld, 1, Bm, ld, stream, 1.0, 0.0, none, true, cleanb);   // B = Q^T Y
-        {
+            // (no second CholeskyQR pass: a single pass leaves the filtered basis orthonormal to ~1e-14 - see the degree
+            //  cap above; whatever is left shows up in the residuals below, which are computed from the emitted vectors)
+            bool cleany = false, cleanb = false;
+            double *Yb = ring_take(ws, &cleany);
+            Zb = ring_take(ws, nullptr);
+            double *Wb = ring_take(ws, nullptr);
+            double *Bm = hring_take(ws, &cleanb);
+            gemm_f64(n, p, n, A, lda, 1, Qc, ld, 1, Yb, ld, stream, 1.0, 0.0, none, true, cleany);   // Y = A Q
+            gemm_f64(p, p, n, Qc, 1, ld, Yb, ld, 1, Bm, ld, stream, 1.0, 0.0, none, true, cleanb);   // B = Q^T Y
             int rcj = jacobi_small_launch(Bm, ld, p, ws.U, ld, ws.theta, jinfo, stream);
             if (rcj != GS_OK) return rcj;
-        }
-        gemm_f64(n, p, p, Qc, ld, 1, ws.U, ld, 1, Zb, ld, stream, 1.0, 0.0, none, false);    // Z = Q U
-        gemm_f64(n, k, p, Yb, ld, 1, ws.U, ld, 1, Wb, ld, stream, 1.0, 0.0, none, false);    // (A Q) U_k
-        hipLaunchKernelGGL(topk_resid_kernel, dim3((unsigned)k), dim3(256), 0, stream, Wb, Zb, ld, ws.theta, n,
-                           k, ws.theta + ws.pp);
+            gemm_f64(n, p, p, Qc, ld, 1, ws.U, ld, 1, Zb, ld, stream, 1.0, 0.0, none, false);    // Z = Q U
+            gemm_f64(n, k, p, Yb, ld, 1, ws.U, ld, 1, Wb, ld, stream, 1.0, 0.0, none, false);    // (A Q) U_k
+            GS_LAUNCH(topk_resid_kernel, dim3((unsigned)k), dim3(256), 0, stream, Wb, Zb, ld, ws.theta, n, k,
+                      ws.theta + ws.pp);
+            // optimistic: the Ritz pairs leave for the caller's arrays before the host has looked at the residuals -
+            // a failed attempt continues from Zb (not from Vk), a failed solve is redone by the caller's fall-back
+            GS_LAUNCH(topk_emit_kernel, dim3((unsigned)ceil_div(n, 256), (unsigned)k), dim3(256), 0, stream, Zb, ld,
+                      ws.theta, n, k, Vk, ldv, lam);
+            if (ws.epilogue) {
+                ws.epilogue(stream);
+                ws.epilogue_done = true;
+            }
+            return GS_OK;
+        };
+        const int rcb = run_as_graph(ws.graphs, graph_key({2, deg, ncyc, n, p, k, ws.ring_next, ws.h_next, lda, ldv,
+                                                           (int64_t)(intptr_t)A, (int64_t)(intptr_t)Vk,
+                                                           (int64_t)(intptr_t)Qc, ws.epilogue ? 1 : 0}), stream, segment_b);
+        if (rcb != GS_OK) return rcb;
         GS_HIP_CHECK(hipMemcpyAsync(host.data(), ws.theta + ws.pp, sizeof(double) * k, hipMemcpyDeviceToHost, stream));
         GS_HIP_CHECK(hipMemcpyAsync(host.data() + k, ws.theta, sizeof(double), hipMemcpyDeviceToHost, stream));
         int jhost[2] = {0, 0};
@@ -1024,28 +1123,34 @@ int eigh_topk_cheb(SubspaceWorkspace &ws, const double *A, int n, int64_t lda, i
         const bool ok = finite && th1 > 0.0 && jhost[1] == 0 && worst <= tol2 * th1 * th1;
         if (ok) {
             *converged = 1;
-            hipLaunchKernelGGL(topk_emit_kernel, dim3((unsigned)ceil_div(n, 256), (unsigned)k), dim3(256), 0, stream,
-                               Zb, ld, ws.theta, n, k, Vk, ldv, lam);
-            GS_HIP_CHECK(hipGetLastError());
             if (ws.reuse_guards) {
                 GS_HIP_CHECK(hipMemcpyAsync(ws.G, Zb, sizeof(double) * (size_t)n * ld, hipMemcpyDeviceToDevice, stream));
                 ws.guards_valid = true;
                 ws.guards_n = n;
                 ws.guards_p = p;
             }
+            // remember the schedule: consecutive blocks of the incremental PCA (warm) and consecutive fits of
+            // same-shaped data (cold) have near-identical spectra.  A wide margin (> 3 digits in the residual) tries
+            // one cycle fewer next time.
+            const bool wide = worst <= 1e-6 * tol2 * th1 * th1;
+            const int next_ncyc = (wide && ncyc > 1 && attempt == 0) ? ncyc - 1 : ncyc;
             if (warm) {
-                // remember the schedule: consecutive blocks of the incremental PCA have near-identical spectra.
-                // A wide margin (> 3 digits in the residual) tries one cycle fewer next time.
-                const bool wide = worst <= 1e-6 * tol2 * th1 * th1;
                 ws.plan_valid = true;
                 ws.plan_p = p;
                 ws.plan_deg = deg;
                 ws.plan_gain = gain;
                 ws.plan_ncyc = (wide && ncyc > 0 && attempt == 0) ? ncyc - 1 : ncyc;
+            } else if (attempt == 0) {
+                ws.cold_plan_valid = true;
+                ws.cold_plan_p = p;
+                ws.cold_plan_deg = deg;
+                ws.cold_plan_gain = gain;
+                ws.cold_plan_ncyc = reuse_cold ? ncyc : next_ncyc;    // (a reused schedule is kept as it is: no drift)
             }
             break;
         }
         ws.plan_valid = false;
+        ws.cold_plan_valid = false;
         if (!finite || !(th1 > 0.0) || attempt == 2) break;
         // not there yet: continue from the Ritz basis.  Cycles still needed from the measured residual.
         Qc = Zb;
@@ -1056,12 +1161,7 @@ int eigh_topk_cheb(SubspaceWorkspace &ws, const double *A, int n, int64_t lda, i
             if (extra < 1) extra = 1;
             if (extra > 6) extra = 6;
         }
-        if (reuse_plan && attempt == 0) {
-            // the remembered schedule was too short (coefficients are still valid: same edge estimate)
-            ncyc = extra;
-        } else {
-            ncyc = extra;
-        }
+        ncyc = extra;
     }
     if (iters_out) *iters_out = mults;
     return GS_OK;

@@ -300,64 +300,121 @@ class IPCAEstimator:
         return t.components_, stdev, t.explained_variance_ratio_
 
 
+def _column_moments(lib, Xd):
+    """``(sum [d], sumsq [d])`` float64 host arrays of the rows of ``Xd`` - one pass of ``gs_column_moments``."""
+    torch = _torch()
+    n, d = Xd.shape
+    acc = torch.zeros((2, d), dtype=torch.float64, device=Xd.device)
+    _lib.check(lib.gs_column_moments(C.c_void_p(Xd.data_ptr()), n, Xd.stride(0), d, C.c_void_p(0),
+                                     C.c_void_p(acc[0].data_ptr()), C.c_void_p(acc[1].data_ptr()),
+                                     _lib.current_stream_ptr()))
+    acc = acc.cpu().numpy()
+    return acc[0], acc[1]
+
+
 class _WholeMatrixPCA:
-    """Shared body of the two non-batch PCA estimators: ONE pass of the Gram kernel over the whole
-    ``[N, d]`` matrix (EXACT-mode handle, fed in launches of <= 2^20 rows), one top-k eigensolve, then the
-    reference's post-processing (estimators.py:96-118 / :137-157): projected standard deviations (ddof = 0),
+    """Shared body of the two non-batch PCA estimators (reference estimators.py:84-160): fit on the whole ``[N, d]``
+    matrix, then the reference's post-processing (:96-118 / :140-157): projected standard deviations (ddof = 0),
     components sorted by them, ``total_var = X.var(axis=0).sum()``, ``mean_ = X.mean(axis=0)``.
 
-    ``centre=True``  -> eigenvectors of the centred scatter  (sklearn ``PCA(svd_solver='full')``)
-    ``centre=False`` -> eigenvectors of ``X^T X``            (fbpca ``pca(raw=True)``)
-    The projected variance of a unit vector v is ``v^T S v / N`` with S the centred scatter in both cases, so no
-    second pass over X is needed: it is evaluated from the accumulated statistics in float64.
+    Components come from the subclass's ``_components(Xd)`` (device rows in, ``[k, d]`` float32 device tensor out);
+    the post-processing is two more passes on the device: ``gs_column_moments`` (per-feature sum / sum of squares)
+    and ``X @ components^T`` on the f32 MFMA (``gs_linear_forward``) followed by the ``[N, k]`` column statistics.
     """
 
+    GRAM_SIDE_MAX_FEATURES = 8192
     ROWS_PER_LAUNCH = 1 << 20
 
-    def __init__(self, n_components, centre, device=None):
+    def __init__(self, n_components, device=None):
         self.n_components = int(n_components)
         self.batch_support = False
-        self._centre = centre
         self._device = device
+        self._lib = _lib.load()
         self.transformer = SimpleNamespace()
         self.stdev = np.zeros((self.n_components,))
         self.total_var = 0.0
 
+    # -- building blocks shared by the subclasses ------------------------------------------------------------
+    def _device_rows(self, X):
+        torch = _torch()
+        if not torch.cuda.is_available():
+            raise RuntimeError("ganspace_amd needs a HIP device (torch.cuda.is_available() is False)")
+        helper = _DeviceIncrementalPCA(self.n_components, _lib.GS_MODE_EXACT, self._device)
+        Xd = helper._as_device_rows(X).contiguous()
+        self._device = Xd.device
+        return Xd
+
+    def _exact_components(self, Xd, centre):
+        """Leading eigenvectors of the centred scatter (``centre``: sklearn ``PCA(svd_solver='full')``) or of
+        ``X^T X`` (what ``fbpca.pca(raw=True)`` returns when it falls back to a dense SVD).  d <= 8192: one pass of the
+        Gram kernel + one top-k eigensolve; wider: the small side of the matrix (rows x rows), one block."""
+        torch = _torch()
+        n, d = Xd.shape
+        k = self.n_components
+        if d <= self.GRAM_SIDE_MAX_FEATURES:
+            inc = _DeviceIncrementalPCA(k, _lib.GS_MODE_EXACT, self._device)
+            for lo in range(0, n, self.ROWS_PER_LAUNCH):
+                inc.partial_fit(Xd[lo:lo + self.ROWS_PER_LAUNCH])
+            if centre:
+                comp = torch.from_numpy(np.array(inc.components_, dtype=np.float32))
+            else:
+                # uncentred second moment  X^T X = S + n mean mean^T  -> same eigensolver through a second handle
+                state = inc.export_state().cpu().numpy()
+                mean, S = state[1:1 + d], state[1 + d:].reshape(d, d)
+                raw = _DeviceIncrementalPCA(k, _lib.GS_MODE_EXACT, self._device)
+                raw._ensure(d)
+                st = state.copy()
+                st[1 + d:] = (S + n * np.outer(mean, mean)).ravel()
+                st[1:1 + d] = 0.0
+                raw.import_state(torch.from_numpy(st).to(Xd.device), d)
+                comp = torch.from_numpy(np.array(raw.components_, dtype=np.float32))
+                raw.close()
+            inc.close()
+            return comp.to(Xd.device)
+        if not centre:
+            raise RuntimeError(
+                f"fbpca's dense fall-back (l >= rows / 1.25 or l >= feat_dim / 1.25) on feat_dim = {d} > "
+                f"{self.GRAM_SIDE_MAX_FEATURES} is not available on the device; use a larger sample")
+        # feat_dim >> rows: exact PCA of the block from the small side (T = Xc Xc^T is rows x rows) - the first block of
+        # the small-side recurrence IS the plain centred PCA of that block
+        inc = _DeviceIncrementalPCA(k, _lib.GS_MODE_SMALLSIDE, self._device)
+        try:
+            inc.partial_fit(Xd)
+        except _lib.GanspaceHipError as e:
+            if e.code == _lib.GS_ENOTIMPL:
+                raise RuntimeError(
+                    f"whole-matrix PCA of a [{n}, {d}] matrix: feat_dim > {self.GRAM_SIDE_MAX_FEATURES} is solved from "
+                    "the rows x rows side, which holds n_components + rows + 1 <= 32768; use the batch estimator "
+                    "'ipca' (small-side recurrence, any number of rows) for more samples") from e
+            raise
+        comp = torch.from_numpy(np.array(inc.components_, dtype=np.float32)).to(Xd.device)
+        inc.close()
+        return comp
+
+    def _components(self, Xd):
+        raise NotImplementedError
+
     def fit(self, X):
         torch = _torch()
-        inc = _DeviceIncrementalPCA(self.n_components, _lib.GS_MODE_EXACT, self._device)
-        Xd = inc._as_device_rows(X)
+        Xd = self._device_rows(X)
         n, d = Xd.shape
-        if d > inc.GRAM_SIDE_MAX_FEATURES:
-            raise RuntimeError(
-                f"whole-matrix PCA on the device handles feat_dim <= {inc.GRAM_SIDE_MAX_FEATURES} (got {d}); "
-                "use the batch estimator 'ipca', which switches to the small-side recurrence for wide layers")
         k = self.n_components
-        for lo in range(0, n, self.ROWS_PER_LAUNCH):
-            inc.partial_fit(Xd[lo:lo + self.ROWS_PER_LAUNCH])
-        state = inc.export_state().cpu().numpy()            # [n | mean | centred scatter], float64
-        mean, S = state[1:1 + d], state[1 + d:].reshape(d, d)
-        if self._centre:
-            comp = np.array(inc.components_, dtype=np.float64)
-        else:
-            # uncentred second moment  X^T X = S + n mean mean^T  -> same eigensolver through a second handle
-            raw = _DeviceIncrementalPCA(k, _lib.GS_MODE_EXACT, self._device)
-            raw._ensure(d)
-            st = state.copy()
-            st[1 + d:] = (S + n * np.outer(mean, mean)).ravel()
-            st[1:1 + d] = 0.0
-            raw.import_state(torch.from_numpy(st).to(Xd.device), d)
-            comp = np.array(raw.components_, dtype=np.float64)
-            raw.close()
-        inc.close()
-        var = np.einsum("kd,de,ke->k", comp, S, comp) / n   # np.dot(components_, X.T).std(axis=1) ** 2
-        self.stdev = np.sqrt(np.maximum(var, 0.0))
-        order = np.argsort(self.stdev)[::-1]                   # estimators.py:103-106
+        if d % 4 != 0:
+            raise RuntimeError(f"whole-matrix estimators need feat_dim % 4 == 0 on the device (got {d})")
+        comp = self._components(Xd).contiguous()                     # [k, d] float32 on the device
+        s1, s2 = _column_moments(self._lib, Xd)
+        mean = s1 / n
+        self.total_var = float(np.sum(s2 / n - mean * mean))        # X.var(axis=0).sum()
+        proj = torch.empty((n, k), dtype=torch.float32, device=Xd.device)
+        _lib.check(self._lib.gs_linear_forward(C.c_void_p(Xd.data_ptr()), C.c_void_p(comp.data_ptr()), C.c_void_p(0),
+                                               C.c_void_p(proj.data_ptr()), n, d, k, _lib.current_stream_ptr()))
+        self.stdev = proj.double().std(dim=0, unbiased=False).cpu().numpy()   # np.dot(components_, X.T).std(axis=1)
+        order = np.argsort(self.stdev)[::-1]                         # estimators.py:103-106
         self.stdev = self.stdev[order]
-        self.transformer.components_ = comp[order].astype(np.float32)
-        self.total_var = float(np.trace(S) / n)                # X.var(axis=0).sum()
+        self.transformer.components_ = comp.cpu().numpy()[order].astype(np.float32)
         self.transformer.mean_ = mean[None, :].astype(np.float32)
-        gram = self.transformer.components_.astype(np.float64) @ self.transformer.components_.astype(np.float64).T
+        c64 = self.transformer.components_.astype(np.float64)
+        gram = c64 @ c64.T
         off = np.abs(gram - np.diag(np.diag(gram))).max() if k > 1 else 0.0
         if off > 1e-4:
             print("PCA components not orthogonal, max dot", off)
@@ -368,26 +425,52 @@ class _WholeMatrixPCA:
 
 
 class PCAEstimator(_WholeMatrixPCA):
-    """Drop-in for the reference ``PCAEstimator`` (estimators.py:84-118)."""
+    """Drop-in for the reference ``PCAEstimator`` (estimators.py:84-118): sklearn ``PCA(k, svd_solver='full')``."""
 
     def __init__(self, n_components, device=None):
-        super().__init__(n_components, centre=True, device=device)
+        super().__init__(n_components, device=device)
         self.solver = "full"
 
     def get_param_str(self):
         return f"pca-{self.solver}_c{self.n_components}"
 
+    def _components(self, Xd):
+        return self._exact_components(Xd, centre=True)
+
 
 class FacebookPCAEstimator(_WholeMatrixPCA):
-    """Drop-in for the reference ``FacebookPCAEstimator`` (estimators.py:124-160)."""
+    """Drop-in for the reference ``FacebookPCAEstimator`` (estimators.py:124-160):
+    ``fbpca.pca(X, k, n_iter=2, raw=True, l=2k)`` - the randomized range finder with two normalised power iterations -
+    as ``gs_randomized_pca`` (csrc/gs_rangefinder.hip).  The test matrix is drawn here from NumPy's global stream with
+    the very call fbpca makes (``np.random.uniform(-1, 1, (n, l))`` for rows >= feat_dim, ``(l, m)`` otherwise), so a
+    given RNG state gives the matrix the reference would use.  Where fbpca falls back to a dense SVD
+    (``l >= rows / 1.25 or l >= feat_dim / 1.25``) the exact solver runs."""
 
     def __init__(self, n_components, device=None):
-        super().__init__(n_components, centre=False, device=device)
+        super().__init__(n_components, device=device)
         self.n_iter = 2
         self.l = 2 * self.n_components
 
     def get_param_str(self):
         return "fbpca_c{}_it{}_l{}".format(self.n_components, self.n_iter, self.l)
+
+    def _components(self, Xd):
+        torch = _torch()
+        n, d = Xd.shape
+        k, l = self.n_components, self.l
+        if l >= n / 1.25 or l >= d / 1.25:
+            return self._exact_components(Xd, centre=False)
+        if l > 256:
+            raise RuntimeError(f"fbpca on the device handles l = 2 * n_components <= 256 (got {l})")
+        omega = np.random.uniform(low=-1.0, high=1.0, size=(d, l) if n >= d else (l, n))
+        om = torch.from_numpy(omega).to(Xd.device)
+        comp = torch.empty((k, d), dtype=torch.float32, device=Xd.device)
+        sv = torch.empty(k, dtype=torch.float64, device=Xd.device)
+        _lib.check(self._lib.gs_randomized_pca(C.c_void_p(Xd.data_ptr()), n, d, k, l, self.n_iter,
+                                               C.c_void_p(om.data_ptr()), C.c_void_p(comp.data_ptr()),
+                                               C.c_void_p(sv.data_ptr()), _lib.current_stream_ptr()))
+        self.singular_values_ = sv.cpu().numpy()
+        return comp
 
 
 def get_estimator(name, n_components, alpha=1.0):

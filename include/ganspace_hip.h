@@ -207,6 +207,24 @@ int gs_eigh_topk(const double *A, int n, int k, const double *V0, int k0, double
 int gs_cholqr(const double *Y, int n, int p, double *Q, double *rdiag, void *stream);
 int gs_jacobi_small(const double *B, int p, double *U, double *theta, int *info_host, void *stream);
 
+/* Replaces FacebookPCAEstimator.fit's `fbpca.pca(X, k, n_iter=2, raw=True, l=2k)` (estimators.py:137; fbpca 1.0's
+ * randomized range finder with normalised power iterations - Halko / Martinsson / Tropp) for a whole sample matrix
+ * A [rows, d] float32, contiguous, on the device: 2 (n_iter + 1) passes over A (Y = A Q on the f32 MFMA; Z = A^T Y by
+ * a row-contraction kernel with float64 carry), float64 CholeskyQR of the d x l bases, Rayleigh-Ritz from the l x l
+ * side.  `omega`: the test matrix fbpca would draw, float64 on the device - [d, l] row-major when rows >= d, [l, rows]
+ * otherwise (np.random.uniform(-1, 1, size)).  Outputs (device): components [k, d] float32 unit rows (sign arbitrary,
+ * as LAPACK's), singular_values [k] float64.  Needs d % 4 == 0, l <= 256 and l < min(rows, d) / 1.25 (beyond that
+ * fbpca itself falls back to a dense SVD: GS_ENOTIMPL tells the caller to use the exact solver).  Synchronises.      */
+int gs_randomized_pca(const float *A, int64_t rows, int64_t d, int k, int l, int n_iter, const double *omega,
+                      float *components, double *singular_values, void *stream);
+
+/* Per-feature first and second moments of X [rows, ld] float32 in ONE pass (X.mean(axis=0) / X.var(axis=0) of
+ * estimators.py:96-97,141-142,116,156; the per-block mean / variance update of sklearn extmath.py:1064-1187):
+ * sum[j] += sum_r (x_rj - shift_j), sumsq[j] += sum_r (x_rj - shift_j)^2, float64 on the device, accumulated (zero them
+ * for a fresh sum); shift (float64 [d]) may be NULL.  Needs d % 4 == 0, ld % 4 == 0, 16-byte aligned rows.           */
+int gs_column_moments(const float *X, int64_t rows, int64_t ld, int64_t d, const double *shift, double *sum,
+                      double *sumsq, void *stream);
+
 /* ---- host-side latent stream -----------------------------------------------------------------------
  * Replaces the per-batch RNG of StyleGAN2.sample_latent (models/wrappers.py:167-174:
  * `np.random.RandomState(seed).standard_normal(512 * n).reshape(n, 512)` -> float32), bit for bit: MT19937 with NumPy's

@@ -84,7 +84,51 @@ def test_sharded_exact_compute_equals_single_process(tmp_path, case, k):
     _compare(one, two, k, 1e-6)
 
 
-@pytest.mark.parametrize("case,k", [("w_ipca", 20), ("wide_ipca", 10)])
+def test_sharded_faithful_wide_layer_equals_in_process_merge_of_the_same_shards(tmp_path):
+    """``--est=ipca`` on a wide layer (BigGAN gen_z, d = 32 768: small-side recurrence per rank) with two ranks against
+    the same computation done in THIS process through the library API: presample the one z stream, run rank 0's and
+    rank 1's block ranges through two estimators, export, merge.  BigGAN's gen_z activation is affine in z with a flat
+    leading spectrum, so a sequential fit and a merged fit legitimately differ (truncation order); the two-rank file
+    must equal the in-process merge - plumbing (shard plan, per-rank z batches, all-gather, rank-0 write) is what this
+    pins, the merge arithmetic itself is pinned against the oracle in tests/test_gpu_merge.py."""
+    import torch
+    from ganspace_amd import decomposition as dec
+    from ganspace_amd.config import Config
+    from ganspace_amd.estimators import get_estimator
+    from ganspace_amd.wrappers import get_instrumented_model
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import dist_worker
+    two = _run_case("wide_ipca", 2, tmp_path / "two")
+    kw = dict(dist_worker.CASES["wide_ipca"], output_class=250)
+    cfg = Config(**kw)
+    dev = torch.device("cuda", 0)
+    inst = get_instrumented_model(cfg.model, cfg.output_class, cfg.layer, dev)
+    model, layer, k = inst.model, cfg.layer, cfg.components
+    inst.retain_layer(layer)
+    input_shape = model.get_latent_shape()
+    plan = dec._Plan.make(cfg.n, cfg.batch_size, k)
+    torch.manual_seed(dec.SEED_SAMPLING)
+    np.random.seed(dec.SEED_SAMPLING)
+    latents, _ = dec._presample(model, plan, input_shape, dev)
+    states, d = [], 32768
+    for r in range(2):
+        est = get_estimator("ipca", k, 1.0)
+        dec._fit_blocks(est, inst, latents, plan, layer, d, False, dev, plan.shard_blocks(r, 2), 0)
+        states.append(est.transformer.export_lowrank())
+    merged = get_estimator("ipca", k, 1.0)
+    merged.transformer._ensure(d)
+    merged.transformer.merge_lowrank(torch.stack(states))
+    comp, stdev, ratio = merged.get_components()
+    c = O.signed_cosines(two["act_comp"].reshape(k, -1), comp)
+    assert c.min() > 1 - 1e-6, c
+    np.testing.assert_allclose(two["act_stdev"], stdev, rtol=1e-6)
+    np.testing.assert_allclose(two["var_ratio"], ratio, rtol=1e-6)
+    np.testing.assert_allclose(two["act_mean"].ravel(), merged.transformer.mean_, atol=1e-6)
+    assert two["lat_comp"].shape == (k, 1, 128)            # the sharded regression ran (Z-space layer)
+    inst.close()
+
+
+@pytest.mark.parametrize("case,k", [("w_ipca", 20)])
 def test_sharded_faithful_compute_matches_single_process_on_leading_components(tmp_path, case, k):
     """``--est=ipca`` (the reference's default, sequential in the blocks): each rank runs the sklearn-faithful
     recurrence on its share, the ranks all-gather ``(n, mean, m2, S, V)`` and merge by one more step of the same

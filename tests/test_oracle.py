@@ -193,3 +193,28 @@ def test_smallside_torch_oracle_matches_sklearn_recurrence_oracle():
     np.testing.assert_allclose(a.var_, b.var_, rtol=1e-10)
     np.testing.assert_allclose(a.explained_variance_ratio_, b.explained_variance_ratio_, rtol=1e-10)
     assert a.n_samples_seen_ == b.n_samples_seen_ == 720
+
+
+@pytest.mark.parametrize("m,n", [(3000, 200), (150, 900), (60, 40)])
+def test_fbpca_port_recovers_leading_singular_triplets(m, n):
+    """oracle/fbpca_port.py (restatement of fbpca.pca, raw=True; the package itself is absent - parity unpinned by the
+    reference): on a matrix with a decaying spectrum the n_iter = 2, l = 2k range finder reproduces the leading
+    singular values / right singular vectors of the dense SVD; both branches (m >= n, m < n) and the dense fall-back."""
+    from oracle import fbpca_port
+    rs = np.random.RandomState(4)
+    k = 8
+    r = min(m, n)
+    U0 = np.linalg.qr(rs.standard_normal((m, r)))[0]
+    V0 = np.linalg.qr(rs.standard_normal((n, r)))[0]
+    sv = 10.0 * 1.35 ** -np.arange(r)
+    A = (U0 * sv) @ V0.T
+    np.random.seed(11)
+    U, s, Va = fbpca_port.pca(A, k=k, raw=True, n_iter=2, l=2 * k)
+    assert U.shape == (m, k) and Va.shape == (k, n)
+    np.testing.assert_allclose(s, sv[:k], rtol=1e-6)
+    cos = np.abs(np.sum(Va * V0[:, :k].T, axis=1))
+    assert cos.min() > 1 - 1e-8
+    # deterministic in the global stream, like fbpca
+    np.random.seed(11)
+    _, s2, Va2 = fbpca_port.pca(A, k=k, raw=True, n_iter=2, l=2 * k)
+    np.testing.assert_array_equal(Va, Va2)

@@ -14,7 +14,7 @@ dev = torch.device("cuda", 0)
 nb = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 mode = sys.argv[3] if len(sys.argv) > 3 else "both"
-blocks, _, _ = bench.make_blocks(-(-nb // 5) * 5, dev)
+blocks = bench.make_blocks(-(-nb // 5) * 5, dev)[0]
 blocks = blocks[:nb]
 if mode in ("exact", "both"):
     for rep in range(reps):
