@@ -370,11 +370,12 @@ def main():
                                              "ms_per_block": round(tf_ / n_blocks * 1e3, 4), "blocks": n_blocks,
                                              "job_s_of_3_runs": [round(r, 5) for r in runs]}
 
-        # ---- opt-in split-bf16 contraction modes (precision="bf16x6" / "bf16x3"; the headline stays exact f32):
+        # ---- opt-in bf16 contraction modes (precision="bf16x6" / "bf16x3": split, float32-class / 2^-16; "bf16": one
+        #      plane, the HBM-bound single-pass contraction of SURVEY.md 8d; the headline stays exact f32):
         #      same job, same timed region; cos-sim against the same sklearn reference sample ------------------
         if args.mode == "exact":
             split = {}
-            for prec, nprod in (("bf16x6", 6), ("bf16x3", 3)):
+            for prec, nprod in (("bf16x6", 6), ("bf16x3", 3), ("bf16", 1)):
                 e = IPCAEstimator(K_COMP, "exact", precision=prec)
                 for b in blocks[:nb]:
                     e.fit_partial(b)
@@ -389,9 +390,9 @@ def main():
                 run(e2, K)
                 torch.cuda.synchronize()
                 job = time.perf_counter() - t0
-                # the launch of one step: bf16x3 takes the 50 000 rows in one "wide" launch (pairs of workgroups hold
-                # the whole upper triangle); bf16x6 launches are capped at 24 576 rows (no float64 carry)
-                us_p, rt = gram_kernel_us(lib, _lib, e2, step_views[0])
+                # the launch the resident path issues: 131 072 rows in one "wide" launch for bf16x3 / bf16 (pairs of
+                # workgroups hold the whole upper triangle); bf16x6 launches are capped at 24 576 rows (no float64 carry)
+                us_p, rt = gram_kernel_us(lib, _lib, e2, RESIDENT_ROWS[:LAUNCH_ROWS])
                 mfma_tf = nprod * rt * D * (D + 1) / (us_p * 1e-6) / 1e12
                 gbs = rt * D * 4 / (us_p * 1e-6) / 1e9
                 split[prec] = {"samples_per_s": round(n_blocks * NB / job, 1), "gram_launch_us": round(us_p, 2),

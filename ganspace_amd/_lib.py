@@ -13,8 +13,8 @@ from . import _build
 
 GS_OK, GS_EINVAL, GS_EHIP, GS_ENOMEM, GS_ESTATE, GS_ENOTIMPL, GS_ENOCONV = 0, -1, -2, -3, -4, -5, -6
 GS_MODE_EXACT, GS_MODE_FAITHFUL, GS_MODE_SMALLSIDE = 0, 1, 2
-GS_PREC_F32, GS_PREC_BF16X3, GS_PREC_BF16X6 = 0, 1, 2
-PRECISIONS = {"f32": GS_PREC_F32, "bf16x3": GS_PREC_BF16X3, "bf16x6": GS_PREC_BF16X6}
+GS_PREC_F32, GS_PREC_BF16X3, GS_PREC_BF16X6, GS_PREC_BF16 = 0, 1, 2, 3
+PRECISIONS = {"f32": GS_PREC_F32, "bf16x3": GS_PREC_BF16X3, "bf16x6": GS_PREC_BF16X6, "bf16": GS_PREC_BF16}
 
 _vp, _i64, _int, _f32 = C.c_void_p, C.c_int64, C.c_int, C.c_float
 

@@ -581,7 +581,8 @@ static GramGeom gram_geometry(const GramWorkspace &ws, int64_t n, bool aligned16
     // (launches below ~20 000 rows - the 10 000-row block of the faithful loop - stay with the tiled kernel: the 71 MB of
     //  slabs of 128 pairs, or the long chunks of fewer pairs, cost more than its panel re-reads: 28 vs 21 us)
     static const bool no_wide_f32 = getenv("GS_GRAM_NO_WIDE_F32") != nullptr;
-    const bool wide_prec = ws.precision == GS_PREC_BF16X3 || (ws.precision == GS_PREC_F32 && !no_wide_f32);
+    const bool wide_prec = ws.precision == GS_PREC_BF16X3 || ws.precision == GS_PREC_BF16 ||
+                           (ws.precision == GS_PREC_F32 && !no_wide_f32);
     if (wide_prec && ws.d == 512 && aligned16 && !no_wide && n >= 20000) {
         // pairs of workgroups, each pair one chunk of <= 1024 rows (float32 accumulation span) and one 0.56 MB slab
         // (upper triangle): more pairs shorten the matrix work per pair (~108 clk per row), fewer pairs write and
@@ -598,7 +599,7 @@ static GramGeom gram_geometry(const GramWorkspace &ws, int64_t n, bool aligned16
             if (ceil_div(units, (int64_t)np) * kRowUnit > kMaxChunkRows) continue;
             // matrix work per row and pair: 136 sub-tiles x 3 bf16 MFMAs x 32 clk (resp. x 1/2 f32 MFMA x 64 clk)
             // over 8 SIMDs, 18 / 17 imbalance
-            const double clk_row = ws.precision == GS_PREC_F32 ? 576.0 : 108.0;
+            const double clk_row = ws.precision == GS_PREC_F32 ? 576.0 : ws.precision == GS_PREC_BF16 ? 60.0 : 108.0;
             const double t = (double)n / np * clk_row / 2.4e9 + 2.0 * np * 0.557e6 / 5e12;
             if (t < best_t) {
                 best_t = t;
@@ -699,7 +700,7 @@ static void launch_partial(const GramWorkspace &ws, const GramGeom &g, int buf, 
         if (nfold < 8 || nfold > 64) nfold = 16;
         // the two-plane split kernel needs 80 KiB of LDS: two workgroups fit a CU, so fold workgroups can sit next
         // to compute workgroups - its launches are short enough for a 16-workgroup fold to become the critical path
-        if (ws.precision == GS_PREC_BF16X3) nfold = 64;
+        if (ws.precision == GS_PREC_BF16X3 || ws.precision == GS_PREC_BF16) nfold = 64;
     }
     static unsigned long long *trace_buf = []() -> unsigned long long * {
         if (!getenv("GS_GRAM_TRACE")) return nullptr;
@@ -727,7 +728,7 @@ static void launch_partial(const GramWorkspace &ws, const GramGeom &g, int buf, 
             (void)launch_gram_f32_wide(g.grid, fold.P != nullptr ? 256 : 0, Xb, n, ld, shift, ws.partial[buf],
                                        ws.colsum_partial[buf], g.nchunks, g.plan, fj, stream);
         else
-            (void)launch_gram_bf16_wide(g.grid, fold.P != nullptr ? 256 : 0, Xb, n, ld, shift, ws.partial[buf],
+            (void)launch_gram_bf16_wide(ws.precision, g.grid, fold.P != nullptr ? 256 : 0, Xb, n, ld, shift, ws.partial[buf],
                                         ws.colsum_partial[buf], g.nchunks, g.plan, fj, stream);
         return;
     }

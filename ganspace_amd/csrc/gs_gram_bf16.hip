@@ -82,7 +82,7 @@ __device__ __forceinline__ void gram_bf16_body(const float *__restrict__ X, int6
     auto stamp = [&](int) {};
 #endif
     stamp(0);
-    constexpr int NPL = (NPROD == 3) ? 2 : 3;
+    constexpr int NPL = (NPROD == 1) ? 1 : (NPROD == 3) ? 2 : 3;
     constexpr int kStageBytes = NPL * 2 * kPanelBytes;       // [plane][panel A|B][128 cols][80 B]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wi = wave >> 1, wj = wave & 1;
@@ -188,8 +188,8 @@ __device__ __forceinline__ void gram_bf16_body(const float *__restrict__ X, int6
         constexpr int PA3[3] = {1, 0, 0}, PB3[3] = {0, 1, 0};
 #pragma unroll
         for (int t = 0; t < NPROD; ++t) {
-            const int pa = (NPROD == 3) ? PA3[t % 3] : PA6[t];
-            const int pb = (NPROD == 3) ? PB3[t % 3] : PB6[t];
+            const int pa = (NPROD == 1) ? 0 : (NPROD == 3) ? PA3[t % 3] : PA6[t];
+            const int pb = (NPROD == 1) ? 0 : (NPROD == 3) ? PB3[t % 3] : PB6[t];
 #pragma unroll
             for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -386,7 +386,7 @@ __device__ __forceinline__ void split4(const float (&v)[4], uint2 (&planes)[2]) 
 // XOP: rectangle waves - fragment index (0-3 = A block, 4-5 = B block) whose diagonal sub-tile this wave computes on
 // top of its eight (-1: none).  SKIP: diagonal waves - index (a <= b enumeration) of the sub-tile left to a rectangle
 // wave.  With that every SIMD carries 17 sub-tiles (see gs_gram_wide.hip).
-template <bool DIAGROLE, int XOP, int SKIP>
+template <int NPROD, bool DIAGROLE, int XOP, int SKIP>
 __device__ __forceinline__ void gram_wide_body(const float *__restrict__ X, int64_t ld, const float *__restrict__ shift,
                                                float *__restrict__ P, float *__restrict__ CS, int chunk, int64_t r0,
                                                int64_t r1, int half, int wave, unsigned char *lds, int ablate) {
@@ -443,27 +443,36 @@ __device__ __forceinline__ void gram_wide_body(const float *__restrict__ X, int6
                 v[i] = (x - s0) * m[i];
                 cs[j] += v[i];
             }
-            uint2 pl[2];
-            split4(v, pl);
-            *reinterpret_cast<uint2 *>(base + j * (132 * 16)) = pl[0];
-            *reinterpret_cast<uint2 *>(base + j * (132 * 16) + kWPlaneBytes) = pl[1];
+            if (NPROD == 1) {
+                // plain bf16: ONE plane, round-to-nearest-even (v_cvt_pk_bf16_f32)
+                const f32x2 p0 = {v[0], v[1]}, p1 = {v[2], v[3]};
+                *reinterpret_cast<uint2 *>(base + j * (132 * 16)) =
+                    make_uint2(__builtin_bit_cast(unsigned, __builtin_convertvector(p0, bf16x2)),
+                               __builtin_bit_cast(unsigned, __builtin_convertvector(p1, bf16x2)));
+            } else {
+                uint2 pl[2];
+                split4(v, pl);
+                *reinterpret_cast<uint2 *>(base + j * (132 * 16)) = pl[0];
+                *reinterpret_cast<uint2 *>(base + j * (132 * 16) + kWPlaneBytes) = pl[1];
+            }
         }
     };
+    constexpr int NPLW = (NPROD == 1) ? 1 : 2;
     const int fragoff = (lane >> 5) * kWKgBytes + ((lane & 3) * 132 + ((lane & 31) >> 2)) * 16;
     auto frag = [&](int buf, int pl, int blk) {
         return *reinterpret_cast<const bf16x8 *>(lds + buf * kWStageBytes + pl * kWPlaneBytes + blk * 128 + fragoff);
     };
-    // plane 0 = leading bf16 term, 1 = second: mid*hi, hi*mid, hi*hi (smallest products first)
-    constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0};
+    // plane 0 = leading bf16 term, 1 = second: mid*hi, hi*mid, hi*hi (smallest products first); plain bf16: hi*hi only
+    constexpr int PA[3] = {NPROD == 1 ? 0 : 1, 0, 0}, PB[3] = {0, NPROD == 1 ? 0 : 1, 0};
     auto mma = [&](int buf) {
         if (DIAGROLE) {
-            bf16x8 F[2][4];
+            bf16x8 F[NPLW][4];
 #pragma unroll
-            for (int pl = 0; pl < 2; ++pl)
+            for (int pl = 0; pl < NPLW; ++pl)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) F[pl][q] = frag(buf, pl, ablk0 + q);
 #pragma unroll
-            for (int t = 0; t < 3; ++t) {
+            for (int t = 0; t < NPROD; ++t) {
                 int idx = 0, full = 0;
 #pragma unroll
                 for (int a = 0; a < 4; ++a)
@@ -477,16 +486,16 @@ __device__ __forceinline__ void gram_wide_body(const float *__restrict__ X, int6
                     }
             }
         } else {
-            bf16x8 A[2][4], B[2][2];
+            bf16x8 A[NPLW][4], B[NPLW][2];
 #pragma unroll
-            for (int pl = 0; pl < 2; ++pl) {
+            for (int pl = 0; pl < NPLW; ++pl) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) A[pl][q] = frag(buf, pl, ablk0 + q);
 #pragma unroll
                 for (int q = 0; q < 2; ++q) B[pl][q] = frag(buf, pl, bblk0 + q);
             }
 #pragma unroll
-            for (int t = 0; t < 3; ++t) {
+            for (int t = 0; t < NPROD; ++t) {
 #pragma unroll
                 for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -506,26 +515,55 @@ __device__ __forceinline__ void gram_wide_body(const float *__restrict__ X, int6
     // (the split / write phase before the MFMAs, in all or in half of the waves, measured 2-13 % slower)
     const int64_t nrows = r1 - r0;
     const int nst = (int)((nrows + 15) / 16);
-    float4 f0[4], f1[4];
-    fetch(f0, r0);
-    fetch(f1, r0 + 16);
-    stash(f0, 0, r0);
-    __syncthreads();
     int s = 0;
-    auto step = [&](float4 (&fnext2)[4], const float4 (&fnext1)[4]) {
-        const int buf = s & 1;
-        if (!(ablate & 4)) fetch(fnext2, r0 + (int64_t)(s + 2) * 16);
-        __builtin_amdgcn_sched_barrier(0);          // the loads go out first: two k-steps of latency cover
-        if (!(ablate & 1)) mma(buf);
-        if (!(ablate & 2)) stash(fnext1, buf ^ 1, r0 + (int64_t)(s + 1) * 16);
+    if (NPROD == 1) {
+        // plain bf16: one plane of fragments instead of two frees the registers of a THIRD set of loads - the loads of a
+        // k-step are latency-bound (bytes in flight per CU), and with a single product per sub-tile they, not the matrix
+        // pipe, are what the launch lasts: k-step s + 3 is requested while s is multiplied and s + 1 split
+        float4 f0[4], f1[4], f2[4];
+        fetch(f0, r0);
+        fetch(f1, r0 + 16);
+        fetch(f2, r0 + 32);
+        stash(f0, 0, r0);
         __syncthreads();
-        ++s;
-    };
-    while (s + 1 < nst) {
-        step(f0, f1);
-        step(f1, f0);
+        auto step3 = [&](float4 (&fnext3)[4], const float4 (&fnext1)[4]) {
+            const int buf = s & 1;
+            if (!(ablate & 4)) fetch(fnext3, r0 + (int64_t)(s + 3) * 16);
+            __builtin_amdgcn_sched_barrier(0);
+            if (!(ablate & 1)) mma(buf);
+            if (!(ablate & 2)) stash(fnext1, buf ^ 1, r0 + (int64_t)(s + 1) * 16);
+            __syncthreads();
+            ++s;
+        };
+        // entering iteration s: k-step s is in LDS, sets hold s + 1 (-> stash), s + 2; the set of k-step s is free
+        while (s + 2 < nst) {
+            step3(f0, f1);
+            step3(f1, f2);
+            step3(f2, f0);
+        }
+        if (s < nst) step3(f0, f1);
+        if (s < nst) step3(f1, f2);
+    } else {
+        float4 f0[4], f1[4];
+        fetch(f0, r0);
+        fetch(f1, r0 + 16);
+        stash(f0, 0, r0);
+        __syncthreads();
+        auto step = [&](float4 (&fnext2)[4], const float4 (&fnext1)[4]) {
+            const int buf = s & 1;
+            if (!(ablate & 4)) fetch(fnext2, r0 + (int64_t)(s + 2) * 16);
+            __builtin_amdgcn_sched_barrier(0);          // the loads go out first: two k-steps of latency cover
+            if (!(ablate & 1)) mma(buf);
+            if (!(ablate & 2)) stash(fnext1, buf ^ 1, r0 + (int64_t)(s + 1) * 16);
+            __syncthreads();
+            ++s;
+        };
+        while (s + 1 < nst) {
+            step(f0, f1);
+            step(f1, f0);
+        }
+        if (s < nst) step(f0, f1);
     }
-    if (s < nst) step(f0, f1);
     // (column sums: the stashes "after the end" added zeros)
 
     // ---- epilogue ----
@@ -587,6 +625,7 @@ __device__ __forceinline__ void gram_wide_body(const float *__restrict__ X, int6
     }
 }
 
+template <int NPROD>
 __global__ __launch_bounds__(kWThreads, 1) void gram_bf16_wide_kernel(
     const float *__restrict__ X, int64_t rows, int64_t ld, const float *__restrict__ shift, float *__restrict__ P,
     float *__restrict__ CS, int nchunks, ChunkPlan plan, int ncompute, FoldJob fold, int ablate) {
@@ -610,41 +649,47 @@ __global__ __launch_bounds__(kWThreads, 1) void gram_bf16_wide_kernel(
 #define GS_WIDE_ARGS X, ld, shift, P, CS, chunk, r0, r1, half, wave, lds, ablate
     if (wave >= 6) {
         if (half == 1 && wave == 6)
-            gram_wide_body<true, -1, 4>(GS_WIDE_ARGS);
+            gram_wide_body<NPROD, true, -1, 4>(GS_WIDE_ARGS);
         else
-            gram_wide_body<true, -1, 9>(GS_WIDE_ARGS);
+            gram_wide_body<NPROD, true, -1, 9>(GS_WIDE_ARGS);
     } else if (half == 0 && wave == 0) {
-        gram_wide_body<false, 3, -1>(GS_WIDE_ARGS);
+        gram_wide_body<NPROD, false, 3, -1>(GS_WIDE_ARGS);
     } else if ((half == 0 && wave == 1) || (half == 1 && (wave == 0 || wave == 5))) {
-        gram_wide_body<false, 5, -1>(GS_WIDE_ARGS);
+        gram_wide_body<NPROD, false, 5, -1>(GS_WIDE_ARGS);
     } else {
-        gram_wide_body<false, -1, -1>(GS_WIDE_ARGS);
+        gram_wide_body<NPROD, false, -1, -1>(GS_WIDE_ARGS);
     }
 #undef GS_WIDE_ARGS
 }
 
-int launch_gram_bf16_wide(int grid, int nfold, const float *X, int64_t n, int64_t ld, const float *shift, float *P,
-                          float *CS, int nchunks, ChunkPlan plan, const FoldJob &fold, hipStream_t stream) {
+int launch_gram_bf16_wide(int precision, int grid, int nfold, const float *X, int64_t n, int64_t ld, const float *shift,
+                          float *P, float *CS, int nchunks, ChunkPlan plan, const FoldJob &fold, hipStream_t stream) {
     const size_t lds_bytes = (size_t)2 * kWStageBytes;
     GS_REQUIRE(ld < ((int64_t)1 << 27) && ld % 4 == 0 && (reinterpret_cast<uintptr_t>(X) & 15) == 0, GS_EINVAL,
                "gram (wide): rows must be 16-byte aligned");
     static bool attr = false;
     if (!attr) {
-        GS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gram_bf16_wide_kernel),
+        GS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gram_bf16_wide_kernel<3>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        GS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gram_bf16_wide_kernel<1>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
         attr = true;
     }
     // measurement only (results wrong by design): GS_GRAM_ABLATE bit 0 no MFMA, bit 1 no split / LDS writes, bit 2 no loads
     const int ablate = gram_ablate_mask();
-    hipLaunchKernelGGL(gram_bf16_wide_kernel, dim3((unsigned)(grid + nfold)), dim3(kWThreads), lds_bytes, stream, X, n, ld,
-                       shift, P, CS, nchunks, plan, grid, fold, ablate);
+    if (precision == GS_PREC_BF16)
+        hipLaunchKernelGGL(gram_bf16_wide_kernel<1>, dim3((unsigned)(grid + nfold)), dim3(kWThreads), lds_bytes, stream, X, n,
+                           ld, shift, P, CS, nchunks, plan, grid, fold, ablate);
+    else
+        hipLaunchKernelGGL(gram_bf16_wide_kernel<3>, dim3((unsigned)(grid + nfold)), dim3(kWThreads), lds_bytes, stream, X, n,
+                           ld, shift, P, CS, nchunks, plan, grid, fold, ablate);
     return GS_OK;
 }
 
 int launch_gram_bf16(int precision, int grid, int nfold, const float *X, int64_t n, int64_t ld, int d,
                      const float *shift, float *P, float *CS, int dp, int nchunks, ChunkPlan plan, int nmt, int T,
                      const FoldJob &fold, hipStream_t stream) {
-    const int npl = (precision == GS_PREC_BF16X3) ? 2 : 3;
+    const int npl = (precision == GS_PREC_BF16) ? 1 : (precision == GS_PREC_BF16X3) ? 2 : 3;
     const size_t lds_bytes = (size_t)2 * npl * 2 * kPanelBytes;
 #define GS_BF16_ARGS lds_bytes, grid, nfold, X, n, ld, d, shift, P, CS, dp, nchunks, plan, nmt, T, fold, stream
 #ifdef GS_GRAM_ABLATE_BUILD
@@ -660,6 +705,7 @@ int launch_gram_bf16(int precision, int grid, int nfold, const float *X, int64_t
         }
     }
 #endif
+    if (precision == GS_PREC_BF16) return launch_variant<1, 0>(GS_BF16_ARGS);
     if (precision == GS_PREC_BF16X3) return launch_variant<3, 0>(GS_BF16_ARGS);
     return launch_variant<6, 0>(GS_BF16_ARGS);
 #undef GS_BF16_ARGS

@@ -126,7 +126,7 @@ int launch_gram_bf16(int precision, int grid, int nfold, const float *X, int64_t
                      const FoldJob &fold, hipStream_t stream);
 
 // bf16x3 "wide" variant for d = 512: pairs of workgroups hold the whole upper triangle (gs_gram_bf16.hip)
-int launch_gram_bf16_wide(int grid, int nfold, const float *X, int64_t n, int64_t ld, const float *shift, float *P,
+int launch_gram_bf16_wide(int precision, int grid, int nfold, const float *X, int64_t n, int64_t ld, const float *shift, float *P,
                           float *CS, int nchunks, ChunkPlan plan, const FoldJob &fold, hipStream_t stream);
 
 // exact-f32 "wide" variant for d = 512 (gs_gram_wide.hip)

@@ -127,27 +127,61 @@ __global__ void faithful_stats_kernel(const double *__restrict__ S1, const float
 
 // T = Bk Vk (k x dp); the old-state term Vk^T Bk Vk is evaluated as sum_t T[t][lo] Vk[t][hi] with lo <= hi so that W
 // is symmetric to the last bit whatever rounding Bk carries.
-__global__ void faithful_assemble_kernel(const double *__restrict__ G, const double *__restrict__ vec,
-                                         const double *__restrict__ Vk, const double *__restrict__ T,
-                                         double *__restrict__ W, double *__restrict__ m2, int d, int dp,
-                                         int k, double n0, double m) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    const int i = blockIdx.y;
-    if (j >= d) return;
-    const double gc = upper_get(G, dp, i, j) - m * vec[i] * vec[j];
-    double c = gc;
-    if (n0 > 0) {
-        c += vec[dp + i] * vec[dp + j];
-        const int lo = i < j ? i : j, hi = i < j ? j : i;
-        double acc = 0;
-        for (int t = 0; t < k; ++t) acc += T[(int64_t)t * dp + lo] * Vk[(int64_t)t * dp + hi];
-        c += acc;
+// LDS-tiled: one workgroup per upper 32 x 32 tile of W.  The old-state term V^T B V is a (d x k)(k x d) product - 80
+// multiply-adds per element; with both operands from L2 per multiply-add that was 27 us at d = 512 (12 TB/s of L2
+// traffic) - the two k x 32 panels of T and Vk are staged in LDS once per tile instead.  Every
+// element is computed once, by the thread of its upper-triangle position (lo <= hi), and written to both (i, j) and
+// (j, i): W is symmetric to the last bit as before.
+__global__ __launch_bounds__(256) void faithful_assemble_tiled_kernel(const double *__restrict__ G,
+                                                                      const double *__restrict__ vec,
+                                                                      const double *__restrict__ Vk,
+                                                                      const double *__restrict__ T, double *__restrict__ W,
+                                                                      double *__restrict__ m2, int d, int dp, int k,
+                                                                      double n0, double m, int ntile) {
+    constexpr int KC = 64;
+    __shared__ double Ts[KC][33], Vs[KC][33];
+    int I = 0, J = blockIdx.x, len = ntile;          // linear index over the upper triangle of 32 x 32 tiles
+    while (J >= len) {
+        J -= len;
+        ++I;
+        --len;
     }
-    W[(int64_t)i * dp + j] = c;
-    if (i == j) {
-        const double n1 = n0 + m;
-        const double dl = vec[2 * dp + i];
-        m2[i] = (n0 > 0 ? m2[i] : 0.0) + gc + dl * dl * (n0 * m / n1);
+    J += I;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // thread: column tx, rows ty, ty + 8, ty + 16, ty + 24
+    double acc[4] = {0, 0, 0, 0};
+    if (n0 > 0) {
+        for (int t0 = 0; t0 < k; t0 += KC) {
+            const int kc = (k - t0 < KC) ? k - t0 : KC;
+            for (int e = threadIdx.x; e < KC * 32; e += 256) {
+                const int t = e >> 5, c = e & 31;
+                Ts[t][c] = (t < kc) ? T[(int64_t)(t0 + t) * dp + I * 32 + c] : 0.0;
+                Vs[t][c] = (t < kc) ? Vk[(int64_t)(t0 + t) * dp + J * 32 + c] : 0.0;
+            }
+            __syncthreads();
+#pragma unroll 8
+            for (int t = 0; t < KC; ++t) {
+                const double v = Vs[t][tx];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[q] += Ts[t][ty + 8 * q] * v;
+            }
+            __syncthreads();
+        }
+    }
+    const int j = J * 32 + tx;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int i = I * 32 + ty + 8 * q;
+        if (i >= d || j >= d || i > j) continue;                 // (diagonal tiles: the lower half is the mirror image)
+        const double gc = G[(int64_t)i * dp + j] - m * vec[i] * vec[j];       // upper tiles of G64 are stored
+        double c = gc;
+        if (n0 > 0) c += vec[dp + i] * vec[dp + j] + acc[q];
+        W[(int64_t)i * dp + j] = c;
+        W[(int64_t)j * dp + i] = c;
+        if (i == j) {
+            const double n1 = n0 + m;
+            const double dl = vec[2 * dp + i];
+            m2[i] = (n0 > 0 ? m2[i] : 0.0) + gc + dl * dl * (n0 * m / n1);
+        }
     }
 }
 
@@ -642,8 +676,9 @@ int gs_ipca_create(int64_t d, int k, int mode, int precision, int device, gs_ipc
     *out = nullptr;
     GS_REQUIRE(mode == GS_MODE_EXACT || mode == GS_MODE_FAITHFUL || mode == GS_MODE_SMALLSIDE, GS_EINVAL,
                "gs_ipca_create: bad mode");
-    GS_REQUIRE(precision == GS_PREC_F32 || precision == GS_PREC_BF16X3 || precision == GS_PREC_BF16X6, GS_ENOTIMPL,
-               "gs_ipca_create: unknown precision (GS_PREC_F32 / GS_PREC_BF16X3 / GS_PREC_BF16X6)");
+    GS_REQUIRE(precision == GS_PREC_F32 || precision == GS_PREC_BF16X3 || precision == GS_PREC_BF16X6 ||
+                   precision == GS_PREC_BF16, GS_ENOTIMPL,
+               "gs_ipca_create: unknown precision (GS_PREC_F32 / GS_PREC_BF16X3 / GS_PREC_BF16X6 / GS_PREC_BF16)");
     if (mode == GS_MODE_SMALLSIDE) {
         GS_REQUIRE(d >= 4 && d <= ((int64_t)1 << 21), GS_EINVAL, "gs_ipca_create: feature dim out of range");
         GS_REQUIRE(d % 4 == 0, GS_ENOTIMPL, "gs_ipca_create: small-side mode needs feat_dim % 4 == 0");
@@ -805,7 +840,7 @@ int gs_ipca_update(gs_ipca_t *h, const float *X, int64_t rows, int64_t ld, void 
                 h->pending_diag = false;
             }
             GS_HIP_CHECK(hipStreamSynchronize(stream));
-            h->ss.precision = h->prec;
+            h->ss.precision = h->prec == GS_PREC_BF16 ? GS_PREC_BF16X3 : h->prec;   // (no single-plane T = M M^T kernel)
             int rc = smallside_alloc(h->ss, h->d, h->k, (int)rows);
             if (rc != GS_OK) return rc;
             h->ss.sws.graphs.enabled = true;
@@ -850,8 +885,11 @@ int gs_ipca_update(gs_ipca_t *h, const float *X, int64_t rows, int64_t ld, void 
                        h->shift, h->mean, h->vec, d, dp, n0, m);
     if (n0 > 0)   // T = Bk Vk
         gemm_f64(h->k, dp, h->k, h->Bk, h->k, 1, h->Vk, dp, 1, h->T, dp, stream, 1.0, 0.0, GemmEpilogue(), false);
-    hipLaunchKernelGGL(faithful_assemble_kernel, dim3((unsigned)ceil_div(d, 256), (unsigned)d), dim3(256), 0,
-                       stream, h->G64, h->vec, h->Vk, h->T, h->W, h->m2, d, dp, h->k, n0, m);
+    {
+        const int ntile = (int)ceil_div(d, 32);
+        hipLaunchKernelGGL(faithful_assemble_tiled_kernel, dim3((unsigned)(ntile * (ntile + 1) / 2)), dim3(256), 0, stream,
+                           h->G64, h->vec, h->Vk, h->T, h->W, h->m2, d, dp, h->k, n0, m, ntile);
+    }
     h->n_seen += rows;
     h->blocks += 1;
     // From the fifth block on the k leading eigenvalues of W sit (n0 / m + 1) times above the rest: carry the
@@ -1032,7 +1070,7 @@ int gs_gram_accumulate(const float *X, int64_t rows, int64_t ld, int64_t d, cons
 
 int gs_gram_accumulate_prec(const float *X, int64_t rows, int64_t ld, int64_t d, const float *shift, double *G,
                             double *colsum, int precision, void *stream_) {
-    GS_REQUIRE(precision >= GS_PREC_F32 && precision <= GS_PREC_BF16X6, GS_EINVAL, "gs_gram_accumulate: bad precision");
+    GS_REQUIRE(precision >= GS_PREC_F32 && precision <= GS_PREC_BF16, GS_EINVAL, "gs_gram_accumulate: bad precision");
     GS_REQUIRE(X && G && colsum, GS_EINVAL, "gs_gram_accumulate: NULL argument");
     GS_REQUIRE(d >= 1 && d <= 8192 && rows >= 0 && ld >= d, GS_EINVAL, "gs_gram_accumulate: bad shape");
     hipStream_t stream = (hipStream_t)stream_;

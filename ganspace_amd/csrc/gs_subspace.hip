@@ -167,7 +167,7 @@ void gemm_f64(int M, int N, int K, const double *A, int64_t a_i, int64_t a_t, co
     // experiment knob: workgroups a split-K launch aims for
     static const int target_wgs = []() {
         const char *e = getenv("GS_GEMM_TARGET_WGS");
-        return e ? atoi(e) : 160;
+        return e ? atoi(e) : 640;      // (160 -> 640: small-side block at d = 131 072 7.3 -> 6.9 ms, profiles/r03_probes.md)
     }();
     if (allow_split && beta == 0.0 && tiles < 128 && K >= 256) {
         splits = (int)ceil_div(target_wgs, tiles);

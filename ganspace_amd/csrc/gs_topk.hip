@@ -293,7 +293,7 @@ __global__ __launch_bounds__(1024) void chol_blocked_kernel(const double *__rest
 // the eigenvectors as COLUMNS of U (U[t * ldu + rank]); info[0] = sweeps, info[1] = 1 if the sweep limit was hit.
 constexpr int kJacLd = 128;
 constexpr int kJacMaxSweeps = 30;
-constexpr int kJacobiDefaultLP = 8;
+constexpr int kJacobiDefaultLP = 16;     // 2 665 vs 2 800 clk per round at p = 128 (profiles/r03_probes.md)
 template <int NT, int LP = 8>
 __global__ __launch_bounds__(64 * LP) void jacobi_lds_kernel(const double *__restrict__ B, int64_t ldb, int p,
                                                           double *__restrict__ U, int64_t ldu,

@@ -62,9 +62,14 @@ enum { GS_MODE_EXACT = 0, GS_MODE_FAITHFUL = 1, GS_MODE_SMALLSIDE = 2 };
  *                 at 6/16 of the f32-MFMA time.
  * GS_PREC_BF16X3  two bf16 terms, three MFMAs: dropped terms <= 2^-16 |xy| with random sign
  *                 (averaging out over the rows of a block); 3/16 of the f32-MFMA time.
+ * GS_PREC_BF16    ONE bf16 term (round to nearest even), one MFMA: every product carries a relative error <= 2^-8
+ *                 of random sign, i.e. a Gram entry summed over n rows is off by ~2^-9 / sqrt(n) of its
+ *                 Cauchy-Schwarz scale (n = 1e6: ~2e-6).  The contraction SURVEY 8b/8d calls "bf16 single-pass": the
+ *                 update is then bound by HBM, not by the matrix pipe.  Leading components stay within the
+ *                 north_star's tolerance (top-20 cosine >= 0.999; measured in tests/ and bench.py); opt-in.
  * In GS_MODE_SMALLSIDE the precision selects the contraction of T = M M^T (both operands are K-contiguous rows of
- * M: the split needs no transpose there).                                                   */
-enum { GS_PREC_F32 = 0, GS_PREC_BF16X3 = 1, GS_PREC_BF16X6 = 2 };
+ * M: the split needs no transpose there); GS_PREC_BF16 runs as GS_PREC_BF16X3 there.          */
+enum { GS_PREC_F32 = 0, GS_PREC_BF16X3 = 1, GS_PREC_BF16X6 = 2, GS_PREC_BF16 = 3 };
 
 typedef struct gs_ipca gs_ipca_t;
 

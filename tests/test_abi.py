@@ -39,7 +39,7 @@ def test_version_and_error_paths_without_gpu(lib):
     assert b"feature dim" in lib.gs_last_error()
     assert lib.gs_ipca_create(16, 32, 0, 0, 0, C.byref(h)) == -1       # k > d
     assert lib.gs_ipca_create(16, 4, 7, 0, 0, C.byref(h)) == -1        # bad mode
-    assert lib.gs_ipca_create(16, 4, 0, 3, 0, C.byref(h)) == -5        # precision not implemented
+    assert lib.gs_ipca_create(16, 4, 0, 9, 0, C.byref(h)) == -5        # precision not implemented
     assert lib.gs_ipca_create(100000, 4, 0, 0, 0, C.byref(h)) == -5    # d beyond the Gram-side solver
     assert lib.gs_ipca_update(None, None, 1, 1, None) == -1
     assert lib.gs_ipca_destroy(None) == 0

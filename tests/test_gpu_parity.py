@@ -110,10 +110,11 @@ def test_gram_accumulates_and_is_linear(dev):
 @pytest.mark.parametrize("rows,d,ld_extra", [(1, 4, 0), (17, 100, 3), (1000, 512, 0), (10000, 512, 0),
                                              (2311, 640, 0), (4097, 96, 5), (20000, 512, 0), (50001, 512, 4),
                                              (131072 + 20777, 512, 0), (30003, 512, 3)])
-@pytest.mark.parametrize("precision,tol", [("bf16x6", 3e-6), ("bf16x3", 6e-5)])
+@pytest.mark.parametrize("precision,tol", [("bf16x6", 3e-6), ("bf16x3", 6e-5), ("bf16", 6e-3)])
 def test_gram_split_bf16_matches_float64(dev, rows, d, ld_extra, precision, tol):
     """x = hi + mid (+ lo) in bf16, products rebuilt from 3 / 6 bf16 MFMAs: dropped terms are 2^-16 / 2^-24 of
-    |x||y| per product, so the elementwise error is bounded on the Cauchy-Schwarz scale."""
+    |x||y| per product, so the elementwise error is bounded on the Cauchy-Schwarz scale.  Plain ``bf16`` (one term,
+    one MFMA): each operand is off by <= 2^-9 relative, a product by <= 2^-8 (4e-3), whatever the row count."""
     from ganspace_amd import ops
     rs = np.random.RandomState(rows + d)
     Xh = (rs.standard_normal((rows, d + ld_extra)) * rs.uniform(0.2, 3.0, d + ld_extra) + 0.7).astype(np.float32)
@@ -716,3 +717,33 @@ def test_exact_mode_resident_rows_are_merged_and_match_block_by_block(dev, preci
     w, V = np.linalg.eigh(Xc.T @ Xc)
     ref = V[:, ::-1][:, :k].T
     assert np.abs(O.signed_cosines(ca, ref)).min() > 1 - (2e-6 if precision == "f32" else 3e-5)
+
+
+def test_plain_bf16_contraction_keeps_the_leading_components(dev):
+    """``precision="bf16"`` (the single-pass contraction that makes the Gram update HBM-bound): the
+    rounding errors of the rows are independent, so a Gram entry summed over n rows is off by ~2^-9 / sqrt(n) of its
+    Cauchy-Schwarz scale - measured here - and the leading components stay inside the north_star's tolerance
+    (top-20 cosine >= 0.999) with three digits to spare on cfg2-shaped data (d = 512, k = 80, 131 072 + rows through
+    the wide kernel and a tail through the tiled one)."""
+    from ganspace_amd import ops
+    from ganspace_amd.estimators import IPCAEstimator
+    rng = np.random.default_rng(17)
+    d, k, n = 512, 80, 300_000
+    A = rng.standard_normal((160, d)) * (1.04 ** -np.arange(160))[:, None]
+    X = (rng.standard_normal((n, 160)) @ A + 0.05 * rng.standard_normal((n, d)) + 0.2).astype(np.float32)
+    Xd = torch.from_numpy(X).to(dev)
+    est = IPCAEstimator(k, "exact", precision="bf16")
+    ref = IPCAEstimator(k, "exact")
+    for lo in range(0, n, 50_000):
+        assert est.fit_partial(Xd[lo:lo + 50_000], resident=True)
+        assert ref.fit_partial(Xd[lo:lo + 50_000], resident=True)
+    cos = O.signed_cosines(est.get_components()[0], ref.get_components()[0])
+    assert cos[:20].min() > 1 - 1e-6, cos[:20]            # north_star asks for >= 0.999
+    assert np.abs(cos).min() > 0.999, np.abs(cos).min()   # all 80: eigenvalue gaps of a few per cent
+    np.testing.assert_allclose(est.transformer.singular_values_, ref.transformer.singular_values_, rtol=2e-4)
+    np.testing.assert_allclose(est.transformer.mean_, ref.transformer.mean_, atol=1e-6)
+    # error of the Gram itself: ~2^-9 / sqrt(rows), far below the 4e-3 bound of a single product
+    G, _ = ops.gram_accumulate(Xd[:131072], precision="bf16")
+    G32, _ = ops.gram_accumulate(Xd[:131072])
+    scale = torch.sqrt(torch.outer(torch.diag(G32), torch.diag(G32)))
+    assert float(((G - G32) / scale).abs().max()) < 2e-4
