@@ -690,7 +690,11 @@ int launch_gram_bf16(int precision, int grid, int nfold, const float *X, int64_t
                      const float *shift, float *P, float *CS, int dp, int nchunks, ChunkPlan plan, int nmt, int T,
                      const FoldJob &fold, hipStream_t stream) {
     const int npl = (precision == GS_PREC_BF16) ? 1 : (precision == GS_PREC_BF16X3) ? 2 : 3;
-    const size_t lds_bytes = (size_t)2 * npl * 2 * kPanelBytes;
+    // two stages of [plane][panel A|B] images - and at least what the epilogue needs: the four waves' 64 x 64 output
+    // tiles (row stride kOutStride) plus the column-sum scratch behind them (one plane alone would be too small)
+    const size_t stage_bytes = (size_t)2 * npl * 2 * kPanelBytes;
+    const size_t epi_bytes = (size_t)4 * 64 * kOutStride * sizeof(float) + (size_t)2 * kMacroTile * sizeof(float);
+    const size_t lds_bytes = stage_bytes > epi_bytes ? stage_bytes : epi_bytes;
 #define GS_BF16_ARGS lds_bytes, grid, nfold, X, n, ld, d, shift, P, CS, dp, nchunks, plan, nmt, T, fold, stream
 #ifdef GS_GRAM_ABLATE_BUILD
     // measurement builds only (results are wrong): 1 no MFMA/LDS reads, 2 no split, 3 no global loads, 4 MFMA from registers
