@@ -392,7 +392,7 @@ def main():
                 job = time.perf_counter() - t0
                 # the launch the resident path issues: 131 072 rows in one "wide" launch for bf16x3 / bf16 (pairs of
                 # workgroups hold the whole upper triangle); bf16x6 launches are capped at 24 576 rows (no float64 carry)
-                us_p, rt = gram_kernel_us(lib, _lib, e2, RESIDENT_ROWS[:LAUNCH_ROWS])
+                us_p, rt = gram_kernel_us(lib, _lib, e2, RESIDENT_ROWS[:LAUNCH_ROWS * (4 if prec == "bf16" else 1)])
                 mfma_tf = nprod * rt * D * (D + 1) / (us_p * 1e-6) / 1e12
                 gbs = rt * D * 4 / (us_p * 1e-6) / 1e9
                 split[prec] = {"samples_per_s": round(n_blocks * NB / job, 1), "gram_launch_us": round(us_p, 2),
@@ -404,6 +404,26 @@ def main():
                                "top20_min_signed_cos": round(float(c[:20].min()), 7),
                                "all80_min_abs_cos": round(float(np.abs(c).min()), 5)}
             out["split_bf16_modes"] = split
+            # the HBM-bound contraction ("bf16 single-pass") as a second roofline entry: opt-in
+            # (precision="bf16"), leading components inside the north_star tolerance - see its cos fields
+            b = split["bf16"]
+            hb_traffic = None
+            try:
+                with open(os.path.join(ROOT, "profiles", "gram_pmc_latest.json")) as f:
+                    pm = json.load(f).get("bf16", {})
+                if pm.get("rows_per_launch") == b["rows_per_launch"]:
+                    hb_traffic = pm.get("hbm_bytes_per_launch")
+            except Exception:
+                pass
+            out["roofline_hbm"] = {"bound": "hbm", "kernel": "gram_bf16_wide_kernel<1> (precision=\"bf16\", opt-in)",
+                                   "achieved": b["roofline"]["achieved"], "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                   "frac": b["roofline"]["frac"], "traffic": hb_traffic,
+                                   "avg_launch_us": b["gram_launch_us"], "rows_per_launch": b["rows_per_launch"],
+                                   "algorithmic_bytes_per_launch": b["rows_per_launch"] * D * 4,
+                                   "samples_per_s_whole_job": b["samples_per_s"],
+                                   "top20_min_signed_cos_vs_sklearn": b["top20_min_signed_cos"],
+                                   "read_ceiling_note": "a plain streaming-read kernel reaches 6.0-6.2 TB/s on this chip "
+                                                        "(tools/ubench/read_bw.hip, profiles/r03_probes.md)"}
 
     # ---- the wide-feature BASELINE shapes (cfg3 d = 32 768, cfg5 d = 131 072; NB = 2 000, k = 80): PCA-only
     #      throughput of the small-side recurrence on the synthetic low-rank-plus-noise blocks of SURVEY.md 8d item 5,

@@ -589,14 +589,18 @@ static GramGeom gram_geometry(const GramWorkspace &ws, int64_t n, bool aligned16
         // fold fewer slabs (~5 TB/s) - pick the multiple of 8 that minimises the sum
         g.wide = true;
         g.want = 128;
-        g.rows_per_launch = (int64_t)128 * kMaxChunkRows;
+        // rows a pair accumulates in float32 before its slab leaves: 1024 for the float32-class contractions; the plain
+        // bf16 products carry 2^-9 per operand, next to which 4096 float32 additions (<= 2.4e-4 worst case, ~4e-6
+        // typical) are nothing - and a launch of 4 x the rows amortises the 71 MB of slabs it writes 4 x better
+        const int64_t max_chunk = ws.precision == GS_PREC_BF16 ? 4 * (int64_t)kMaxChunkRows : kMaxChunkRows;
+        g.rows_per_launch = (int64_t)128 * max_chunk;
         if (n > g.rows_per_launch) n = g.rows_per_launch;
         const int64_t units = ceil_div(n, (int64_t)kRowUnit);
         int best = 8;
         double best_t = 1e300;
         for (int np = 8; np <= 128; np += 8) {
             if ((int64_t)np * 4 > units && np > 8) break;                      // at least 64 rows per pair
-            if (ceil_div(units, (int64_t)np) * kRowUnit > kMaxChunkRows) continue;
+            if (ceil_div(units, (int64_t)np) * kRowUnit > max_chunk) continue;
             // matrix work per row and pair: 136 sub-tiles x 3 bf16 MFMAs x 32 clk (resp. x 1/2 f32 MFMA x 64 clk)
             // over 8 SIMDs, 18 / 17 imbalance
             const double clk_row = ws.precision == GS_PREC_F32 ? 576.0 : ws.precision == GS_PREC_BF16 ? 60.0 : 108.0;

@@ -521,17 +521,21 @@ __device__ __forceinline__ void gram_wide_body(const float *__restrict__ X, int6
         // k-step are latency-bound (bytes in flight per CU), and with a single product per sub-tile they, not the matrix
         // pipe, are what the launch lasts: k-step s + 3 is requested while s is multiplied and s + 1 split
         float4 f0[4], f1[4], f2[4];
-        fetch(f0, r0);
-        fetch(f1, r0 + 16);
-        fetch(f2, r0 + 32);
-        stash(f0, 0, r0);
+        // (walking the chunk from a chunk-dependent k-step - so that the 128 lock-stepped pairs, whose chunks lie a power of
+        //  two apart, would not hit the same memory channel together - measured no different: 402 vs 408 us per 524 288
+        //  rows, loads alone 304 vs 303; profiles/r03_probes.md)
+        auto kb = [&](int t) -> int64_t { return r0 + (int64_t)t * 16; };
+        fetch(f0, kb(0));
+        fetch(f1, kb(1));
+        fetch(f2, kb(2));
+        stash(f0, 0, kb(0));
         __syncthreads();
         auto step3 = [&](float4 (&fnext3)[4], const float4 (&fnext1)[4]) {
             const int buf = s & 1;
-            if (!(ablate & 4)) fetch(fnext3, r0 + (int64_t)(s + 3) * 16);
+            if (!(ablate & 4)) fetch(fnext3, kb(s + 3));
             __builtin_amdgcn_sched_barrier(0);
             if (!(ablate & 1)) mma(buf);
-            if (!(ablate & 2)) stash(fnext1, buf ^ 1, r0 + (int64_t)(s + 1) * 16);
+            if (!(ablate & 2)) stash(fnext1, buf ^ 1, kb(s + 1));
             __syncthreads();
             ++s;
         };
