@@ -411,7 +411,9 @@ __device__ __forceinline__ void gram_wide_body(const float *__restrict__ X, int6
     // ---- staging: thread = (column quad, row quad): four float4 loads per k-step (dword loads, one column per thread,
     //      were limited by the vector-memory instruction rate: 128 wave loads of 256 B per k-step took 1 800 clk) ----
     const int cq = tid & 127, rq = tid >> 7;
-    const float4 sh = *reinterpret_cast<const float4 *>(shift + 4 * cq);
+    // (the single-plane variant is one register short of three fetch sets: it re-reads its four shift values - an L1 hit -
+    //  in every stash instead of holding them; a spilled register in this loop was measured to corrupt results)
+    const float4 sh_reg = *reinterpret_cast<const float4 *>(shift + 4 * cq);
     float cs[4] = {0.f, 0.f, 0.f, 0.f};
     const int ld32 = (int)ld;                                      // 16 * ld < 2^31 (checked by the launcher)
     // ONE code path for every k-step: the loads are unconditional and clamped to the chunk's last row (also for the
@@ -432,6 +434,12 @@ __device__ __forceinline__ void gram_wide_body(const float *__restrict__ X, int6
         float m[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) m[i] = (rbase + rq * 4 + i < r1) ? 1.f : 0.f;
+        float4 sh = sh_reg;
+        if (NPROD == 1) {
+            const float *sp = shift + 4 * cq;
+            asm volatile("" : "+v"(sp));                 // opaque: keeps the compiler from hoisting the loads out of the loop
+            sh = *reinterpret_cast<const float4 *>(sp);
+        }
         unsigned char *base = lds + buf * kWStageBytes + (rq >> 1) * kWKgBytes + cq * 16 + (rq & 1) * 8;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
