@@ -36,6 +36,15 @@
 #include "gs_common.h"
 #include "gs_gram_internal.h"
 
+// The ablation mask is a compile-time 0 in the tiled f32 kernel unless this is a measurement build: its phases then have
+// no branch around them (a conditional fetch costs an s_waitcnt vmcnt(0) right behind the loads, see gs_gram_bf16.hip);
+// 36.6 -> 34.8 us per 10 000-row block (profiles/r03_probes.md).
+#ifdef GS_GRAM_ABLATE_BUILD
+#define GS_TILED_ABL(mask, bits) ((mask) & (bits))
+#else
+#define GS_TILED_ABL(mask, bits) 0
+#endif
+
 namespace gs {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
@@ -377,16 +386,16 @@ __device__ __forceinline__ void gram_tile(const GramTileCtx &c, float (*lds)[2][
         const bool more = s + 1 < nst;
         const bool next_whole = tile_full && s + 1 <= nfull;      // stage s + 1 may use the mask-free path
         if (more) pace(s + 1);
-        if (more && !(c.ablate & 2)) {
+        if (more && !GS_TILED_ABL(c.ablate, 2)) {
             if (next_whole)
                 fetch_fast(f, stage_row(s + 1));
             else
                 fetch(f, stage_row(s + 1), (stage_rows(s + 1) + 15) / 16);
         }
         __builtin_amdgcn_sched_barrier(0);
-        if ((M0 || M1) && !(c.ablate & 1)) mfma_stage<M0, M1>(opA(buf), opB(buf), (stage_rows(s) + 1) / 2, acc0, acc1);
+        if ((M0 || M1) && !GS_TILED_ABL(c.ablate, 1)) mfma_stage<M0, M1>(opA(buf), opB(buf), (stage_rows(s) + 1) / 2, acc0, acc1);
         __builtin_amdgcn_sched_barrier(0);
-        if (more && !(c.ablate & 16)) {
+        if (more && !GS_TILED_ABL(c.ablate, 16)) {
             if (next_whole)
                 stash_fast(f, buf ^ 1);
             else
@@ -412,11 +421,11 @@ __device__ __forceinline__ void gram_tile(const GramTileCtx &c, float (*lds)[2][
         while (s < nfull) {
             const int buf = s & 1;
             pace(s + 1);
-            if (!(c.ablate & 2)) fetch_fast(f, stage_row(s + 1));
+            if (!GS_TILED_ABL(c.ablate, 2)) fetch_fast(f, stage_row(s + 1));
             __builtin_amdgcn_sched_barrier(0);
-            if ((M0 || M1) && !(c.ablate & 1)) mfma_steps<M0, M1, kKB / 2>(opA(buf), opB(buf), acc0, acc1);
+            if ((M0 || M1) && !GS_TILED_ABL(c.ablate, 1)) mfma_steps<M0, M1, kKB / 2>(opA(buf), opB(buf), acc0, acc1);
             __builtin_amdgcn_sched_barrier(0);
-            if (!(c.ablate & 16)) stash_fast(f, buf ^ 1);
+            if (!GS_TILED_ABL(c.ablate, 16)) stash_fast(f, buf ^ 1);
             __syncthreads();
             stamp(2 + s);
             ++s;
@@ -428,7 +437,7 @@ __device__ __forceinline__ void gram_tile(const GramTileCtx &c, float (*lds)[2][
     publish(1ull << 30);                                       // done: nobody waits for a finished workgroup
 
     // ---- epilogue: 32x32 sub-tiles -> this chunk's float32 slab --------------------------------
-    if (!(c.ablate & 32) || c.r0 < 0) {
+    if (!GS_TILED_ABL(c.ablate, 32) || c.r0 < 0) {
         float *Pc = c.P + (int64_t)c.chunk * c.dp * c.dp;
         const int row_base = c.I * kMacroTile + wi * 64 + 4 * (lane >> 5);
         const int col = c.J * kMacroTile + wj * 32 + (lane & 31);

@@ -528,6 +528,7 @@ __device__ __forceinline__ void gram_wide_body(const float *__restrict__ X, int6
         // plain bf16: one plane of fragments instead of two frees the registers of a THIRD set of loads - the loads of a
         // k-step are latency-bound (bytes in flight per CU), and with a single product per sub-tile they, not the matrix
         // pipe, are what the launch lasts: k-step s + 3 is requested while s is multiplied and s + 1 split
+#if defined(GS_GRAM_ABLATE_BUILD) || defined(GS_BF16_DEPTH3)
         float4 f0[4], f1[4], f2[4];
         // (walking the chunk from a chunk-dependent k-step - so that the 128 lock-stepped pairs, whose chunks lie a power of
         //  two apart, would not hit the same memory channel together - measured no different: 402 vs 408 us per 524 288
@@ -538,12 +539,28 @@ __device__ __forceinline__ void gram_wide_body(const float *__restrict__ X, int6
         fetch(f2, kb(2));
         stash(f0, 0, kb(0));
         __syncthreads();
+        // (measurement builds only: three fetch sets with runtime-conditional phases - the form round 3 first shipped.)
+        // The phases are UNCONDITIONAL in the production build (step2 below): a runtime `if (!(ablate & 4)) fetch(...)` makes
+        // every loaded register a phi of "old value | loaded value", which the compiler resolves with copies at the end of
+        // the conditional block - i.e. with an s_waitcnt vmcnt(0) right behind the loads (seen in the ISA of this loop:
+        // the pipeline drained every k-step and the load phase ran at 3.96 TB/s where the same access pattern streams at
+        // 5.45).  The scheduling fences keep the straight-line version from hoisting the loads of all three unrolled
+        // steps to the top (312 spilled registers without them).
         auto step3 = [&](float4 (&fnext3)[4], const float4 (&fnext1)[4]) {
             const int buf = s & 1;
+#ifdef GS_GRAM_ABLATE_BUILD
             if (!(ablate & 4)) fetch(fnext3, kb(s + 3));
             __builtin_amdgcn_sched_barrier(0);
             if (!(ablate & 1)) mma(buf);
             if (!(ablate & 2)) stash(fnext1, buf ^ 1, kb(s + 1));
+#else
+            fetch(fnext3, kb(s + 3));
+            __builtin_amdgcn_sched_barrier(0);
+            mma(buf);
+            __builtin_amdgcn_sched_barrier(0);
+            stash(fnext1, buf ^ 1, kb(s + 1));
+            __builtin_amdgcn_sched_barrier(0);
+#endif
             __syncthreads();
             ++s;
         };
@@ -555,6 +572,29 @@ __device__ __forceinline__ void gram_wide_body(const float *__restrict__ X, int6
         }
         if (s < nst) step3(f0, f1);
         if (s < nst) step3(f1, f2);
+#else
+        float4 f0[4], f1[4];
+        fetch(f0, r0);
+        fetch(f1, r0 + 16);
+        stash(f0, 0, r0);
+        __syncthreads();
+        auto step2 = [&](float4 (&fnext2)[4], const float4 (&fnext1)[4]) {
+            const int buf = s & 1;
+            fetch(fnext2, r0 + (int64_t)(s + 2) * 16);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(buf);
+            __builtin_amdgcn_sched_barrier(0);
+            stash(fnext1, buf ^ 1, r0 + (int64_t)(s + 1) * 16);
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();
+            ++s;
+        };
+        while (s + 1 < nst) {
+            step2(f0, f1);
+            step2(f1, f0);
+        }
+        if (s < nst) step2(f0, f1);
+#endif
     } else {
         float4 f0[4], f1[4];
         fetch(f0, r0);
@@ -563,10 +603,19 @@ __device__ __forceinline__ void gram_wide_body(const float *__restrict__ X, int6
         __syncthreads();
         auto step = [&](float4 (&fnext2)[4], const float4 (&fnext1)[4]) {
             const int buf = s & 1;
+#ifdef GS_GRAM_ABLATE_BUILD
             if (!(ablate & 4)) fetch(fnext2, r0 + (int64_t)(s + 2) * 16);
             __builtin_amdgcn_sched_barrier(0);          // the loads go out first: two k-steps of latency cover
             if (!(ablate & 1)) mma(buf);
             if (!(ablate & 2)) stash(fnext1, buf ^ 1, r0 + (int64_t)(s + 1) * 16);
+#else
+            // unconditional in the production build (see step2 above: a conditional fetch turns into loads followed by
+            // s_waitcnt vmcnt(0)); 136 -> 132 us per 131 072 rows
+            fetch(fnext2, r0 + (int64_t)(s + 2) * 16);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(buf);
+            stash(fnext1, buf ^ 1, r0 + (int64_t)(s + 1) * 16);
+#endif
             __syncthreads();
             ++s;
         };
