@@ -151,10 +151,17 @@ __device__ __forceinline__ void gram_f32_wide_body(const float *__restrict__ X, 
     int s = 0;
     auto step = [&](float4 (&fnext2)[4], const float4 (&fnext1)[4]) {
         const int buf = s & 1;
+#if defined(GS_WIDE_F32_UNCOND) && !defined(GS_GRAM_ABLATE_BUILD)
+        fetch(fnext2, r0 + (int64_t)(s + 2) * 16);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(buf);
+        stash(fnext1, buf ^ 1, r0 + (int64_t)(s + 1) * 16);
+#else
         if (!(ablate & 4)) fetch(fnext2, r0 + (int64_t)(s + 2) * 16);
         __builtin_amdgcn_sched_barrier(0);
         if (!(ablate & 1)) mma(buf);
         if (!(ablate & 2)) stash(fnext1, buf ^ 1, r0 + (int64_t)(s + 1) * 16);
+#endif
         __syncthreads();
         ++s;
     };
