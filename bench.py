@@ -392,7 +392,7 @@ def main():
                 job = time.perf_counter() - t0
                 # the launch the resident path issues: 131 072 rows in one "wide" launch for bf16x3 / bf16 (pairs of
                 # workgroups hold the whole upper triangle); bf16x6 launches are capped at 24 576 rows (no float64 carry)
-                us_p, rt = gram_kernel_us(lib, _lib, e2, RESIDENT_ROWS[:LAUNCH_ROWS * (4 if prec == "bf16" else 1)])
+                us_p, rt = gram_kernel_us(lib, _lib, e2, RESIDENT_ROWS[:LAUNCH_ROWS * (8 if prec == "bf16" else 1)])
                 mfma_tf = nprod * rt * D * (D + 1) / (us_p * 1e-6) / 1e12
                 gbs = rt * D * 4 / (us_p * 1e-6) / 1e9
                 split[prec] = {"samples_per_s": round(n_blocks * NB / job, 1), "gram_launch_us": round(us_p, 2),

@@ -599,9 +599,9 @@ static GramGeom gram_geometry(const GramWorkspace &ws, int64_t n, bool aligned16
         g.wide = true;
         g.want = 128;
         // rows a pair accumulates in float32 before its slab leaves: 1024 for the float32-class contractions; the plain
-        // bf16 products carry 2^-9 per operand, next to which 4096 float32 additions (<= 2.4e-4 worst case, ~4e-6
-        // typical) are nothing - and a launch of 4 x the rows amortises the 71 MB of slabs it writes 4 x better
-        const int64_t max_chunk = ws.precision == GS_PREC_BF16 ? 4 * (int64_t)kMaxChunkRows : kMaxChunkRows;
+        // bf16 products carry 2^-9 per operand, next to which 8192 float32 additions (<= 4.9e-4 worst case, ~5e-6
+        // typical) are nothing - and a launch of 8 x the rows amortises the 71 MB of slabs it writes 8 x better
+        const int64_t max_chunk = ws.precision == GS_PREC_BF16 ? 8 * (int64_t)kMaxChunkRows : kMaxChunkRows;
         g.rows_per_launch = (int64_t)128 * max_chunk;
         if (n > g.rows_per_launch) n = g.rows_per_launch;
         const int64_t units = ceil_div(n, (int64_t)kRowUnit);

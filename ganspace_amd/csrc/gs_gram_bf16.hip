@@ -20,7 +20,9 @@
 // Measured limit (profiles/): with the matrix work this cheap the kernel is bound by the L2 -> CU path -
 // every panel is fetched by the 4 macro tiles that use it, ~50 GB/s per CU - not by MFMA issue: dedicating
 // separate load/split waves (wave specialisation), deeper prefetch and wider loads were tried and did not help.
+#include <cstdio>
 #include <cstdlib>
+#include <vector>
 #include <type_traits>
 
 #include "gs_common.h"
@@ -389,7 +391,8 @@ __device__ __forceinline__ void split4(const float (&v)[4], uint2 (&planes)[2]) 
 template <int NPROD, bool DIAGROLE, int XOP, int SKIP>
 __device__ __forceinline__ void gram_wide_body(const float *__restrict__ X, int64_t ld, const float *__restrict__ shift,
                                                float *__restrict__ P, float *__restrict__ CS, int chunk, int64_t r0,
-                                               int64_t r1, int half, int wave, unsigned char *lds, int ablate) {
+                                               int64_t r1, int half, int wave, unsigned char *lds, int ablate,
+                                               unsigned long long *trace = nullptr) {
     constexpr int dp = 512;
     const int tid = threadIdx.x, lane = tid & 63;
     // ---- sub-tile ownership (in units of 32-column blocks) ----
@@ -578,15 +581,31 @@ __device__ __forceinline__ void gram_wide_body(const float *__restrict__ X, int6
         fetch(f1, r0 + 16);
         stash(f0, 0, r0);
         __syncthreads();
+#ifdef GS_WIDE_TRACE_BUILD
+        // measurement build: shader-clock stamps of k-steps 64..79 of four workgroups, waves 0 (rectangle) and 6 (diagonal):
+        // [0] step start, [1] loads issued, [2] MFMAs issued, [3] conversion + LDS writes done, [4] past the barrier
+        const bool tr = trace != nullptr && lane == 0 && (wave == 0 || wave == 6) && ((blockIdx.x & 63) == 0);
+        auto stamp = [&](int slot) {
+            if (tr && s >= 64 && s < 80)
+                trace[(((blockIdx.x >> 6) * 2 + (wave == 6)) * 16 + (s - 64)) * 8 + slot] = clock64();
+        };
+#else
+        auto stamp = [&](int) {};
+#endif
         auto step2 = [&](float4 (&fnext2)[4], const float4 (&fnext1)[4]) {
             const int buf = s & 1;
+            stamp(0);
             fetch(fnext2, r0 + (int64_t)(s + 2) * 16);
             __builtin_amdgcn_sched_barrier(0);
+            stamp(1);
             mma(buf);
             __builtin_amdgcn_sched_barrier(0);
+            stamp(2);
             stash(fnext1, buf ^ 1, r0 + (int64_t)(s + 1) * 16);
             __builtin_amdgcn_sched_barrier(0);
+            stamp(3);
             __syncthreads();
+            stamp(4);
             ++s;
         };
         while (s + 1 < nst) {
@@ -707,7 +726,7 @@ __global__ __launch_bounds__(kWThreads, 1) void gram_bf16_wide_kernel(
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     // waves w and w + 4 share a SIMD: 0-3 run MFMA then split / write, 4-7 the other way round
     // who takes the sub-tile a diagonal wave hands over: see gram_f32_wide_kernel (gs_gram_wide.hip)
-#define GS_WIDE_ARGS X, ld, shift, P, CS, chunk, r0, r1, half, wave, lds, ablate
+#define GS_WIDE_ARGS X, ld, shift, P, CS, chunk, r0, r1, half, wave, lds, ablate, fold.trace
     if (wave >= 6) {
         if (half == 1 && wave == 6)
             gram_wide_body<NPROD, true, -1, 4>(GS_WIDE_ARGS);
@@ -721,6 +740,289 @@ __global__ __launch_bounds__(kWThreads, 1) void gram_bf16_wide_kernel(
         gram_wide_body<NPROD, false, -1, -1>(GS_WIDE_ARGS);
     }
 #undef GS_WIDE_ARGS
+}
+
+// =====================================================================================================
+// Single-plane bf16, rows staged by LDS-DMA (`global_load_lds_dwordx4`): THREE k-steps in flight without a register.
+//
+// The per-wave stamps of gram_bf16_wide_kernel<1> (profiles/r03_probes.md) show where its k-step goes: ~300-800 clk to issue
+// the loads, ~450 for the MFMAs, and 1400-1600 in the conversion phase - most of it the s_waitcnt for rows requested a
+// whole k-step earlier: under this load a request takes ~2 us to come back, and with two k-steps in flight
+// (64 KB per CU; a third register set spills) Little's law stops at ~3.9 TB/s.  Here the rows go straight from global
+// memory into a ring of three raw float32 stages in LDS (3 x 32 KB; no fetch registers at all), the conversion phase
+// reads its OWN rows back (thread = the lanes that issued the piece: no cross-wave dependency, a counted
+// s_waitcnt vmcnt(8) is all it needs), converts and writes the bf16 image as before.  The barrier of a k-step is a raw
+// s_barrier behind s_waitcnt lgkmcnt(0): __syncthreads() would drain the DMA queue (vmcnt(0)) at every k-step.
+// raw ring and bf16 images are distinct __shared__ objects so that the compiler's own waitcnt insertion does not tie
+// the fragment reads to the outstanding DMA.
+constexpr int kRawStage = 16 * 2048;                 // one k-step: 16 rows x 512 float32
+typedef __attribute__((address_space(3))) void gs_lds_void;
+typedef __attribute__((address_space(1))) void gs_glb_void;
+
+template <bool DIAGROLE, int XOP, int SKIP>
+__device__ __forceinline__ void gram_wide_glds_body(const float *__restrict__ X, int64_t ld, const float *__restrict__ shift,
+                                                    float *__restrict__ P, float *__restrict__ CS, int chunk, int64_t r0,
+                                                    int64_t r1, int half, int wave, unsigned char *raw, unsigned char *img,
+                                                    int order, unsigned long long *trace = nullptr) {
+    constexpr int dp = 512;
+    const int tid = threadIdx.x, lane = tid & 63;
+    int ablk0, bblk0;
+    if (DIAGROLE) {
+        ablk0 = bblk0 = (half * 2 + (wave - 6)) * 4;
+    } else {
+        const int m = wave >> 1, sub = wave & 1;
+        const int I = half == 0 ? 0 : (m < 2 ? 1 : 2);
+        const int J = half == 0 ? m + 1 : (m == 0 ? 2 : 3);
+        ablk0 = I * 4;
+        bblk0 = J * 4 + sub * 2;
+    }
+    constexpr int NT = 9 - ((!DIAGROLE && XOP < 0) ? 1 : 0);
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = f32x16{0};
+
+    // thread = (column quad cq, row quad rq); a wave = 64 consecutive column quads (1 KB of a row) of row quad wave >> 1
+    const int cq = tid & 127, rq = tid >> 7;
+    const float4 sh = *reinterpret_cast<const float4 *>(shift + 4 * cq);
+    float cs[4] = {0.f, 0.f, 0.f, 0.f};
+    const int ld32 = (int)ld;
+    const int nst = (int)((r1 - r0 + 15) / 16);
+    // k-step t -> raw stage t % 3: four 1 KB pieces per wave (rows rq * 4 + i), addresses clamped to the chunk's last row
+    // (also for the k-steps "after the end": the DMA count per k-step stays 4, the conversion masks those rows)
+    // Complete k-steps (all but the last of a chunk): address = wave-uniform base of the k-step (scalar ALU) + a per-lane
+    // byte offset that never changes - the `global_load_lds_dwordx4 voffset, sbase` form, no vector arithmetic per piece
+    // (the clamped per-lane addresses cost ~100 clk per piece: 430 of the 2 250 clk of a k-step went into issuing four DMAs).
+    unsigned voff[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) voff[i] = (unsigned)(((rq * 4 + i) * ld32 + 4 * cq) * 4);
+    const int nfull_k = (int)((r1 - r0) / 16);
+    auto issue = [&](int t) {
+        unsigned char *stage = raw + (t % 3) * kRawStage + (wave & 1) * 1024;
+        if (t < nfull_k) {
+            const char *kbase = reinterpret_cast<const char *>(X + (r0 + (int64_t)t * 16) * ld);      // uniform
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                __builtin_amdgcn_global_load_lds((gs_glb_void *)(uintptr_t)(kbase + voff[i]),
+                                                 (gs_lds_void *)(uint32_t)(uintptr_t)(stage + (rq * 4 + i) * 2048), 16, 0, 0);
+            return;
+        }
+        const int64_t rbase = r0 + (int64_t)t * 16;
+        const int64_t rb = rbase < r1 ? rbase : r1 - 1;
+        const float *p = X + rb * ld;
+        const int last = (int)(r1 - 1 - rb);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = rq * 4 + i;
+            const float *src = p + (unsigned)((row < last ? row : last) * ld32) + (unsigned)(4 * cq);
+            __builtin_amdgcn_global_load_lds((gs_glb_void *)(uintptr_t)src,
+                                             (gs_lds_void *)(uint32_t)(uintptr_t)(stage + row * 2048), 16, 0, 0);
+        }
+    };
+    // raw stage t % 3 (this thread's own rows) -> bf16 image `buf`.  FULL: every row of the k-step lies inside the chunk
+    // (all but the last one or two k-steps of a chunk): no row masks - a quarter of the phase's vector instructions
+    auto convert = [&](int t, int buf, auto full_tag) {
+        constexpr bool FULL = decltype(full_tag)::value;
+        const int64_t rbase = r0 + (int64_t)t * 16;
+        float m[4];
+        float4 f[4];
+        const unsigned char *stage = raw + (t % 3) * kRawStage + cq * 16;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            m[i] = (FULL || rbase + rq * 4 + i < r1) ? 1.f : 0.f;
+            f[i] = *reinterpret_cast<const float4 *>(stage + (rq * 4 + i) * 2048);
+        }
+        unsigned char *base = img + buf * kWPlaneBytes + (rq >> 1) * kWKgBytes + cq * 16 + (rq & 1) * 8;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float v[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float x = j == 0 ? f[i].x : j == 1 ? f[i].y : j == 2 ? f[i].z : f[i].w;
+                const float s0 = j == 0 ? sh.x : j == 1 ? sh.y : j == 2 ? sh.z : sh.w;
+                v[i] = FULL ? (x - s0) : (x - s0) * m[i];
+                cs[j] += v[i];
+            }
+            const f32x2 p0 = {v[0], v[1]}, p1 = {v[2], v[3]};
+            *reinterpret_cast<uint2 *>(base + j * (132 * 16)) =
+                make_uint2(__builtin_bit_cast(unsigned, __builtin_convertvector(p0, bf16x2)),
+                           __builtin_bit_cast(unsigned, __builtin_convertvector(p1, bf16x2)));
+        }
+    };
+    const int fragoff = (lane >> 5) * kWKgBytes + ((lane & 3) * 132 + ((lane & 31) >> 2)) * 16;
+    auto frag = [&](int buf, int blk) {
+        return *reinterpret_cast<const bf16x8 *>(img + buf * kWPlaneBytes + blk * 128 + fragoff);
+    };
+    auto mma = [&](int buf) {
+        if (DIAGROLE) {
+            bf16x8 F[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) F[q] = frag(buf, ablk0 + q);
+            int idx = 0, full = 0;
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = a; b < 4; ++b) {
+                    if (full != SKIP) {
+                        acc[idx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F[a], F[b], acc[idx], 0, 0, 0);
+                        ++idx;
+                    }
+                    ++full;
+                }
+        } else {
+            bf16x8 A[4], B[2];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) A[q] = frag(buf, ablk0 + q);
+#pragma unroll
+            for (int q = 0; q < 2; ++q) B[q] = frag(buf, bblk0 + q);
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+                    acc[a * 2 + b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[a], B[b], acc[a * 2 + b], 0, 0, 0);
+            if (XOP >= 0) {
+                constexpr int xo = XOP < 0 ? 0 : XOP;
+                const bf16x8 xa = xo < 4 ? A[xo & 3] : B[(xo - 4) & 1];
+                acc[NT - 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa, xa, acc[NT - 1], 0, 0, 0);
+            }
+        }
+    };
+    // LDS writes of this wave done, then the workgroup barrier - WITHOUT touching vmcnt (the DMA queue stays in flight)
+    auto lds_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+
+    // ---- pipeline: k-steps s + 1 .. s + 3 in flight | MFMA on image s & 1 | convert k-step s + 1 | barrier ----
+    issue(0);
+    issue(1);
+    issue(2);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");        // k-step 0 has landed (4 pieces per k-step and wave)
+    convert(0, 0, std::false_type{});
+    lds_barrier();
+    const int nfull = (int)((r1 - r0) / 16);                  // k-steps 0 .. nfull - 1 are complete
+#ifdef GS_WIDE_TRACE_BUILD
+    // measurement build: shader-clock stamps of k-steps 64..79 (see launch_gram_bf16_wide): [0] step start, [1] DMA issued,
+    // [2] MFMAs issued, [3] rows of k-step s + 1 landed, [4] converted, [5] past the barrier
+    const bool tr = trace != nullptr && lane == 0 && (wave == 0 || wave == 6) && ((blockIdx.x & 63) == 0);
+#define GS_GLDS_STAMP(slot)                                                                                     \
+    if (tr && s >= 64 && s < 80) trace[(((blockIdx.x >> 6) * 2 + (wave == 6)) * 16 + (s - 64)) * 8 + (slot)] = clock64()
+#else
+#define GS_GLDS_STAMP(slot)
+#endif
+    // The two waves of a SIMD (w and w + 4) run the two phases of a k-step in OPPOSITE order - one multiplies image s & 1
+    // on the matrix pipe while the other converts k-step s + 1 on the vector ALU (the phases touch different images) - unless
+    // GS_BF16_SAME_ORDER is set (A/B knob read by the launcher and passed in `order`).
+    const bool convert_first = order != 0 && wave >= 4;
+    for (int s = 0; s < nst; ++s) {
+        GS_GLDS_STAMP(0);
+        issue(s + 3);                                         // its stage held k-step s: converted one iteration ago by these very lanes
+        __builtin_amdgcn_sched_barrier(0);
+        GS_GLDS_STAMP(1);
+        if (!convert_first) mma(s & 1);
+        __builtin_amdgcn_sched_barrier(0);
+        GS_GLDS_STAMP(2);
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");    // k-step s + 1 has landed; s + 2 and s + 3 stay in flight
+        GS_GLDS_STAMP(3);
+        if (s + 1 < nfull)
+            convert(s + 1, (s + 1) & 1, std::true_type{});
+        else
+            convert(s + 1, (s + 1) & 1, std::false_type{});
+        __builtin_amdgcn_sched_barrier(0);
+        GS_GLDS_STAMP(4);
+        if (convert_first) mma(s & 1);
+        __builtin_amdgcn_sched_barrier(0);
+        lds_barrier();
+        GS_GLDS_STAMP(5);
+    }
+#undef GS_GLDS_STAMP
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the pieces "after the end" must not land in the epilogue's scratch
+    __syncthreads();
+
+    // ---- epilogue (scratch: the raw ring) ----
+    float *Pc = P + (int64_t)chunk * dp * dp;
+    const int cc = lane & 31, hh = lane >> 5;
+    float *t = reinterpret_cast<float *>(raw + 16384) + wave * (32 * 33);
+    auto mirror = [&](f32x16 &a) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t[((r & 3) + 8 * (r >> 2) + 4 * hh) * 33 + cc] = a[r];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;
+            const float mv = t[cc * 33 + row];
+            if (row > cc) a[r] = mv;
+        }
+    };
+    if (DIAGROLE) {
+        int idx = 0, full = 0;
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = a; b < 4; ++b) {
+                if (full != SKIP) {
+                    if (a == b) mirror(acc[idx]);
+                    float *dst = Pc + (int64_t)((ablk0 + a) * 32 + 4 * hh) * dp + (ablk0 + b) * 32 + cc;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) dst[(int64_t)((r & 3) + 8 * (r >> 2)) * dp] = acc[idx][r];
+                    ++idx;
+                }
+                ++full;
+            }
+    } else {
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                float *dst = Pc + (int64_t)((ablk0 + a) * 32 + 4 * hh) * dp + (bblk0 + b) * 32 + cc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dst[(int64_t)((r & 3) + 8 * (r >> 2)) * dp] = acc[a * 2 + b][r];
+            }
+        if (XOP >= 0) {
+            const int xblk = XOP < 4 ? ablk0 + XOP : bblk0 + (XOP - 4);
+            mirror(acc[NT - 1]);
+            float *dst = Pc + (int64_t)(xblk * 32 + 4 * hh) * dp + xblk * 32 + cc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dst[(int64_t)((r & 3) + 8 * (r >> 2)) * dp] = acc[NT - 1][r];
+        }
+    }
+    {
+        float *scr = reinterpret_cast<float *>(raw);          // [4 row quads][512] below the mirror scratch
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) scr[rq * 512 + 4 * cq + j] = cs[j];
+        __syncthreads();
+        if (half == 0) CS[(int64_t)chunk * dp + tid] = scr[tid] + scr[512 + tid] + scr[1024 + tid] + scr[1536 + tid];
+    }
+}
+
+__global__ __launch_bounds__(kWThreads, 1) void gram_bf16_glds_kernel(
+    const float *__restrict__ X, int64_t rows, int64_t ld, const float *__restrict__ shift, float *__restrict__ P,
+    float *__restrict__ CS, int nchunks, ChunkPlan plan, int ncompute, FoldJob fold, int order) {
+    __shared__ __attribute__((aligned(16))) unsigned char raw[3 * kRawStage];       // 96 KB: ring of raw float32 k-steps
+    __shared__ __attribute__((aligned(16))) unsigned char img[2 * kWPlaneBytes];    // 33 KB: two bf16 images
+    if ((int)blockIdx.x >= ncompute) {
+        fold_elements(fold.P, fold.CS, fold.G64, fold.S1, 512, fold.nchunks, fold.T32, fold.ntiles, fold.accumulate,
+                      (int)blockIdx.x - ncompute, (int)gridDim.x - ncompute, kWThreads);
+        return;
+    }
+    const int b = blockIdx.x;
+    const int xcd = b & 7, local = b >> 3;
+    const int half = local & 1;
+    const int chunk = (local >> 1) * 8 + xcd;
+    if (chunk >= nchunks) return;
+    int64_t r0, r1;
+    chunk_range(plan, chunk, rows, r0, r1);
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+#define GS_GLDS_ARGS X, ld, shift, P, CS, chunk, r0, r1, half, wave, raw, img, order, fold.trace
+    if (wave >= 6) {
+        if (half == 1 && wave == 6)
+            gram_wide_glds_body<true, -1, 4>(GS_GLDS_ARGS);
+        else
+            gram_wide_glds_body<true, -1, 9>(GS_GLDS_ARGS);
+    } else if (half == 0 && wave == 0) {
+        gram_wide_glds_body<false, 3, -1>(GS_GLDS_ARGS);
+    } else if ((half == 0 && wave == 1) || (half == 1 && (wave == 0 || wave == 5))) {
+        gram_wide_glds_body<false, 5, -1>(GS_GLDS_ARGS);
+    } else {
+        gram_wide_glds_body<false, -1, -1>(GS_GLDS_ARGS);
+    }
+#undef GS_GLDS_ARGS
 }
 
 int launch_gram_bf16_wide(int precision, int grid, int nfold, const float *X, int64_t n, int64_t ld, const float *shift,
@@ -738,7 +1040,35 @@ int launch_gram_bf16_wide(int precision, int grid, int nfold, const float *X, in
     }
     // measurement only (results wrong by design): GS_GRAM_ABLATE bit 0 no MFMA, bit 1 no split / LDS writes, bit 2 no loads
     const int ablate = gram_ablate_mask();
-    if (precision == GS_PREC_BF16)
+    // single-plane bf16: the LDS-DMA kernel (GS_BF16_NO_GLDS=1 keeps the register-staged one for A/B runs)
+    static const bool glds = getenv("GS_BF16_NO_GLDS") == nullptr;
+    static const int glds_order = getenv("GS_BF16_SAME_ORDER") == nullptr ? 1 : 0;
+#ifdef GS_WIDE_TRACE_BUILD
+    static int dumped = 0;
+    if (fold.trace != nullptr && precision == GS_PREC_BF16 && dumped < 2) {
+        hipLaunchKernelGGL(gram_bf16_glds_kernel, dim3((unsigned)(grid + nfold)), dim3(kWThreads), 0, stream, X, n, ld, shift, P,
+                           CS, nchunks, plan, grid, fold, glds_order);
+        (void)hipStreamSynchronize(stream);
+        std::vector<unsigned long long> h(4 * 2 * 16 * 8);
+        (void)hipMemcpy(h.data(), fold.trace, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost);
+        if (++dumped == 2)
+            for (int w = 0; w < 8; ++w) {
+                fprintf(stderr, "[glds trace] workgroup %d wave %d: per k-step clk  issue | mfma | wait rows | convert | barrier | whole step\n",
+                        (w >> 1) * 64, (w & 1) ? 6 : 0);
+                for (int st = 0; st + 1 < 16; ++st) {
+                    const unsigned long long *e = &h[(w * 16 + st) * 8], *nx = &h[(w * 16 + st + 1) * 8];
+                    fprintf(stderr, "   k-step %d: %5lld %5lld %5lld %5lld %5lld | %5lld\n", 64 + st, (long long)(e[1] - e[0]),
+                            (long long)(e[2] - e[1]), (long long)(e[3] - e[2]), (long long)(e[4] - e[3]), (long long)(e[5] - e[4]),
+                            (long long)(nx[0] - e[0]));
+                }
+            }
+        return GS_OK;
+    }
+#endif
+    if (precision == GS_PREC_BF16 && glds && ablate == 0)
+        hipLaunchKernelGGL(gram_bf16_glds_kernel, dim3((unsigned)(grid + nfold)), dim3(kWThreads), 0, stream, X, n, ld, shift, P,
+                           CS, nchunks, plan, grid, fold, glds_order);
+    else if (precision == GS_PREC_BF16)
         hipLaunchKernelGGL(gram_bf16_wide_kernel<1>, dim3((unsigned)(grid + nfold)), dim3(kWThreads), lds_bytes, stream, X, n,
                            ld, shift, P, CS, nchunks, plan, grid, fold, ablate);
     else

@@ -501,8 +501,8 @@ constexpr int64_t kSmallSideMaxRows = 16384;   // r = k + rows + 1 of one small-
 
 // contract the resident rows that are still pending: whole launches of kResidentRows, and the rest if `all`
 int resident_flush(gs_ipca *h, bool all, hipStream_t stream) {
-    // (plain bf16: the wide kernel takes 4096-row chunks, i.e. 524 288 rows per launch)
-    const int64_t per_launch = h->prec == GS_PREC_BF16 ? 4 * kResidentRows : kResidentRows;
+    // (plain bf16: the wide kernel takes 8192-row chunks, i.e. 2^20 rows per launch)
+    const int64_t per_launch = h->prec == GS_PREC_BF16 ? 8 * kResidentRows : kResidentRows;
     while (h->res_rows > 0 && (all || h->res_rows >= per_launch)) {
         const int64_t n = h->res_rows < per_launch ? h->res_rows : per_launch;
         int rc = gram_update(h->gws, h->res_ptr, n, h->res_ld, h->d, h->shift, h->G64, h->S1, h->res_acc, /*defer=*/true,
