@@ -390,8 +390,9 @@ def main():
                 run(e2, K)
                 torch.cuda.synchronize()
                 job = time.perf_counter() - t0
-                # the launch the resident path issues: 131 072 rows in one "wide" launch for bf16x3 / bf16 (pairs of
-                # workgroups hold the whole upper triangle); bf16x6 launches are capped at 24 576 rows (no float64 carry)
+                # the launch the resident path issues: one "wide" launch (pairs of workgroups hold the whole upper
+                # triangle) of 131 072 rows for bf16x3 and of up to 2^20 rows for bf16 (8192-row chunks: all the
+                # resident rows of this job); bf16x6 launches are capped at 24 576 rows (no float64 carry)
                 us_p, rt = gram_kernel_us(lib, _lib, e2, RESIDENT_ROWS[:LAUNCH_ROWS * (8 if prec == "bf16" else 1)])
                 mfma_tf = nprod * rt * D * (D + 1) / (us_p * 1e-6) / 1e12
                 gbs = rt * D * 4 / (us_p * 1e-6) / 1e9
@@ -415,15 +416,16 @@ def main():
                     hb_traffic = pm.get("hbm_bytes_per_launch")
             except Exception:
                 pass
-            out["roofline_hbm"] = {"bound": "hbm", "kernel": "gram_bf16_wide_kernel<1> (precision=\"bf16\", opt-in)",
+            out["roofline_hbm"] = {"bound": "hbm", "kernel": "gram_bf16_glds_kernel (precision=\"bf16\", opt-in)",
                                    "achieved": b["roofline"]["achieved"], "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                    "frac": b["roofline"]["frac"], "traffic": hb_traffic,
                                    "avg_launch_us": b["gram_launch_us"], "rows_per_launch": b["rows_per_launch"],
                                    "algorithmic_bytes_per_launch": b["rows_per_launch"] * D * 4,
                                    "samples_per_s_whole_job": b["samples_per_s"],
                                    "top20_min_signed_cos_vs_sklearn": b["top20_min_signed_cos"],
-                                   "read_ceiling_note": "a plain streaming-read kernel reaches 6.0-6.2 TB/s on this chip "
-                                                        "(tools/ubench/read_bw.hip, profiles/r03_probes.md)"}
+                                   "read_ceiling_note": "a streaming-read kernel with this access pattern and no arithmetic "
+                                                        "reaches 5.45 TB/s on this chip (tools/ubench/read_bw.hip, "
+                                                        "profiles/r03_probes.md)"}
 
     # ---- the wide-feature BASELINE shapes (cfg3 d = 32 768, cfg5 d = 131 072; NB = 2 000, k = 80): PCA-only
     #      throughput of the small-side recurrence on the synthetic low-rank-plus-noise blocks of SURVEY.md 8d item 5,

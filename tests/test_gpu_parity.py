@@ -747,3 +747,30 @@ def test_plain_bf16_contraction_keeps_the_leading_components(dev):
     G32, _ = ops.gram_accumulate(Xd[:131072])
     scale = torch.sqrt(torch.outer(torch.diag(G32), torch.diag(G32)))
     assert float(((G - G32) / scale).abs().max()) < 2e-4
+
+
+@pytest.mark.parametrize("rows", [1_000_000, 1_048_576 + 4_099])
+def test_plain_bf16_contraction_at_the_benchmarked_launch_size(dev, rows):
+    """The launch ``bench.py`` prices for ``roofline_hbm``: all the resident rows of the cfg2 job in ONE
+    ``gram_bf16_glds_kernel`` launch (8192-row chunks, 2^20 rows at most; a second launch takes the rest) against a
+    float64 contraction of the same device rows (torch float64 matmul as the checker).  Column sums come from the
+    float32 rows, not from their bf16 images: float32-exact."""
+    from ganspace_amd import ops
+    g = torch.Generator(device=dev).manual_seed(rows)
+    d = 512
+    X = torch.randn(rows, d, device=dev, generator=g) * torch.linspace(0.3, 2.5, d, device=dev) + 0.4
+    shift = X[:4096].mean(0) + 0.01
+    G, cs = ops.gram_accumulate(X, shift=shift, precision="bf16")
+    Gref = torch.zeros(d, d, dtype=torch.float64, device=dev)
+    csref = torch.zeros(d, dtype=torch.float64, device=dev)
+    absum = torch.zeros(d, dtype=torch.float64, device=dev)
+    for lo in range(0, rows, 131072):
+        Xc = X[lo:lo + 131072].double() - shift.double()
+        Gref += Xc.T @ Xc
+        csref += Xc.sum(0)
+        absum += Xc.abs().sum(0)
+    scale = torch.sqrt(torch.outer(torch.diag(Gref), torch.diag(Gref)))
+    err = float(((G.double() - Gref) / scale).abs().max())
+    assert err < 1e-4, err                                  # ~2^-9 / sqrt(rows) per entry; 4e-3 is the per-product bound
+    assert float((cs.double() - csref).abs().max()) <= 2e-6 * float(absum.max())
+    assert float((G - G.T).abs().max()) == 0.0

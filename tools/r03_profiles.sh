@@ -15,10 +15,10 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/ss32_trace -o s -- py
 # 2. PMC: HBM traffic of the Gram kernels (f32 wide, bf16 wide) and of the small-side kernels
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_f32_$c -o p -- python tools/gram_probe.py 131072 512 f32 > /dev/null 2>&1
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_bf16_$c -o p -- python tools/gram_probe.py 524288 512 bf16 > /dev/null 2>&1
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_bf16_$c -o p -- python tools/gram_probe.py 1000000 512 bf16 > /dev/null 2>&1
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_ss_$c -o p -- python tools/smallside_probe.py 131072 2000 80 8 bf16x6 > /dev/null 2>&1
 done
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_f32_sq -o p -- python tools/gram_probe.py 131072 512 f32 > /dev/null 2>&1
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_bf16_sq -o p -- python tools/gram_probe.py 524288 512 bf16 > /dev/null 2>&1
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_bf16_sq -o p -- python tools/gram_probe.py 1000000 512 bf16 > /dev/null 2>&1
 python tools/summarize_r03.py $O > $O/summary.md 2> $O/summary.err
 cat $O/summary.md | head -150

@@ -38,7 +38,7 @@ for sub in ("bench_trace", "finalize_trace", "ss131_trace", "ss131f_trace", "ss3
 print("## PMC passes (averages per launch; FETCH_SIZE x 2 per the guide's gfx950 correction)\n")
 print("| run | kernel | counter | avg per launch | launches |\n|---|---|---|---|---|")
 latest = {}
-for tag, rows in (("f32", 131072), ("bf16", 524288), ("ss", None)):
+for tag, rows in (("f32", 131072), ("bf16", 1000000), ("ss", None)):
     merged = collections.defaultdict(dict)
     for c in ("FETCH_SIZE", "WRITE_SIZE", "sq"):
         for k, v in pmc(f"pmc_{tag}_{c}").items():
@@ -52,7 +52,7 @@ for tag, rows in (("f32", 131072), ("bf16", 524288), ("ss", None)):
             if cn == "WRITE_SIZE":
                 note = f" KiB = {avg*1024/1e6:.1f} MB written"
             print(f"| {tag} | `{k}` | {cn} | {avg:.1f}{note} | {n} |")
-        if rows and ("wide" in k) and "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+        if rows and ("wide" in k or "glds" in k) and "FETCH_SIZE" in v and "WRITE_SIZE" in v:
             rd, wr = v["FETCH_SIZE"][0] * 2 * 1024, v["WRITE_SIZE"][0] * 1024
             latest[tag] = {"kernel": k, "rows_per_launch": rows, "hbm_read_bytes_per_launch_corrected_x2": int(rd),
                            "hbm_write_bytes_per_launch": int(wr), "hbm_bytes_per_launch": int(rd + wr),
