@@ -394,10 +394,20 @@ def main():
                 # triangle) of 131 072 rows for bf16x3 and of up to 2^20 rows for bf16 (8192-row chunks: all the
                 # resident rows of this job); bf16x6 launches are capped at 24 576 rows (no float64 carry)
                 us_p, rt = gram_kernel_us(lib, _lib, e2, RESIDENT_ROWS[:LAUNCH_ROWS * (8 if prec == "bf16" else 1)])
+                us_randn = None
+                if prec == "bf16":
+                    # the same launch on N(0,1) rows of the same shape: the kernel's duration depends on the DATA
+                    # (bit toggling -> power -> clock), so both are reported; `roofline_hbm` prices the job's own rows
+                    Xr = torch.randn(rt, D, device=dev)
+                    us_randn, _ = gram_kernel_us(lib, _lib, e2, Xr)
+                    del Xr
                 mfma_tf = nprod * rt * D * (D + 1) / (us_p * 1e-6) / 1e12
                 gbs = rt * D * 4 / (us_p * 1e-6) / 1e9
                 split[prec] = {"samples_per_s": round(n_blocks * NB / job, 1), "gram_launch_us": round(us_p, 2),
                                "rows_per_launch": rt,
+                               **({"gram_launch_us_on_randn_rows": round(us_randn, 2),
+                                   "hbm_frac_on_randn_rows": round(rt * D * 4 / (us_randn * 1e-6) / 1e9 / PEAK_HBM_GBS, 4)}
+                                  if us_randn else {}),
                                "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS,
                                             "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4)},
                                "bf16_mfma_TFLOPs_executed": round(mfma_tf, 1),
@@ -420,6 +430,8 @@ def main():
                                    "achieved": b["roofline"]["achieved"], "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                    "frac": b["roofline"]["frac"], "traffic": hb_traffic,
                                    "avg_launch_us": b["gram_launch_us"], "rows_per_launch": b["rows_per_launch"],
+                                   "avg_launch_us_on_randn_rows": b.get("gram_launch_us_on_randn_rows"),
+                                   "frac_on_randn_rows": b.get("hbm_frac_on_randn_rows"),
                                    "algorithmic_bytes_per_launch": b["rows_per_launch"] * D * 4,
                                    "samples_per_s_whole_job": b["samples_per_s"],
                                    "top20_min_signed_cos_vs_sklearn": b["top20_min_signed_cos"],

@@ -6,6 +6,8 @@ R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp && cd "$R"
 O=gpurun_out/r03p; mkdir -p $O
 tools/ubench/read_bw > $O/read_bw.log 2>&1
+for r in 1000000 524288 131072; do python tools/gram_probe.py $r 512 bf16 2>&1 | grep gram_partial | tail -1 >> $O/gram_probe.log; done
+python tools/gram_probe.py 131072 512 f32 2>&1 | grep gram_partial | tail -1 >> $O/gram_probe.log
 # 1. kernel stats: headline job (+ modes), finalize / faithful chains, small side at d = 131 072 and 32 768
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/bench_trace -o b -- python bench.py --no-cpu-baseline --no-wide > $O/bench_profiled.json 2> /dev/null
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/finalize_trace -o f -- python tools/finalize_trace.py 100 6 both > $O/finalize_trace.log 2> /dev/null
