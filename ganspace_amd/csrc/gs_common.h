@@ -135,6 +135,14 @@ struct GramWorkspace {
     int pend_buf = 0, pend_nchunks = 0;
     bool pend_acc = false;         // fold adds to (true) or overwrites (false) the accumulators
     unsigned long long *pace = nullptr;   // [max_chunks][macro tiles] progress words (see FoldJob::pace)
+    // "wide" launches (d = 512, every CU holds one compute workgroup): the slabs of launch t are folded by a small
+    // kernel on `aux` WHILE launch t + 1 computes (its waves fit next to the compute waves: no LDS, <= 48 VGPRs) -
+    // spare workgroups of the compute kernel itself inherit its LDS / register footprint and only run once the
+    // compute workgroups have retired (measured: +50-70 us per 131 072-row launch)
+    hipStream_t aux = nullptr;
+    hipEvent_t ev_comp[2] = {nullptr, nullptr};    // slabs of set i are complete (recorded on the caller's stream)
+    hipEvent_t ev_fold[2] = {nullptr, nullptr};    // slabs of set i are folded (recorded on aux)
+    bool aux_busy[2] = {false, false};             // a fold on aux that the caller's stream has not waited for yet
 };
 
 int gram_workspace_alloc(GramWorkspace &ws, int64_t d);
@@ -146,8 +154,10 @@ void gram_workspace_free(GramWorkspace &ws);
 // defer = true leaves the fold of this launch's slabs to the NEXT launch (or to gram_flush).
 int gram_update(GramWorkspace &ws, const float *X, int64_t rows, int64_t ld, int64_t d, const float *shift,
                 double *G64, double *S1, bool accumulate, bool defer, hipStream_t stream);
-// fold whatever is still pending into G64 / S1
+// fold whatever is still pending into G64 / S1 (and order `stream` behind the folds running on ws.aux)
 int gram_flush(GramWorkspace &ws, double *G64, double *S1, hipStream_t stream);
+// forget pending slabs (reset / state import); waits for the folds in flight on ws.aux (host-side)
+void gram_discard_pending(GramWorkspace &ws);
 
 // average duration of the partial-Gram kernel alone (HIP events on `stream`)
 int gram_partial_time(GramWorkspace &ws, const float *X, int64_t rows, int64_t ld, int64_t d,

@@ -536,6 +536,60 @@ __global__ __launch_bounds__(kThreads, 1) void gram_partial_kernel(
     gram_tile_dispatch<VEC, LONG>(c, lds);
 }
 
+// The fold of a wide launch's slabs, small enough to run NEXT TO the following launch's compute workgroups (those
+// leave 48 VGPRs per SIMD lane and no LDS): two chunks in flight per thread instead of eight (it has a whole
+// compute launch of time: 71 MB in ~300 us).
+__global__ __launch_bounds__(256) void gram_fold_light_kernel(const float *__restrict__ P, const float *__restrict__ CS,
+                                                              double *__restrict__ G64, double *__restrict__ S1, int dp,
+                                                              int nchunks, int T32, int ntiles, int accumulate) {
+    const int64_t stride = (int64_t)dp * dp;
+    const int ngroups = ntiles * 256;
+    const int total = ngroups + dp;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
+        if (e < ngroups) {
+            int ti, tj;
+            decode_upper(e >> 8, T32, ti, tj);
+            const int w = e & 255;
+            const int64_t off = (int64_t)(ti * kSubTile + (w >> 3)) * dp + tj * kSubTile + (w & 7) * 4;
+            const float *p = P + off;
+            double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+            int c = 0;
+            for (; c + 2 <= nchunks; c += 2) {
+                const float4 a = *reinterpret_cast<const float4 *>(p), b = *reinterpret_cast<const float4 *>(p + stride);
+                p += 2 * stride;
+                s0 += (double)a.x + (double)b.x;
+                s1 += (double)a.y + (double)b.y;
+                s2 += (double)a.z + (double)b.z;
+                s3 += (double)a.w + (double)b.w;
+            }
+            for (; c < nchunks; ++c, p += stride) {
+                const float4 a = *reinterpret_cast<const float4 *>(p);
+                s0 += a.x;
+                s1 += a.y;
+                s2 += a.z;
+                s3 += a.w;
+            }
+            double *g = G64 + off;
+            if (accumulate) {
+                g[0] += s0;
+                g[1] += s1;
+                g[2] += s2;
+                g[3] += s3;
+            } else {
+                g[0] = s0;
+                g[1] = s1;
+                g[2] = s2;
+                g[3] = s3;
+            }
+        } else {
+            const int j = e - ngroups;
+            double t = 0;
+            for (int c = 0; c < nchunks; ++c) t += CS[(int64_t)c * dp + j];
+            S1[j] = accumulate ? S1[j] + t : t;
+        }
+    }
+}
+
 // Stand-alone fold (faithful mode needs the block's Gram immediately; also the final flush).
 __global__ __launch_bounds__(256) void gram_fold_kernel(const float *__restrict__ P,
                                                         const float *__restrict__ CS,
@@ -559,12 +613,27 @@ int gram_workspace_alloc(GramWorkspace &ws, int64_t d) {
         GS_HIP_CHECK(hipMalloc(&ws.partial[i], sizeof(float) * ws.max_chunks * ws.dp * ws.dp));
         GS_HIP_CHECK(hipMalloc(&ws.colsum_partial[i], sizeof(float) * ws.max_chunks * ws.dp));
     }
+    if (ws.dp == 512 && getenv("GS_GRAM_NO_AUX_FOLD") == nullptr) {
+        GS_HIP_CHECK(hipStreamCreateWithFlags(&ws.aux, hipStreamNonBlocking));
+        for (int i = 0; i < 2; ++i) {
+            GS_HIP_CHECK(hipEventCreateWithFlags(&ws.ev_comp[i], hipEventDisableTiming));
+            GS_HIP_CHECK(hipEventCreateWithFlags(&ws.ev_fold[i], hipEventDisableTiming));
+        }
+    }
     GS_HIP_CHECK(hipMalloc(&ws.pace, sizeof(unsigned long long) * ws.max_chunks * nmt));
     GS_HIP_CHECK(hipMemset(ws.pace, 0, sizeof(unsigned long long) * ws.max_chunks * nmt));
     return GS_OK;
 }
 
 void gram_workspace_free(GramWorkspace &ws) {
+    if (ws.aux) {
+        (void)hipStreamSynchronize(ws.aux);      // a fold may still be reading the slabs freed below
+        (void)hipStreamDestroy(ws.aux);
+        for (int i = 0; i < 2; ++i) {
+            if (ws.ev_comp[i]) (void)hipEventDestroy(ws.ev_comp[i]);
+            if (ws.ev_fold[i]) (void)hipEventDestroy(ws.ev_fold[i]);
+        }
+    }
     for (int i = 0; i < 2; ++i) {
         if (ws.partial[i]) (void)hipFree(ws.partial[i]);
         if (ws.colsum_partial[i]) (void)hipFree(ws.colsum_partial[i]);
@@ -785,7 +854,25 @@ static FoldJob pending_job(const GramWorkspace &ws, double *G64, double *S1) {
     return f;
 }
 
+// order `stream` behind every fold still running on ws.aux
+static int aux_join(GramWorkspace &ws, hipStream_t stream) {
+    for (int i = 0; i < 2; ++i)
+        if (ws.aux_busy[i]) {
+            GS_HIP_CHECK(hipStreamWaitEvent(stream, ws.ev_fold[i], 0));
+            ws.aux_busy[i] = false;
+        }
+    return GS_OK;
+}
+
+void gram_discard_pending(GramWorkspace &ws) {
+    if (ws.aux && (ws.aux_busy[0] || ws.aux_busy[1])) (void)hipStreamSynchronize(ws.aux);
+    ws.aux_busy[0] = ws.aux_busy[1] = false;
+    ws.pend_valid = false;
+}
+
 int gram_flush(GramWorkspace &ws, double *G64, double *S1, hipStream_t stream) {
+    const int rcj = aux_join(ws, stream);
+    if (rcj != GS_OK) return rcj;
     if (!ws.pend_valid) return GS_OK;
     const FoldJob f = pending_job(ws, G64, S1);
     const int grid = f.ntiles + (int)ceil_div(ws.dp, 256);
@@ -805,6 +892,36 @@ int gram_update(GramWorkspace &ws, const float *X, int64_t rows, int64_t ld, int
     for (int64_t base = 0; base < rows; base += rows_per_launch) {
         const int64_t n = (rows - base < rows_per_launch) ? rows - base : rows_per_launch;
         const GramGeom g = gram_geometry(ws, n, al);
+        // (the three-plane kernel needs 250 VGPRs per wave: no room for a fold wave next to it - it keeps the spare
+        //  workgroups, whose eight chunks in flight fold faster once the CUs are free)
+        if (g.wide && ws.aux != nullptr && ws.precision != GS_PREC_BF16X3) {
+            // slabs of a tiled launch still pending: fold them on this stream first (the fold below is ordered behind it
+            // through ev_comp)
+            if (ws.pend_valid) {
+                int rcw = gram_flush(ws, G64, S1, stream);
+                if (rcw != GS_OK) return rcw;
+            }
+            const int buf = ws.cur;
+            if (ws.aux_busy[buf]) {       // the fold of the launch before the previous one read this slab set
+                GS_HIP_CHECK(hipStreamWaitEvent(stream, ws.ev_fold[buf], 0));
+                ws.aux_busy[buf] = false;
+            }
+            launch_partial(ws, g, buf, X + base * ld, n, ld, d, shift, FoldJob{}, stream);
+            GS_HIP_CHECK(hipEventRecord(ws.ev_comp[buf], stream));
+            GS_HIP_CHECK(hipStreamWaitEvent(ws.aux, ws.ev_comp[buf], 0));
+            const int T32 = (int)ws.dp / kSubTile, ntiles = T32 * (T32 + 1) / 2;
+            hipLaunchKernelGGL(gram_fold_light_kernel, dim3(256), dim3(256), 0, ws.aux, ws.partial[buf],
+                               ws.colsum_partial[buf], G64, S1, (int)ws.dp, g.nchunks, T32, ntiles, acc ? 1 : 0);
+            GS_HIP_CHECK(hipEventRecord(ws.ev_fold[buf], ws.aux));
+            ws.aux_busy[buf] = true;
+            ws.cur ^= 1;
+            acc = true;
+            continue;
+        }
+        {
+            const int rcj = aux_join(ws, stream);       // (tiled launches fold on this stream: behind the aux folds)
+            if (rcj != GS_OK) return rcj;
+        }
         // the previous launch's slabs are folded by this launch's spare workgroups
         const FoldJob f = pending_job(ws, G64, S1);
         const int buf = ws.cur;
@@ -825,6 +942,10 @@ int gram_update(GramWorkspace &ws, const float *X, int64_t rows, int64_t ld, int
 int gram_partial_time(GramWorkspace &ws, const float *X, int64_t rows, int64_t ld, int64_t d,
                       const float *shift, int iters, float *avg_ms, hipStream_t stream, int64_t *rows_timed) {
     const FoldJob nofold = {};
+    {
+        const int rcj = aux_join(ws, stream);
+        if (rcj != GS_OK) return rcj;
+    }
     const int buf = ws.pend_valid ? (ws.pend_buf ^ 1) : ws.cur;  // never clobber slabs that still wait for a fold
     const GramGeom g = gram_geometry(ws, rows, (ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0));
     const int64_t n = rows < g.rows_per_launch ? rows : g.rows_per_launch;

@@ -801,7 +801,7 @@ int gs_ipca_reset(gs_ipca_t *h) {
     h->n_seen = 0;
     h->blocks = 0;
     h->finalized = false;
-    h->gws.pend_valid = false;
+    gram_discard_pending(h->gws);
     h->sws.guards_valid = false;
     h->sws.plan_valid = false;
     h->sws.inv_plan = 0;
@@ -980,7 +980,7 @@ int gs_ipca_state_import(gs_ipca_t *h, const double *state, void *stream_) {
     GS_HIP_CHECK(hipMemcpyAsync(&n, state, sizeof(double), hipMemcpyDeviceToHost, stream));
     GS_HIP_CHECK(hipStreamSynchronize(stream));
     GS_REQUIRE(n >= 0 && n == std::floor(n), GS_EINVAL, "gs_ipca_state_import: bad sample count");
-    h->gws.pend_valid = false;  // the imported state replaces everything accumulated so far
+    gram_discard_pending(h->gws);  // the imported state replaces everything accumulated so far
     h->res_ptr = nullptr;
     h->res_rows = 0;
     h->res_acc = n > 0;
