@@ -205,6 +205,7 @@ def main():
         gram_view = blocks[0]
         n_launches = n_blocks
     us, rows_l = gram_kernel_us(lib, _lib, est2, gram_view)
+    us_first = gram_kernel_us.first
     flops = rows_l * D * (D + 1)           # algorithmic: upper triangle incl. diagonal, 2 flop/MAC
     bytes_ = rows_l * D * 4                # algorithmic: one read of the [rows, d] f32 block
     ach_tf = flops / (us * 1e-6) / 1e12
@@ -216,9 +217,14 @@ def main():
     try:
         with open(os.path.join(ROOT, "profiles", "gram_pmc_latest.json")) as f:
             pmc = json.load(f)
+        pmc = pmc.get("f32", pmc)              # (tools/summarize_r03.py writes one section per precision)
         if pmc.get("rows_per_launch") == rows_l:
             traffic = pmc.get("hbm_bytes_per_launch", pmc["hbm_read_bytes_per_launch_corrected_x2"])
-            traffic_note = pmc.get("traffic_breakdown")
+            traffic_note = pmc.get("traffic_breakdown") or (
+                "%.1f MB read + %.1f MB written per launch against %.1f MB of X rows (algorithmic): the rows are fetched "
+                "once; the rest is the float32 partial-Gram slabs (written by this launch, read back by the fold)"
+                % (pmc["hbm_read_bytes_per_launch_corrected_x2"] / 1e6, pmc["hbm_write_bytes_per_launch"] / 1e6,
+                   bytes_ / 1e6))
     except Exception:
         pass
     frac_of_region = (n_launches * us * 1e-6) / (t_updates + t_final) if (t_updates + t_final) > 0 else None
@@ -227,7 +233,10 @@ def main():
                 "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach_tf / PEAK_F32_MFMA_TFLOPS, 4),
                 "traffic": traffic, "traffic_source": "profiles/gram_pmc_latest.json (rocprofv3 --pmc: FETCH_SIZE x2 + WRITE_SIZE)",
                 "traffic_note": traffic_note,
-                "avg_launch_us": round(us, 2), "rows_per_launch": rows_l, "launches_in_timed_region": n_launches,
+                "avg_launch_us": round(us, 2), "avg_launch_us_first_repetition": round(us_first, 2),
+                "launch_timing": "HIP events around 50 back-to-back launches on the estimator's stream, third repetition "
+                                 "(the first one follows host-side phases and runs while the clocks ramp up)",
+                "rows_per_launch": rows_l, "launches_in_timed_region": n_launches,
                 "share_of_timed_region": None if frac_of_region is None else round(frac_of_region, 3),
                 "algorithmic_flops_per_launch": flops, "algorithmic_bytes_per_launch": bytes_,
                 "hbm_achieved_GBs": round(ach_gbs, 1), "hbm_frac_of_8TBs": round(ach_gbs / PEAK_HBM_GBS, 4),
