@@ -41,6 +41,7 @@ import torch
 D, NB, K_COMP = 512, 10_000, 80
 BLOCKS_PER_STEP = 5
 RESIDENT_ROWS = None              # set by make_blocks: this rank's W-space rows as one contiguous view
+MODEL_SETUP_S = None              # set by make_blocks: construction of the random-init generator (not part of T_sample)
 LAUNCH_ROWS = 131072              # rows per Gram launch when the estimator may merge resident rows (gs_ipca_update_resident)
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_HBM_GBS = 8000.0             # HBM3E spec
@@ -54,12 +55,17 @@ def log(*a):
 def make_blocks(n_blocks, dev, rank=0, world=1):
     """The W-space rows the "Fitting batches" loop of cfg2 reads (decomposition.py:245-267), for this rank's share of
     an n = world x n_blocks x NB job: product path end to end (seed protocol -> parallel z generation -> pinned
-    H2D -> PixelNorm + 8-layer mapping kernel), resident in HBM.  Returns (list of [NB, 512] blocks, seconds)."""
+    H2D -> PixelNorm + 8-layer mapping kernel), resident in HBM.  Returns (blocks, step views, seconds of the
+    pre-sampling phase = decomposition.py:226-236, model); building the model is timed apart (MODEL_SETUP_S)."""
     from ganspace_amd import decomposition as dec
     from ganspace_amd.wrappers import get_model
+    global MODEL_SETUP_S
     t0 = time.perf_counter()
     model = get_model("StyleGAN2", "ffhq", dev)
     model.use_w()
+    torch.cuda.synchronize()
+    MODEL_SETUP_S = time.perf_counter() - t0      # (the reference builds its model before the phase timed below)
+    t0 = time.perf_counter()
     plan = dec._Plan.make(world * n_blocks * NB, NB, K_COMP)
     assert plan.NB == NB and len(list(plan.block_starts)) == world * n_blocks
     starts = plan.shard_blocks(rank, world)
@@ -258,6 +264,7 @@ def main():
         "roofline": roofline,
         "breakdown": {"update_loop_s": round(t_updates, 5), "finalize_eigensolve_s": round(t_final, 5),
                       "sampling_zgen_plus_mapping_s": round(t_sample, 4),
+                      "model_setup_s": None if MODEL_SETUP_S is None else round(MODEL_SETUP_S, 4),
                       "eigh_products": int(lib.gs_ipca_last_mults(est2.transformer._h)),
                       "eigh_sweeps": int(lib.gs_ipca_last_sweeps(est2.transformer._h))},
     }

@@ -92,6 +92,47 @@ struct Mt19937 {
         has_gauss = true;
         return f * x2;
     }
+
+    // `count` values of next_gauss() from a freshly seeded stream, cast to float32 - the same numbers in the same
+    // order, produced in three passes per chunk of candidate pairs: (1) draw the candidates (the serial part: the
+    // generator), (2) keep the accepted ones, (3) log / divide / sqrt of the accepted pairs in a loop whose iterations
+    // are independent, so that the core overlaps their latencies (one value at a time, every pair waits for its own
+    // log -> divide -> sqrt chain and a mispredicted rejection branch flushes it).  Candidates drawn beyond the last
+    // pair that is needed are discarded: the stream is private to this batch (RandomState(seed) in the reference).
+    void fill_float(float *out, int64_t count) {
+        constexpr int CH = 512;
+        double x1[CH], x2[CH], r2[CH];
+        int keep[CH];
+        int64_t p = 0;
+        while (p < count) {
+            for (int j = 0; j < CH; ++j) {
+                x1[j] = 2.0 * next_double() - 1.0;
+                x2[j] = 2.0 * next_double() - 1.0;
+                r2[j] = x1[j] * x1[j] + x2[j] * x2[j];
+            }
+            int n = 0;
+            for (int j = 0; j < CH; ++j) {
+                keep[n] = j;
+                n += (r2[j] < 1.0 && r2[j] != 0.0) ? 1 : 0;
+            }
+            const int64_t pairs_left = (count - p + 1) / 2;
+            if ((int64_t)n > pairs_left) n = (int)pairs_left;
+            const bool half = (int64_t)2 * n > count - p;       // odd count: the last pair gives only its first value
+            const int whole = half ? n - 1 : n;
+            for (int a = 0; a < whole; ++a) {
+                const int j = keep[a];
+                const double f = std::sqrt(-2.0 * std::log(r2[j]) / r2[j]);
+                out[p + 2 * a] = (float)(f * x2[j]);
+                out[p + 2 * a + 1] = (float)(f * x1[j]);
+            }
+            p += 2 * (int64_t)whole;
+            if (half) {
+                const int j = keep[n - 1];
+                const double f = std::sqrt(-2.0 * std::log(r2[j]) / r2[j]);
+                out[p++] = (float)(f * x2[j]);
+            }
+        }
+    }
 };
 
 }  // namespace
@@ -124,7 +165,7 @@ void zgen_worker(gs_zgen *z) {
         }
         rng.seed(z->seeds[(size_t)i]);
         float *out = z->slots[(size_t)(i % ring)];
-        for (int64_t e = 0; e < z->count; ++e) out[e] = (float)rng.next_gauss();
+        rng.fill_float(out, z->count);
         {
             std::lock_guard<std::mutex> lk(z->mu);
             z->done[(size_t)i] = 1;
@@ -141,7 +182,7 @@ int gs_zgen_fill(uint32_t seed, int64_t count, float *out_host) {
     GS_REQUIRE(out_host != nullptr && count >= 0, GS_EINVAL, "gs_zgen_fill: bad argument");
     Mt19937 rng;
     rng.seed(seed);
-    for (int64_t e = 0; e < count; ++e) out_host[e] = (float)rng.next_gauss();
+    rng.fill_float(out_host, count);
     return GS_OK;
 }
 

@@ -137,6 +137,25 @@ def test_native_z_generator_is_bit_identical_to_numpy_randomstate():
     np.testing.assert_allclose(first, [0.76455638, -1.12429114, -0.13731647, 0.52814697], rtol=1e-6)
 
 
+def test_native_z_generator_chunk_boundaries_and_short_counts():
+    """The generator draws candidate pairs 512 at a time and evaluates the accepted ones in a separate pass (the
+    latency chain log -> divide -> sqrt of one pair no longer serialises the next): every count from 0 to 40, counts
+    around the number of values one chunk yields (~ 2 * 512 * pi / 4 = 804), odd counts (the last pair gives one
+    value) - all identical to ``RandomState(seed).standard_normal(count)``."""
+    import ctypes as C
+    from ganspace_amd import _lib
+    lib = _lib.load()
+    rs = np.random.RandomState(11)
+    counts = list(range(41)) + list(range(780, 830)) + [1607, 1608, 1609, 2411, 5119, 30_001]
+    for count in counts:
+        for seed in (3, int(rs.randint(0, 2 ** 31 - 1))):
+            out = np.full(count + 2, 7.0, np.float32)
+            assert lib.gs_zgen_fill(seed, count, out.ctypes.data_as(C.c_void_p)) == 0
+            ref = np.random.RandomState(seed).standard_normal(count).astype(np.float32)
+            assert out[:count].tobytes() == ref.tobytes(), (seed, count)
+            assert out[count] == 7.0 and out[count + 1] == 7.0          # nothing written past the end
+
+
 def test_native_z_stream_ring_backpressure_and_order():
     """More batches than ring slots, more threads than cores: batches come out in order, each equal to the NumPy
     stream of its seed, while slots are recycled only after release()."""
