@@ -138,15 +138,15 @@ def test_native_z_generator_is_bit_identical_to_numpy_randomstate():
 
 
 def test_native_z_generator_chunk_boundaries_and_short_counts():
-    """The generator draws candidate pairs 512 at a time and evaluates the accepted ones in a separate pass (the
-    latency chain log -> divide -> sqrt of one pair no longer serialises the next): every count from 0 to 40, counts
-    around the number of values one chunk yields (~ 2 * 512 * pi / 4 = 804), odd counts (the last pair gives one
-    value) - all identical to ``RandomState(seed).standard_normal(count)``."""
+    """The generator works on blocks of 624 MT19937 draws = 156 candidate pairs and evaluates the accepted ones in a
+    separate pass (the latency chain log -> divide -> sqrt of one pair no longer serialises the next): every count
+    from 0 to 40, counts around the number of values one block yields (~ 2 * 156 * pi / 4 = 245) and a few blocks
+    yield, odd counts (the last pair gives one value) - all identical to ``RandomState(seed).standard_normal(count)``."""
     import ctypes as C
     from ganspace_amd import _lib
     lib = _lib.load()
     rs = np.random.RandomState(11)
-    counts = list(range(41)) + list(range(780, 830)) + [1607, 1608, 1609, 2411, 5119, 30_001]
+    counts = list(range(41)) + list(range(225, 265)) + list(range(480, 500)) + [1607, 1608, 1609, 2411, 5119, 30_001]
     for count in counts:
         for seed in (3, int(rs.randint(0, 2 ** 31 - 1))):
             out = np.full(count + 2, 7.0, np.float32)
