@@ -63,7 +63,9 @@ class NativeNormalStream:
         nb = len(self.seeds)
         env = os.environ.get("GANSPACE_ZGEN_THREADS")
         if threads is None:
-            threads = int(env) if env else min(64, os.cpu_count() or 1)
+            # (ranks of one node share its cores: torch.distributed.run exports LOCAL_WORLD_SIZE)
+            local_world = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1") or 1))
+            threads = int(env) if env else min(64, max(1, (os.cpu_count() or 1) // local_world))
         threads = max(1, min(int(threads), max(nb, 1)))
         n_slots = min(max(nb, 1), threads + 4)
         if pinned is None:
