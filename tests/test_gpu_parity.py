@@ -774,3 +774,27 @@ def test_plain_bf16_contraction_at_the_benchmarked_launch_size(dev, rows):
     assert err < 1e-4, err                                  # ~2^-9 / sqrt(rows) per entry; 4e-3 is the per-product bound
     assert float((cs.double() - csref).abs().max()) <= 2e-6 * float(absum.max())
     assert float((G - G.T).abs().max()) == 0.0
+
+
+def test_second_stream_fold_equals_in_launch_fold(tmp_path):
+    """Wide launches (d = 512, >= 20 000 rows) fold their float32 slabs into the float64 accumulators on a second stream
+    while the next launch computes (``gram_fold_light_kernel``, ordered by events); ``GS_GRAM_NO_AUX_FOLD=1`` keeps the
+    folds on the spare workgroups of the next launch.  Same slabs, same float64 additions per element: faithful and
+    exact estimators on 30 000-row blocks agree to rounding (``tools/aux_fold_check.py``, one process per variant -
+    the switch is read when the workspace is created)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for tag, extra in (("aux", {}), ("inline", {"GS_GRAM_NO_AUX_FOLD": "1"})):
+        path = str(tmp_path / f"{tag}.npy")
+        env = {k: v for k, v in os.environ.items() if k != "GS_GRAM_NO_AUX_FOLD"}
+        env.update(extra)
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "aux_fold_check.py"), path], cwd=root, env=env,
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-3000:]
+        outs.append(np.load(path))
+    a, b = outs
+    assert a.shape == b.shape and np.isfinite(a).all()
+    assert np.abs(a - b).max() <= 1e-10 * max(1.0, np.abs(a).max())
