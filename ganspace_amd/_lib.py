@@ -45,6 +45,8 @@ SIGNATURES = {
     "gs_column_moments": (_int, [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp]),
     "gs_zgen_fill": (C.c_int, [C.c_uint32, _i64, _vp]),
     "gs_zgen_start": (_int, [_vp, _i64, _i64, _vp, _int, _int, C.POINTER(_vp)]),
+    "gs_zgen_fill_truncnorm": (_int, [C.c_uint32, _i64, C.c_double, C.c_double, _f32, _vp]),
+    "gs_zgen_start_truncnorm": (_int, [_vp, _i64, _i64, _vp, _int, _int, C.c_double, C.c_double, _f32, C.POINTER(_vp)]),
     "gs_zgen_wait": (_int, [_vp, _i64, C.POINTER(_vp)]),
     "gs_zgen_release": (_int, [_vp, _i64]),
     "gs_zgen_finish": (_int, [_vp]),
@@ -55,6 +57,8 @@ SIGNATURES = {
     "gs_eigh_topk": (_int, [_vp, _int, _int, _vp, _int, _vp, _vp, _vp, _vp]),
     "gs_cholqr": (_int, [_vp, _int, _int, _vp, _vp, _vp]),
     "gs_jacobi_small": (_int, [_vp, _int, _vp, _vp, _vp, _vp]),
+    "gs_gemm_f64": (_int, [_int, _int, _int, _vp, _i64, _i64, _vp, _i64, _i64, _vp, _i64, C.c_double, C.c_double, _vp, _vp,
+                            _vp, _vp]),
     "gs_mapping_forward": (_int, [_vp, _vp, _vp, _vp, _vp, _int, _int, _f32, _f32, _f32, _f32, _int, _i64, _vp]),
     "gs_linear_forward": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _int, _vp]),
 }

@@ -4,12 +4,12 @@ The reference draws one seed per mini-batch from the global legacy NumPy stream 
 from a private ``RandomState(seed)`` (``models/wrappers.py:167-174`` for StyleGAN2,
 ``models/biggan/.../utils.py:21-33`` for BigGAN).  MT19937 + the polar Gaussian are serial per seed
 (88 k samples/s/core for 512-d z), i.e. 11 s for n = 1e6 - three orders of magnitude more
-than the PCA on the GPU.  The batches are independent once the seed list is drawn.  StyleGAN latents (plain normals)
-come from the library's native thread pool (``NativeNormalStream`` over ``gs_zgen_*``, csrc/gs_zgen.hip: no interpreter
-start-up, pinned ring buffers); BigGAN's ``scipy.stats.truncnorm`` latents are produced by
-worker *subprocesses* (``python -m ganspace_amd._zgen``: NumPy only, never torch or the HIP runtime; no
-``multiprocessing`` start-method pitfalls for callers without a ``__main__`` guard) that write straight
-into a shared memory-mapped array, which the parent consumes in order.
+than the PCA on the GPU.  The batches are independent once the seed list is drawn.  Both latent kinds come from the
+library's native thread pool (``NativeNormalStream`` over ``gs_zgen_*``, csrc/gs_zgen.hip: no interpreter start-up,
+pinned ring buffers): StyleGAN's plain normals and, since round 4, BigGAN's ``scipy.stats.truncnorm`` latents (SciPy's
+inverse-CDF chain restated in C++).  The worker *subprocesses* of round 2 (``python -m ganspace_amd._zgen``: NumPy /
+SciPy only, writing into a shared memory-mapped array) remain behind ``GANSPACE_ZGEN_WORKERS`` as the SciPy-evaluated
+cross-check.
 """
 from __future__ import annotations
 
@@ -39,7 +39,14 @@ def _one(kind, seed, n, dim, truncation):
     return stylegan_z(seed, n, dim) if kind == "stylegan" else biggan_z(seed, n, dim, truncation)
 
 
-_RING_CACHE = {}        # (n_slots, count, pinned) -> (storage, [ctypes pointers]): pinning host memory is not free
+# (n_slots, count, pinned) -> [storage, ctypes pointers, in use]: pinning host memory is not free, so ONE ring is kept
+# between streams.  A ring belongs to one stream at a time: a second stream that is opened while the first is alive
+# (two generators zipped, a generator that was not exhausted) gets a private ring instead of the other's slots.
+_RING_CACHE = {}
+
+# log Phi(-2) and log(Phi(2) - Phi(-2)) as SciPy computes them (scipy.special.log_ndtr(-2.0),
+# np.log1p(-ndtr(-2.0) - ndtr(-2.0))): the interval of BigGAN's truncated_noise_sample
+TRUNCNORM_M2_P2 = (float.fromhex("-0x1.e43f625df3b24p+1"), float.fromhex("-0x1.7d7bfd8ad78c5p-5"))
 
 
 class NativeNormalStream:
@@ -53,7 +60,9 @@ class NativeNormalStream:
     consumer calls it when it is done with batch ``index`` (after the event of its H2D copy); the iterator itself
     never releases anything it has handed out."""
 
-    def __init__(self, seeds, n: int, dim: int, threads=None, pinned=None):
+    def __init__(self, seeds, n: int, dim: int, threads=None, pinned=None, kind="stylegan", truncation=1.0):
+        """``kind="biggan"``: ``truncation * truncnorm.rvs(-2, 2, size=(n, dim), random_state=RandomState(seed))`` in
+        float32 instead of standard normals (``gs_zgen_start_truncnorm``)."""
         import ctypes as C
         from . import _lib
         self._lib = _lib.load()
@@ -76,7 +85,8 @@ class NativeNormalStream:
                 pinned = False
         count = self.n * self.dim
         key = (n_slots, count, bool(pinned))
-        if key not in _RING_CACHE:
+
+        def new_ring():
             if pinned:
                 import torch
                 storage = torch.empty((n_slots, self.n, self.dim), dtype=torch.float32, pin_memory=True)
@@ -84,14 +94,35 @@ class NativeNormalStream:
             else:
                 storage = np.empty((n_slots, self.n, self.dim), dtype=np.float32)
                 base = storage.ctypes.data
-            ptrs = (C.c_void_p * n_slots)(*[base + i * count * 4 for i in range(n_slots)])
-            _RING_CACHE.clear()                    # one ring at a time: a different shape replaces the old buffers
-            _RING_CACHE[key] = (storage, ptrs)
-        self._storage, self._ptrs = _RING_CACHE[key]
+            return [storage, (C.c_void_p * n_slots)(*[base + i * count * 4 for i in range(n_slots)]), True]
+
+        entry = _RING_CACHE.get(key)
+        if entry is not None and not entry[2]:
+            entry[2] = True                        # the cached ring is free: take it
+        elif entry is not None or any(e[2] for e in _RING_CACHE.values()):
+            entry = new_ring()                     # another live stream owns the cached ring: a private one, not cached
+        else:
+            entry = new_ring()
+            _RING_CACHE.clear()                    # one idle ring at a time: a different shape replaces the old buffers
+            _RING_CACHE[key] = entry
+        self._ring = entry
+        self._storage, self._ptrs = entry[0], entry[1]
         self._n_slots = n_slots
         self._h = C.c_void_p()
-        _lib.check(self._lib.gs_zgen_start(self.seeds.ctypes.data_as(C.c_void_p), nb, count,
-                                           C.cast(self._ptrs, C.c_void_p), n_slots, threads, C.byref(self._h)))
+        try:
+            if kind == "biggan":
+                la, lm = TRUNCNORM_M2_P2
+                _lib.check(self._lib.gs_zgen_start_truncnorm(self.seeds.ctypes.data_as(C.c_void_p), nb, count,
+                                                             C.cast(self._ptrs, C.c_void_p), n_slots, threads, la, lm,
+                                                             float(truncation), C.byref(self._h)))
+            elif kind == "stylegan":
+                _lib.check(self._lib.gs_zgen_start(self.seeds.ctypes.data_as(C.c_void_p), nb, count,
+                                                   C.cast(self._ptrs, C.c_void_p), n_slots, threads, C.byref(self._h)))
+            else:
+                raise ValueError(f"unknown latent kind {kind!r}")
+        except Exception:
+            entry[2] = False
+            raise
         self.threads = threads
 
     def __len__(self):
@@ -111,8 +142,9 @@ class NativeNormalStream:
 
     def close(self):
         if self._h:
-            self._lib.gs_zgen_finish(self._h)
+            self._lib.gs_zgen_finish(self._h)      # joins the pool: nobody writes into the ring after this
             self._h = None
+            self._ring[2] = False                  # (a private ring simply goes away with the stream)
 
     def __del__(self):
         try:
@@ -126,8 +158,8 @@ def generate(kind: str, seeds, n: int, dim: int, truncation: float = 1.0, worker
     library's native generator; BigGAN's ``truncnorm.rvs`` batches from worker subprocesses when the job is large
     enough to pay for their start-up (or when ``GANSPACE_ZGEN_WORKERS`` forces a worker count)."""
     seeds = [int(s) for s in seeds]
-    if kind == "stylegan" and len(seeds) > 0 and os.environ.get("GANSPACE_ZGEN_WORKERS") is None:
-        stream = NativeNormalStream(seeds, n, dim, pinned=False)
+    if kind in ("stylegan", "biggan") and len(seeds) > 0 and os.environ.get("GANSPACE_ZGEN_WORKERS") is None:
+        stream = NativeNormalStream(seeds, n, dim, pinned=False, kind=kind, truncation=truncation)
         try:
             for i, z in stream:
                 out = np.array(z, copy=True)

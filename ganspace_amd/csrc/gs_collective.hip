@@ -103,7 +103,9 @@ extern "C" int gs_ipca_allreduce(gs_ipca_t *h, void *comm, void *stream_) {
             rc = gs_state_recenter(state, d, mean, stream);      // C += n_local (mean_local - mean)(...)^T ; mean = global
             if (rc != GS_OK) return fail(rc, gs_last_error());
         } else {
-            GS_HIP_CHECK(hipMemcpyAsync(state + 1, mean, sizeof(double) * (size_t)d, hipMemcpyDeviceToDevice, stream));
+            // a rank without samples: its (all-zero) scatter is already centred about anything - only the mean is replaced
+            if (hipMemcpyAsync(state + 1, mean, sizeof(double) * (size_t)d, hipMemcpyDeviceToDevice, stream) != hipSuccess)
+                return fail(GS_EHIP, "gs_ipca_allreduce: hipMemcpyAsync (global mean) failed");
         }
         if (nc.all_reduce(state + 1 + d, state + 1 + d, (size_t)(d * d), kNcclFloat64, kNcclSum, comm, stream) != 0)
             return fail(GS_EHIP, "gs_ipca_allreduce: ncclAllReduce (scatter) failed");
@@ -122,7 +124,7 @@ extern "C" int gs_ipca_allreduce(gs_ipca_t *h, void *comm, void *stream_) {
         rc = gs_ipca_lowrank_merge(h, all, P, stream);
         if (rc != GS_OK) return fail(rc, gs_last_error());
     }
-    GS_HIP_CHECK(hipStreamSynchronize(stream));
+    if (hipStreamSynchronize(stream) != hipSuccess) return fail(GS_EHIP, "gs_ipca_allreduce: hipStreamSynchronize failed");
     (void)hipFree(buf);
     return GS_OK;
 }

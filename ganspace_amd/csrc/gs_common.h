@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <atomic>
 #include <functional>
 #include <initializer_list>
 #include <string>
@@ -30,7 +31,31 @@ void set_error(const std::string &msg);
         }                                                                               \
     } while (0)
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, DEVICE): the attribute belongs to the device's
+// copy of the kernel, so a process-wide "done" flag breaks the first launch on a second GPU of the same process
+// (the C ABI takes a device argument).  `static LdsOptIn once;` next to the launch.
+struct LdsOptIn {
+    std::atomic<bool> done[64] = {};
+};
+inline int lds_opt_in(LdsOptIn &once, const void *kernel, size_t bytes) {
+    int dev = 0;
+    GS_HIP_CHECK(hipGetDevice(&dev));
+    const bool tracked = dev >= 0 && dev < 64;
+    if (tracked && once.done[dev].load(std::memory_order_acquire)) return GS_OK;
+    GS_HIP_CHECK(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    if (tracked) once.done[dev].store(true, std::memory_order_release);
+    return GS_OK;
+}
+
 inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+
+// A/B switches of the measurement builds (`GS_HIPCC_FLAGS=-DGS_MEASURE_BUILD`, profiles/README.md): the production
+// library never reads the environment for them.
+#ifdef GS_MEASURE_BUILD
+inline const char *gs_knob(const char *name) { return getenv(name); }
+#else
+inline const char *gs_knob(const char *) { return nullptr; }
+#endif
 inline int64_t ceil_div(int64_t x, int64_t m) { return (x + m - 1) / m; }
 
 // ---- launch chains as HIP graphs -----------------------------------------------------------------------------
@@ -75,7 +100,7 @@ inline int run_as_graph(GraphCache &gc, uint64_t key, hipStream_t stream, F &&bo
     // Measured on MI355X / ROCm 7.2 (profiles/r03_graphs_vs_streams.md): replaying these chains as graphs is SLOWER than
     // launching them (exact finalize 2.08 vs 1.88 ms, faithful block 0.34 vs 0.34 ms) - the runtime's graph launch costs
     // more per node than a stream launch.  The path therefore stays opt-in (GS_USE_GRAPHS=1) until that changes.
-    static const bool opted_in = getenv("GS_USE_GRAPHS") != nullptr;
+    static const bool opted_in = gs_knob("GS_USE_GRAPHS") != nullptr;
     if (!gc.enabled || !opted_in) return body();
     for (int i = 0; i < gc.count; ++i)
         if (gc.entries[i].key == key) {
@@ -143,6 +168,7 @@ struct GramWorkspace {
     hipEvent_t ev_comp[2] = {nullptr, nullptr};    // slabs of set i are complete (recorded on the caller's stream)
     hipEvent_t ev_fold[2] = {nullptr, nullptr};    // slabs of set i are folded (recorded on aux)
     bool aux_busy[2] = {false, false};             // a fold on aux that the caller's stream has not waited for yet
+    mutable unsigned long long pace_epoch = 0;     // per workspace: its launches are ordered on its stream, its words are its own
 };
 
 int gram_workspace_alloc(GramWorkspace &ws, int64_t d);
@@ -206,9 +232,33 @@ void gemm_f64(int M, int N, int K, const double *A, int64_t a_i, int64_t a_t, co
               int64_t b_j, double *C, int64_t ldc, hipStream_t stream, double alpha = 1.0, double beta = 0.0,
               const GemmEpilogue &epi = GemmEpilogue(), bool allow_split = true, bool c_is_zero = false);
 
+// MFMA version (gs_dense64.hip: v_mfma_f64_16x16x4_f64, operands straight from global memory); same contract.  gemm_f64
+// dispatches to it.
+void mm64(int M, int N, int K, const double *A, int64_t a_i, int64_t a_t, const double *B, int64_t b_t, int64_t b_j,
+          double *C, int64_t ldc, hipStream_t stream, double alpha = 1.0, double beta = 0.0,
+          const GemmEpilogue &epi = GemmEpilogue(), bool allow_split = true, bool c_is_zero = false);
+// H = R^T R (p x p, p <= 128) -> Rinv = R^-1 (upper triangular, zeros below), rdiag = diag(R) (0 marks a numerically
+// dependent column: its row and column of Rinv are zero).  One single-workgroup launch (gs_dense64.hip).
+int chol_inv_launch(const double *H, int64_t ldh, int p, double *Rinv, int64_t ldr, double *rdiag, hipStream_t stream);
+
 // ---- top-k subspace eigensolver: gs_subspace.hip / gs_topk.hip ----------------------------------------
+// an invariant-subspace step (invsub_begin) whose verdict the host has not read yet
+struct InvsubPending {
+    bool active = false;
+    int attempt = 0, P = 0, P0 = 0, j = 1, jj_last = 1, used = 0;
+    bool pass2 = false, loewdin = false, identity_start = false;
+    double ln_gap = 0.0, blocks_seen = 0.0;
+    const double *A = nullptr;
+    int n = 0, k = 0;
+    int64_t lda = 0, ldv = 0, ldbk = 0;
+    double *Vk = nullptr, *Bk = nullptr, *Qc = nullptr, *Bm = nullptr;
+};
+
 struct SubspaceWorkspace {
     int n_cap = 0, p_cap = 0, pp = 0;
+    InvsubPending inv;
+    double *inv_host = nullptr;    // [8] pinned: verdict of the attempt in flight (invsub_judge_kernel)
+    hipEvent_t inv_event = nullptr;
     int warm_mults = 0;            // products the last converged warm-started solve used (schedule hint)
     // gs_topk.hip: filter schedule of the last converged warm-started solve (reused without a host round trip)
     bool plan_valid = false;
@@ -301,6 +351,12 @@ int eigh_topk_cheb(SubspaceWorkspace &ws, const double *A, int n, int64_t lda, i
 int invsub_iterate(SubspaceWorkspace &ws, const double *A, int n, int64_t lda, int k, double *Vk, int64_t ldv,
                    double *Bk, int64_t ldbk, double blocks_seen, int *mults_out, int *converged, hipStream_t stream,
                    bool identity_start = false);
+// The same in two halves: invsub_begin plans and ENQUEUES the step (acceptance test and emit run on the device; *started
+// = 0: declined, nothing enqueued), invsub_finish reads the verdict later (retries synchronously on a miss).  Between the
+// two the caller may enqueue anything that does not touch A, Vk, Bk or the workspace - e.g. the next block's Gram launch.
+int invsub_begin(SubspaceWorkspace &ws, const double *A, int n, int64_t lda, int k, double *Vk, int64_t ldv, double *Bk,
+                 int64_t ldbk, double blocks_seen, hipStream_t stream, bool identity_start, int *started);
+int invsub_finish(SubspaceWorkspace &ws, hipStream_t stream, int *mults_out, int *converged);
 
 // ---- small-side recurrence for d >> m: gs_smallside.hip -------------------------------------------
 struct SmallSide {

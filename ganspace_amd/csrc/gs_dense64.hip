@@ -1,0 +1,366 @@
+// Float64 dense building blocks of the small-matrix solver chains (gs_topk.hip, gs_smallside.hip, gs_rangefinder.hip),
+// round 4: the products run on the f64 matrix pipe (v_mfma_f64_16x16x4_f64), and CholeskyQR needs ONE single-workgroup
+// launch that leaves the explicit inverse factor, so that "Q = Y R^-1" is just another product.
+//
+// They stand in for LAPACK gesdd inside IncrementalPCA.partial_fit (sklearn/decomposition/_incremental_pca.py:362) via
+// the top-k solvers; the chains they shorten are 44 % of the headline job and ~90 % of a faithful block (round-3 profile).
+//
+//   mm64_kernel       C[M x N] = epilogue(A B) for arbitrary element strides.  One wave owns a 16 x 16 output tile and
+//                     issues v_mfma_f64_16x16x4_f64; a workgroup is four waves, arranged either as four K-slices of ONE
+//                     tile (small outputs with a long K: 512 x 96 x 512 is 192 workgroups, 32 MFMAs per wave, partial
+//                     tiles summed through LDS) or as a 2 x 2 block of tiles (large outputs).  Operands go straight from
+//                     global memory / L2 into the MFMA operand registers - every operand element is used by exactly one
+//                     MFMA of its wave, LDS staging would only add a hop.  All loads of a 128-deep K chunk are issued
+//                     before the first MFMA (64 operand registers per lane), so the wave pays the L2 latency once.
+//                     The f64 matrix and vector peaks coincide on gfx950 (78.6 TF): the gain over the VALU kernel is the
+//                     missing LDS round trip and 4x fewer issue slots, not arithmetic rate.
+//   chol_inv_kernel   p x p Gram matrix (p <= 128), ONE workgroup: blocked right-looking Cholesky, 16 wide, with the
+//                     identity carried through the same elimination, so that it ends with R^-T in the (otherwise unused)
+//                     lower triangle.  The 16 x 16 diagonal blocks are factored by ONE wave without barriers (columns in
+//                     registers, pivot rows broadcast by v_readlane: the round-3 kernel paid an LDS round trip and a
+//                     barrier per two pivots, 1150 clk per pivot).
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+
+#include "gs_common.h"
+
+namespace gs {
+
+namespace {
+
+typedef double d4_t __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ double readlane64(double v, int lane) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ double rsqrt_nr2(double x) {
+    double y = __builtin_amdgcn_rsq(x);
+    const double hx = 0.5 * x;
+    y = y * (1.5 - hx * y * y);
+    y = y * (1.5 - hx * y * y);
+    return y;
+}
+
+__global__ void mm64_zero_kernel(double *__restrict__ C, int N, int64_t ldc) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < N) C[(int64_t)blockIdx.y * ldc + j] = 0.0;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------------------
+// C = epilogue(A B).  A(i,t) = A[i a_i + t a_t], B(t,j) = B[t b_t + j b_j], C row-major.
+// MFMA operand map (v_mfma_f64_16x16x4_f64): lane l supplies A(i = l & 15, k = l >> 4) and B(k = l >> 4, j = l & 15);
+// result register r of lane l is C(row = (l >> 4) + 4 r, col = l & 15).  Within a group of 16 k values lane (i, g) takes
+// k = 4 g + m for MFMA m - any assignment works as long as A and B agree - so that a row-major A is read as 4
+// consecutive doubles per lane.
+// KSPLIT = true : grid (N/16, M/16, zsplit); the 4 waves of a workgroup take quarters of the K range of ONE tile.
+// KSPLIT = false: grid (N/32, M/32, zsplit); wave w owns tile (w >> 1, w & 1) of a 32 x 32 block, full K range.
+// CH: k values a wave loads ahead of its MFMAs (32 or 128).
+template <bool KSPLIT, int CH>
+__global__ __launch_bounds__(256) void mm64_kernel(int M, int N, int K, const double *__restrict__ A, int64_t a_i,
+                                                   int64_t a_t, const double *__restrict__ B, int64_t b_t, int64_t b_j,
+                                                   double *__restrict__ C, int64_t ldc, double alpha, double beta,
+                                                   int kchunk, GemmEpilogue epi) {
+    __shared__ double red[KSPLIT ? 4 * 256 : 1];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int li = lane & 15, g = lane >> 4;
+    int i0, j0, kb, ke;
+    {
+        const int zb = blockIdx.z * kchunk;
+        const int ze = (zb + kchunk < K) ? zb + kchunk : K;
+        if (KSPLIT) {
+            i0 = blockIdx.y * 16;
+            j0 = blockIdx.x * 16;
+            const int kw = (((ze - zb) + 15) >> 4 << 4) >> 2;       // quarter of the range, a multiple of 4
+            kb = zb + wave * kw;
+            ke = (kb + kw < ze) ? kb + kw : ze;
+        } else {
+            i0 = blockIdx.y * 32 + (wave >> 1) * 16;
+            j0 = blockIdx.x * 32 + (wave & 1) * 16;
+            kb = zb;
+            ke = ze;
+        }
+    }
+    const int gi = i0 + li, gj = j0 + li;
+    const bool iok = gi < M, jok = gj < N;
+    const double *Ap = A + (int64_t)(iok ? gi : 0) * a_i;
+    const double *Bp = B + (int64_t)(jok ? gj : 0) * b_j;
+    d4_t acc = {0.0, 0.0, 0.0, 0.0};
+    constexpr int NB = CH / 16;                    // batches of 16 k values = 4 MFMAs each
+    for (int k0 = kb; k0 < ke; k0 += CH) {
+        double a[NB][4], b[NB][4];
+#pragma unroll
+        for (int q = 0; q < NB; ++q) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const int kk = k0 + 16 * q + 4 * g + m;
+                const bool kok = kk < ke;
+                a[q][m] = (iok && kok) ? Ap[(int64_t)kk * a_t] : 0.0;
+                b[q][m] = (jok && kok) ? Bp[(int64_t)kk * b_t] : 0.0;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < NB; ++q) {
+            if (k0 + 16 * q < ke) {                // (wave-uniform)
+#pragma unroll
+                for (int m = 0; m < 4; ++m) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q][m], b[q][m], acc, 0, 0, 0);
+            }
+        }
+    }
+    const bool split = gridDim.z > 1;
+    auto emit = [&](int r, int c, double v) {
+        if (r >= M || c >= N) return;
+        double *dst = C + (int64_t)r * ldc + c;
+        if (epi.coef != nullptr) {
+            double o = epi.coef[0] * v;
+            if (!split || blockIdx.z == 0) {
+                if (epi.E1) o += epi.coef[1] * epi.E1[(int64_t)r * ldc + c];
+                if (epi.E2) o += epi.coef[2] * epi.E2[(int64_t)r * ldc + c];
+            }
+            if (split)
+                atomicAdd(dst, o);
+            else
+                *dst = o;
+        } else if (split) {
+            atomicAdd(dst, alpha * v);
+        } else {
+            *dst = (beta == 0.0) ? alpha * v : beta * *dst + alpha * v;
+        }
+    };
+    if (KSPLIT) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[wave * 256 + (g + 4 * r) * 16 + li] = acc[r];
+        __syncthreads();
+        const double v = (red[tid] + red[256 + tid]) + (red[512 + tid] + red[768 + tid]);
+        emit(i0 + (tid >> 4), j0 + (tid & 15), v);
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) emit(i0 + g + 4 * r, j0 + li, acc[r]);
+    }
+}
+
+void mm64(int M, int N, int K, const double *A, int64_t a_i, int64_t a_t, const double *B, int64_t b_t, int64_t b_j,
+          double *C, int64_t ldc, hipStream_t stream, double alpha, double beta, const GemmEpilogue &epi,
+          bool allow_split, bool c_is_zero) {
+    if (M <= 0 || N <= 0) return;
+    const int64_t t16 = ceil_div(M, 16) * ceil_div(N, 16);
+    // 2 x 2 tile blocks once they alone give every CU a workgroup or two; otherwise one tile per workgroup with the K
+    // range split over its four waves, and over blockIdx.z (atomic epilogue on a zeroed C) when even that leaves most of
+    // the chip idle and K is long
+    const bool ksplit = t16 < 1024;
+    int zs = 1;
+    if (ksplit && allow_split && beta == 0.0 && K >= 1024 && t16 < 192) {
+        zs = (int)ceil_div(384, t16);
+        if (zs > K / 256) zs = K / 256;
+        if (zs < 1) zs = 1;
+    }
+    const int kchunk = (int)round_up(ceil_div(K, zs), 16);
+    zs = (int)ceil_div(K, kchunk);
+    if (zs > 1 && !c_is_zero)
+        GS_LAUNCH(mm64_zero_kernel, dim3((unsigned)ceil_div(N, 256), (unsigned)M), dim3(256), 0, stream, C, N, ldc);
+    if (ksplit) {
+        const dim3 grid((unsigned)ceil_div(N, 16), (unsigned)ceil_div(M, 16), (unsigned)zs);
+        if (kchunk <= 128)
+            GS_LAUNCH((mm64_kernel<true, 32>), grid, dim3(256), 0, stream, M, N, K, A, a_i, a_t, B, b_t, b_j, C, ldc, alpha,
+                      beta, kchunk, epi);
+        else
+            GS_LAUNCH((mm64_kernel<true, 128>), grid, dim3(256), 0, stream, M, N, K, A, a_i, a_t, B, b_t, b_j, C, ldc, alpha,
+                      beta, kchunk, epi);
+    } else {
+        const dim3 grid((unsigned)ceil_div(N, 32), (unsigned)ceil_div(M, 32), (unsigned)zs);
+        if (kchunk <= 32)
+            GS_LAUNCH((mm64_kernel<false, 32>), grid, dim3(256), 0, stream, M, N, K, A, a_i, a_t, B, b_t, b_j, C, ldc, alpha,
+                      beta, kchunk, epi);
+        else
+            GS_LAUNCH((mm64_kernel<false, 128>), grid, dim3(256), 0, stream, M, N, K, A, a_i, a_t, B, b_t, b_j, C, ldc, alpha,
+                      beta, kchunk, epi);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// H = R^T R (p x p Gram matrix, p <= 128)  ->  Rinv = R^-1 (upper triangular, row-major, zeros below the diagonal),
+// rdiag[j] = R_jj (0 = numerically dependent column).  ONE workgroup of 1024 threads, matrix in LDS.
+//
+// Forward elimination of [H | I] leaves [R | R^-T]: the identity half is lower triangular throughout, so it lives in the
+// strictly lower triangle of the LDS image (the factorisation only touches the upper one) plus a separate diagonal.
+// Per 16-wide block step J:
+//   (a) diagonal block + its identity block: ONE wave, lane c < 16 holds column c of the block, lane 16 + c column c of
+//       the identity, all 16 rows in registers; pivot j is broadcast from lane j by v_readlane, row j of R from the lanes
+//       that hold it - no LDS, no barrier inside the 16 pivots.
+//   (b) panel: rows J of both halves are multiplied by R_JJ^-T (16 x 16, lower triangular).
+//   (c) trailing update of every row below the block, both halves, 4 x 4 register tiles out of LDS.
+// A pivot that lost more than ~13 digits against the column's original squared norm marks a numerically dependent
+// column: row j AND column j of R^-1 are zero, so column j of Y R^-1 is exactly zero and no later column uses it.
+constexpr int kCiP = 128;
+constexpr int kCiLd = 129;
+constexpr size_t kCiLdsBytes = sizeof(double) * ((size_t)kCiP * kCiLd + 16 * 17 + 3 * kCiP);
+__global__ __launch_bounds__(1024) void chol_inv_kernel(const double *__restrict__ H, int64_t ldh, int p,
+                                                         double *__restrict__ Rinv, int64_t ldr,
+                                                         double *__restrict__ rdiag, int debug) {
+    extern __shared__ __attribute__((aligned(16))) double cis[];
+    double *Hs = cis;                           // [128][129]  upper: H -> R;  strictly lower: R^-T
+    double *Es = Hs + kCiP * kCiLd;             // [16][17]    R_JJ^-T of the current block (full 16 x 16, zeros above the diagonal)
+    double *ed = Es + 16 * 17;                  // [128]       diagonal of R^-T
+    double *rd = ed + kCiP;                     // [128]       diagonal of R (0 = dead)
+    double *refd = rd + kCiP;                   // [128]       original diagonal of H
+    const long long dbg_c0 = debug ? clock64() : 0;
+    long long dbg_leaf = 0, dbg_panel = 0, dbg_trail = 0;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int li = lane & 15, lg = lane >> 4;
+    const int nblk = (p + 15) >> 4, pend = nblk * 16;
+    for (int e = tid; e < pend * pend; e += 1024) {
+        const int i = e / pend, j = e - i * pend;
+        double v = 0.0;
+        if (i <= j) v = (j < p) ? H[(int64_t)i * ldh + j] : (i == j ? 1.0 : 0.0);
+        Hs[i * kCiLd + j] = v;
+    }
+    if (tid < kCiP) refd[tid] = (tid < p) ? H[(int64_t)tid * ldh + tid] : 1.0;
+    __syncthreads();
+    for (int J = 0; J < nblk; ++J) {
+        const int j0 = 16 * J, j1 = j0 + 16, rem = pend - j1;
+        long long dbg_t = debug ? clock64() : 0;
+        // ---- (a) diagonal block, one wave, branch-free: lane c < 16 column c of the block, lane 16 + c column c of the
+        //      identity.  Entries below the diagonal of a block column only ever see no-op or unread updates, so the
+        //      elimination step needs no row / column masks ----
+        if (tid < 64) {
+            const int c = tid & 15;
+            const bool aug = (tid & 16) != 0;
+            double col[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                double v = (r == c) ? 1.0 : 0.0;
+                if (!aug) v = (r <= c) ? Hs[(j0 + r) * kCiLd + j0 + c] : 0.0;
+                col[r] = v;
+            }
+            const double ref = refd[j0 + c] * 1e-13;
+            unsigned dead_mask = 0;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const double d = readlane64(col[j], j);
+                const double rf = readlane64(ref, j);
+                const bool dead = !(d > rf);                     // (wave-uniform)
+                double inv = __builtin_amdgcn_rsq(d);            // one Newton step on the ~2^-26 seed: ~3e-16 relative
+                inv = inv * (1.5 - (0.5 * d) * inv * inv);
+                inv = dead ? 0.0 : inv;
+                dead_mask |= dead ? (1u << j) : 0u;
+                double rjc = col[j] * inv;                        // row j of R / of R^-T at this lane's column
+                if (!aug) rjc = (c == j) ? (dead ? 1.0 : d * inv) : ((c > j) ? rjc : 0.0);
+                col[j] = rjc;
+#pragma unroll
+                for (int r = j + 1; r < 16; ++r) col[r] -= readlane64(rjc, r) * rjc;     // R[j][r] lives in lane r < 16
+            }
+            const bool dead_c = (dead_mask >> c) & 1u;
+            if (tid < 16) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (r <= c) Hs[(j0 + r) * kCiLd + j0 + c] = col[r];
+                rd[j0 + c] = dead_c ? 0.0 : col[c];
+            } else if (tid < 32) {
+                // lane 16 + c: column c of R_JJ^-T (rows r >= c)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const bool dead_r = (dead_mask >> r) & 1u;
+                    const double v = (r < c || dead_r || dead_c) ? 0.0 : col[r];
+                    Es[r * 17 + c] = v;
+                    if (r > c) Hs[(j0 + r) * kCiLd + j0 + c] = v;
+                    if (r == c) ed[j0 + c] = v;
+                }
+            }
+        }
+        __syncthreads();
+        if (debug) {
+            const long long t = clock64();
+            dbg_leaf += t - dbg_t;
+            dbg_t = t;
+        }
+        // ---- (b) panel on the matrix pipe: rows J of both halves <- R_JJ^-T (rows J); one 16-column tile per wave,
+        //      tile q covers columns [16 q, 16 q + 16) for q < J (identity half) and [16 (q + 1), ...) beyond ----
+        const int ntile_p = nblk - 1;
+        d4_t pacc = {0.0, 0.0, 0.0, 0.0};
+        const int pc0 = 16 * (wave < J ? wave : wave + 1);
+        if (wave < ntile_p) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const int k = 4 * lg + m;
+                const double a = Es[li * 17 + k];                            // R_JJ^-T (i, k), zero for k > i
+                const double b = Hs[(j0 + k) * kCiLd + pc0 + li];
+                pacc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, pacc, 0, 0, 0);
+            }
+        }
+        __syncthreads();
+        if (wave < ntile_p) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Hs[(j0 + lg + 4 * r) * kCiLd + pc0 + li] = pacc[r];
+        }
+        __syncthreads();
+        if (debug) {
+            const long long t = clock64();
+            dbg_panel += t - dbg_t;
+            dbg_t = t;
+        }
+        if (rem <= 0) break;
+        // ---- (c) trailing update on the matrix pipe, rows [j1, pend): X[r][c] -= sum_t R[j0 + t][r] rowJ[t][c] for the
+        //      columns of the identity half (c < j1) and of the upper triangle (c >= r); 16 x 16 tiles dealt to the waves ----
+        {
+            const int ntr = rem >> 4;
+            const int ntiles = ntr * nblk;
+            for (int tile = wave; tile < ntiles; tile += 16) {
+                const int tr = tile / nblk, tc = tile - tr * nblk;
+                const int r0 = j1 + 16 * tr, c0 = 16 * tc;
+                if (c0 >= j1 && c0 < r0) continue;                        // strictly below the diagonal: still zero
+                const bool inJ = (c0 == j0);
+                d4_t acc;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[r] = Hs[(r0 + lg + 4 * r) * kCiLd + c0 + li];
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const int k = 4 * lg + m;
+                    const double a = -Hs[(j0 + k) * kCiLd + r0 + li];       // -R[j0 + k][r0 + i]
+                    const double b = inJ ? Es[k * 17 + li] : Hs[(j0 + k) * kCiLd + c0 + li];
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int rr = r0 + lg + 4 * r, cc = c0 + li;
+                    if (cc < j1 || cc >= rr) Hs[rr * kCiLd + cc] = acc[r];
+                }
+            }
+        }
+        __syncthreads();
+        if (debug) dbg_trail += clock64() - dbg_t;
+    }
+    __syncthreads();
+    // ---- R^-1 = (R^-T)^T ----
+    for (int e = tid; e < p * p; e += 1024) {
+        const int i = e / p, j = e - i * p;
+        Rinv[(int64_t)i * ldr + j] = (i < j) ? Hs[j * kCiLd + i] : (i == j ? ed[i] : 0.0);
+    }
+    if (tid < p) rdiag[tid] = rd[tid];
+    if (debug && tid == 0)
+        printf("[chol_inv p=%d] leaf %lld clk, panel %lld, trailing %lld; total %lld clk\n", p, dbg_leaf, dbg_panel, dbg_trail,
+               (long long)clock64() - dbg_c0);
+}
+
+int chol_inv_prepare() {
+    static LdsOptIn once;
+    return lds_opt_in(once, reinterpret_cast<const void *>(chol_inv_kernel), kCiLdsBytes);
+}
+
+int chol_inv_launch(const double *H, int64_t ldh, int p, double *Rinv, int64_t ldr, double *rdiag, hipStream_t stream) {
+    GS_REQUIRE(p >= 1 && p <= kCiP, GS_EINVAL, "chol_inv: p must be in [1, 128]");
+    {
+        const int rcp = chol_inv_prepare();
+        if (rcp != GS_OK) return rcp;
+    }
+    static const int debug = gs_knob("GS_TOPK_DEBUG") ? 1 : 0;
+    GS_LAUNCH(chol_inv_kernel, dim3(1), dim3(1024), kCiLdsBytes, stream, H, ldh, p, Rinv, ldr, rdiag, debug);
+    GS_HIP_CHECK(hipGetLastError());
+    return GS_OK;
+}
+
+}  // namespace gs

@@ -349,7 +349,7 @@ int eigh_jacobi(const EighWorkspace &ws, double *W, int n, int64_t ldw, int *swe
     hipLaunchKernelGGL(colnorm_kernel, grid_cols, blk, 0, stream, W, n, ldw, ws.norms, maxnorm);
 
     int sweeps = 0;
-    static const bool force_flat = getenv("GS_EIGH_FLAT") != nullptr;
+    static const bool force_flat = gs_knob("GS_EIGH_FLAT") != nullptr;
     if (n > 1 && n <= 4096 && !force_flat) {
         // LDS-resident block Jacobi: NPL = ceil(n / 64) rounded to a power of two, BS sized so that
         // the 2*BS-column panel fits the 160 KiB LDS
@@ -362,7 +362,7 @@ int eigh_jacobi(const EighWorkspace &ws, double *W, int n, int64_t ldw, int *swe
             rc = launch_block_sweeps<4, 16>(ws, W, n, ldw, &sweeps, stream);
         else if (n <= 512) {
             static const int bs = []() {
-                const char *e = getenv("GS_EIGH_BS");
+                const char *e = gs_knob("GS_EIGH_BS");
                 return e ? atoi(e) : 16;
             }();
             if (bs == 4)

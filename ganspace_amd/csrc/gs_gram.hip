@@ -613,7 +613,7 @@ int gram_workspace_alloc(GramWorkspace &ws, int64_t d) {
         GS_HIP_CHECK(hipMalloc(&ws.partial[i], sizeof(float) * ws.max_chunks * ws.dp * ws.dp));
         GS_HIP_CHECK(hipMalloc(&ws.colsum_partial[i], sizeof(float) * ws.max_chunks * ws.dp));
     }
-    if (ws.dp == 512 && getenv("GS_GRAM_NO_AUX_FOLD") == nullptr) {
+    if (ws.dp == 512 && gs_knob("GS_GRAM_NO_AUX_FOLD") == nullptr) {
         GS_HIP_CHECK(hipStreamCreateWithFlags(&ws.aux, hipStreamNonBlocking));
         for (int i = 0; i < 2; ++i) {
             GS_HIP_CHECK(hipEventCreateWithFlags(&ws.ev_comp[i], hipEventDisableTiming));
@@ -655,10 +655,10 @@ static GramGeom gram_geometry(const GramWorkspace &ws, int64_t n, bool aligned16
     const int dp = (int)ws.dp;
     g.T = dp / kMacroTile;
     g.nmt = g.T * (g.T + 1) / 2;
-    static const bool no_wide = getenv("GS_GRAM_NO_WIDE") != nullptr;
+    static const bool no_wide = gs_knob("GS_GRAM_NO_WIDE") != nullptr;
     // (launches below ~20 000 rows - the 10 000-row block of the faithful loop - stay with the tiled kernel: the 71 MB of
     //  slabs of 128 pairs, or the long chunks of fewer pairs, cost more than its panel re-reads: 28 vs 21 us)
-    static const bool no_wide_f32 = getenv("GS_GRAM_NO_WIDE_F32") != nullptr;
+    static const bool no_wide_f32 = gs_knob("GS_GRAM_NO_WIDE_F32") != nullptr;
     const bool wide_prec = ws.precision == GS_PREC_BF16X3 || ws.precision == GS_PREC_BF16 ||
                            (ws.precision == GS_PREC_F32 && !no_wide_f32);
     if (wide_prec && ws.d == 512 && aligned16 && !no_wide && n >= 20000) {
@@ -696,7 +696,7 @@ static GramGeom gram_geometry(const GramWorkspace &ws, int64_t n, bool aligned16
         return g;
     }
     static const int target_wgs = []() {
-        const char *e = getenv("GS_GRAM_TARGET_WGS");
+        const char *e = gs_knob("GS_GRAM_TARGET_WGS");
         const int v = e ? atoi(e) : 0;
         return v > 0 ? v : 256;
     }();
@@ -722,7 +722,7 @@ static GramGeom gram_geometry(const GramWorkspace &ws, int64_t n, bool aligned16
 // debug only (GS_GRAM_TRACE + GS_GRAM_TRACE_DUMP; synchronises): s_memtime stamps (100 MHz) of one launch's compute
 // workgroups.  slots: 0 start, 1 first tile staged, 2+s end of stage s / phase s, 14 slab written
 static void dump_trace(unsigned long long *trace_buf, int grid, hipStream_t stream, int nmt_dbg = 0) {
-    if (!trace_buf || !getenv("GS_GRAM_TRACE_DUMP")) return;
+    if (!trace_buf || !gs_knob("GS_GRAM_TRACE_DUMP")) return;
     (void)hipStreamSynchronize(stream);
     static std::vector<unsigned long long> h(16 * 4096);
     (void)hipMemcpy(h.data(), trace_buf, sizeof(unsigned long long) * 16 * grid, hipMemcpyDeviceToHost);
@@ -785,7 +785,7 @@ static void launch_partial(const GramWorkspace &ws, const GramGeom &g, int buf, 
         if (ws.precision == GS_PREC_BF16X3 || ws.precision == GS_PREC_BF16) nfold = 64;
     }
     static unsigned long long *trace_buf = []() -> unsigned long long * {
-        if (!getenv("GS_GRAM_TRACE")) return nullptr;
+        if (!gs_knob("GS_GRAM_TRACE")) return nullptr;
         unsigned long long *p = nullptr;
         if (hipMalloc(&p, sizeof(unsigned long long) * 16 * 4096) != hipSuccess) return nullptr;
         (void)hipMemset(p, 0, sizeof(unsigned long long) * 16 * 4096);
@@ -793,10 +793,9 @@ static void launch_partial(const GramWorkspace &ws, const GramGeom &g, int buf, 
     }();
     FoldJob fj = fold;
     fj.trace = trace_buf;
-    static const bool no_pace = getenv("GS_GRAM_NO_PACE") != nullptr;
-    static unsigned long long pace_epoch = 0;       // launches of one workspace are ordered on its stream
+    static const bool no_pace = gs_knob("GS_GRAM_NO_PACE") != nullptr;
     fj.pace = no_pace ? nullptr : ws.pace;
-    fj.pace_base = (++pace_epoch) << 32;
+    fj.pace_base = (++ws.pace_epoch) << 32;         // (per workspace: the progress words are the workspace's own)
     if (g.wide && !vec) {
         // rows not 16-byte aligned: the float4 staging of the wide kernel does not apply - same geometry through the
         // tiled kernel is not possible (different grid), so the caller's geometry must not have chosen it

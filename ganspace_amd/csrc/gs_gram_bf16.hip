@@ -333,11 +333,10 @@ template <int NPROD, int ABL>
 static int launch_variant(size_t lds_bytes, int grid, int nfold, const float *X, int64_t n, int64_t ld, int d,
                           const float *shift, float *P, float *CS, int dp, int nchunks, ChunkPlan plan, int nmt, int T,
                           const FoldJob &fold, hipStream_t stream) {
-    static bool attr = false;
-    if (!attr) {
-        GS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gram_bf16_kernel<NPROD, ABL>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-        attr = true;
+    static LdsOptIn once;
+    {
+        const int rco = lds_opt_in(once, reinterpret_cast<const void *>(gram_bf16_kernel<NPROD, ABL>), lds_bytes);
+        if (rco != GS_OK) return rco;
     }
     hipLaunchKernelGGL((gram_bf16_kernel<NPROD, ABL>), dim3((unsigned)(grid + nfold)), dim3(kBThreads), lds_bytes, stream,
                        X, n, ld, d, shift, P, CS, dp, nchunks, plan, nmt, T, grid, fold);
@@ -1030,19 +1029,17 @@ int launch_gram_bf16_wide(int precision, int grid, int nfold, const float *X, in
     const size_t lds_bytes = (size_t)2 * kWStageBytes;
     GS_REQUIRE(ld < ((int64_t)1 << 27) && ld % 4 == 0 && (reinterpret_cast<uintptr_t>(X) & 15) == 0, GS_EINVAL,
                "gram (wide): rows must be 16-byte aligned");
-    static bool attr = false;
-    if (!attr) {
-        GS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gram_bf16_wide_kernel<3>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-        GS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gram_bf16_wide_kernel<1>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-        attr = true;
+    static LdsOptIn once3, once1;
+    {
+        int rco = lds_opt_in(once3, reinterpret_cast<const void *>(gram_bf16_wide_kernel<3>), lds_bytes);
+        if (rco == GS_OK) rco = lds_opt_in(once1, reinterpret_cast<const void *>(gram_bf16_wide_kernel<1>), lds_bytes);
+        if (rco != GS_OK) return rco;
     }
     // measurement only (results wrong by design): GS_GRAM_ABLATE bit 0 no MFMA, bit 1 no split / LDS writes, bit 2 no loads
     const int ablate = gram_ablate_mask();
     // single-plane bf16: the LDS-DMA kernel (GS_BF16_NO_GLDS=1 keeps the register-staged one for A/B runs)
-    static const bool glds = getenv("GS_BF16_NO_GLDS") == nullptr;
-    static const int glds_order = getenv("GS_BF16_SAME_ORDER") == nullptr ? 1 : 0;
+    static const bool glds = gs_knob("GS_BF16_NO_GLDS") == nullptr;
+    static const int glds_order = gs_knob("GS_BF16_SAME_ORDER") == nullptr ? 1 : 0;
 #ifdef GS_WIDE_TRACE_BUILD
     static int dumped = 0;
     if (fold.trace != nullptr && precision == GS_PREC_BF16 && dumped < 2) {

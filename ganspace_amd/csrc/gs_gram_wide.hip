@@ -257,11 +257,10 @@ int launch_gram_f32_wide(int grid, int nfold, const float *X, int64_t n, int64_t
     const size_t lds_bytes = (size_t)2 * kFStageBytes;
     GS_REQUIRE(ld < ((int64_t)1 << 27) && ld % 4 == 0 && (reinterpret_cast<uintptr_t>(X) & 15) == 0, GS_EINVAL,
                "gram (wide): rows must be 16-byte aligned");
-    static bool attr = false;
-    if (!attr) {
-        GS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gram_f32_wide_kernel),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-        attr = true;
+    static LdsOptIn once;
+    {
+        const int rco = lds_opt_in(once, reinterpret_cast<const void *>(gram_f32_wide_kernel), lds_bytes);
+        if (rco != GS_OK) return rco;
     }
     // measurement only (results wrong by design): GS_GRAM_ABLATE bit 0 no MFMA, bit 1 no LDS writes, bit 2 no loads
     const int ablate = gram_ablate_mask();

@@ -73,6 +73,10 @@ struct gs_ipca {
     hipStream_t aux = nullptr;
     hipEvent_t ev_in = nullptr, ev_out = nullptr;
     int last_mults = 0;          // multiplications by A used by the last subspace solve (0 = full Jacobi)
+    // FAITHFUL: the invariant-subspace step of the last block is enqueued but its verdict has not been read
+    // (invsub_begin / invsub_finish): the next call - whatever it is - resolves it first (faithful_resolve)
+    bool inv_pending = false;
+    bool inv_pending_warm = false;
 };
 
 namespace {
@@ -395,7 +399,7 @@ struct StreamScope {
     hipStream_t user, work;
     bool forked = false;
     StreamScope(gs_ipca *h_, hipStream_t user_, bool enable = true) : h(h_), user(user_), work(user_) {
-        static const bool graphs = getenv("GS_USE_GRAPHS") != nullptr;     // (the only reason to leave the caller's stream)
+        static const bool graphs = gs_knob("GS_USE_GRAPHS") != nullptr;     // (the only reason to leave the caller's stream)
         if (graphs && enable && user == nullptr && h->aux != nullptr && hipEventRecord(h->ev_in, user) == hipSuccess &&
             hipStreamWaitEvent(h->aux, h->ev_in, 0) == hipSuccess) {
             work = h->aux;
@@ -412,7 +416,7 @@ struct StreamScope {
 // full Jacobi otherwise or when the residual target is missed.
 int solve_topk(gs_ipca *h, bool warm, const double *total_src, int total_len, hipStream_t stream) {
     const int n = h->n2, dp = (int)h->dp, k = h->k;
-    static const bool no_subspace = getenv("GS_EIGH_FULL") != nullptr;
+    static const bool no_subspace = gs_knob("GS_EIGH_FULL") != nullptr;
     bool done = false, epilogue_done = false;
     h->last_mults = 0;
     if (h->sws.Q != nullptr && !no_subspace) {
@@ -461,6 +465,25 @@ void install_solver_epilogue(gs_ipca *h) {
                   h->mean, h->comp32, h->mean32, (int)h->d, dp, k);
     };
     h->sws.graphs.enabled = true;
+}
+
+// FAITHFUL: read the verdict of the step the last update left in flight.  Accepted: the device has already written the
+// new (Vk, Bk).  Not accepted after the retries: the Rayleigh-Ritz solver runs on the assembled matrix, which is still
+// in h->W (nothing touches it before this call).
+int faithful_resolve(gs_ipca *h, hipStream_t stream) {
+    if (!h->inv_pending) return GS_OK;
+    h->inv_pending = false;
+    int mults = 0, converged = 0;
+    int rc = invsub_finish(h->sws, stream, &mults, &converged);
+    if (rc != GS_OK) return rc;
+    if (converged) {
+        h->pending_diag = true;
+        h->last_mults = mults;
+        h->last_sweeps = 0;
+        h->sws.guards_valid = false;   // the Rayleigh-Ritz solver's guard columns belong to an older matrix
+        return GS_OK;
+    }
+    return solve_topk(h, h->inv_pending_warm, h->m2, (int)h->d, stream);
 }
 
 // FAITHFUL with the diagonalisation deferred: (Vk, Bk) -> eigenpairs of Bk rotate the basis into the components
@@ -778,6 +801,7 @@ int gs_ipca_create(int64_t d, int k, int mode, int precision, int device, gs_ipc
 int gs_ipca_destroy(gs_ipca_t *h) {
     if (!h) return GS_OK;
     (void)hipSetDevice(h->device);
+    if (h->inv_pending) (void)hipDeviceSynchronize();      // a subspace step in flight still uses the buffers freed below
     gram_workspace_free(h->gws);
     eigh_workspace_free(h->ews);
     smallside_free(h->ss);
@@ -798,6 +822,12 @@ int gs_ipca_destroy(gs_ipca_t *h) {
 
 int gs_ipca_reset(gs_ipca_t *h) {
     GS_REQUIRE(h != nullptr, GS_EINVAL, "gs_ipca_reset: NULL handle");
+    if (h->inv_pending) {
+        // a subspace step in flight writes into Vk / Bk when it is accepted: let it finish, then forget it
+        int mults = 0, converged = 0;
+        (void)invsub_finish(h->sws, nullptr, &mults, &converged);
+        h->inv_pending = false;
+    }
     h->n_seen = 0;
     h->blocks = 0;
     h->finalized = false;
@@ -880,7 +910,12 @@ int gs_ipca_update(gs_ipca_t *h, const float *X, int64_t rows, int64_t ld, void 
         return GS_OK;
     }
     // ---- FAITHFUL: close the block ---------------------------------------------------------
+    // This block's Gram launch goes out BEFORE the host waits for the verdict of the previous block's subspace step: the
+    // launch only needs the shift (final since the previous call) and its own accumulators, and the GPU has it to chew
+    // on while the host reads the verdict and enqueues the next chain
     int rc = gram_update(h->gws, X, rows, ld, d, h->shift, h->G64, h->S1, false, /*defer=*/false, stream);
+    if (rc != GS_OK) return rc;
+    rc = faithful_resolve(h, stream);
     if (rc != GS_OK) return rc;
     const double n0 = (double)h->n_seen, m = (double)rows;
     hipLaunchKernelGGL(faithful_stats_kernel, dim3((unsigned)ceil_div(d, 256)), dim3(256), 0, stream, h->S1,
@@ -896,26 +931,27 @@ int gs_ipca_update(gs_ipca_t *h, const float *X, int64_t rows, int64_t ld, void 
     h->blocks += 1;
     // From the fifth block on the k leading eigenvalues of W sit (n0 / m + 1) times above the rest: carry the
     // invariant subspace by orthogonal iteration and leave the diagonalisation to whoever reads the components.
-    static const bool eager = getenv("GS_FAITHFUL_EAGER") != nullptr;
+    static const bool eager = gs_knob("GS_FAITHFUL_EAGER") != nullptr;
     bool carried = false;
+    // the shift of the NEXT block's Gram launch (only needs the mean: ahead of the solver chain)
+    hipLaunchKernelGGL(mean_to_shift_kernel, dim3((unsigned)ceil_div(dp, 256)), dim3(256), 0, stream, h->mean,
+                       h->shift, d, dp);
     if (!eager && h->sws.Q != nullptr && h->k <= 128 && n0 >= 4.0 * m) {
-        int mults = 0, converged = 0;
-        rc = invsub_iterate(h->sws, h->W, h->n2, dp, h->k, h->Vk, dp, h->Bk, h->k, n0 / m, &mults, &converged, stream);
+        // enqueue the step and return: the acceptance test and the emit run on the device, the verdict is read by the next
+        // call on this handle (faithful_resolve), behind that call's Gram launch
+        int started = 0;
+        rc = invsub_begin(h->sws, h->W, h->n2, dp, h->k, h->Vk, dp, h->Bk, h->k, n0 / m, stream, false, &started);
         if (rc != GS_OK) return rc;
-        if (converged) {
+        if (started) {
             carried = true;
-            h->pending_diag = true;
-            h->last_mults = mults;
-            h->last_sweeps = 0;
-            h->sws.guards_valid = false;   // the Rayleigh-Ritz solver's guard columns belong to an older matrix
+            h->inv_pending = true;
+            h->inv_pending_warm = n0 > 0;
         }
     }
     if (!carried) {
         rc = solve_topk(h, /*warm=*/n0 > 0, h->m2, d, stream);
         if (rc != GS_OK) return rc;
     }
-    hipLaunchKernelGGL(mean_to_shift_kernel, dim3((unsigned)ceil_div(dp, 256)), dim3(256), 0, stream, h->mean,
-                       h->shift, d, dp);
     GS_HIP_CHECK(hipGetLastError());
     h->finalized = true;
     return GS_OK;
@@ -1012,6 +1048,10 @@ int gs_ipca_finalize(gs_ipca_t *h, float *components_host, double *singular_valu
     StreamScope scope(h, (hipStream_t)stream_);
     hipStream_t stream = scope.work;
     const int d = (int)h->d, k = h->k;
+    {
+        const int rcp = faithful_resolve(h, stream);      // (the last block's subspace step may still be in flight)
+        if (rcp != GS_OK) return rcp;
+    }
     if (h->mode == GS_MODE_EXACT && !h->finalized) {
         int rc = exact_solve(h, stream);
         if (rc != GS_OK) return rc;
@@ -1054,12 +1094,14 @@ int gs_ipca_finalize(gs_ipca_t *h, float *components_host, double *singular_valu
     return GS_OK;
 }
 
+// (diagnostics of the last RESOLVED solve: a faithful block's subspace step is read by the next call on the handle)
 int gs_ipca_last_sweeps(const gs_ipca_t *h) { return h ? h->last_sweeps : GS_EINVAL; }
 int gs_ipca_last_mults(const gs_ipca_t *h) { return h ? h->last_mults : GS_EINVAL; }
 
 int gs_ipca_components_device(gs_ipca_t *h, const float **components, const float **mean) {
     GS_REQUIRE(h != nullptr, GS_EINVAL, "gs_ipca_components_device: NULL handle");
-    GS_REQUIRE(h->finalized && !h->pending_diag, GS_ESTATE, "gs_ipca_components_device: call finalize first");
+    GS_REQUIRE(h->finalized && !h->pending_diag && !h->inv_pending, GS_ESTATE,
+               "gs_ipca_components_device: call finalize first");
     if (components) *components = h->comp32;
     if (mean) *mean = h->mean32;
     return GS_OK;
@@ -1179,6 +1221,21 @@ int gs_cholqr(const double *Y, int n, int p, double *Q, double *rdiag, void *str
     return rc;
 }
 
+int gs_gemm_f64(int M, int N, int K, const double *A, int64_t a_i, int64_t a_t, const double *B, int64_t b_t, int64_t b_j,
+                double *C, int64_t ldc, double alpha, double beta, const double *coef, const double *E1, const double *E2,
+                void *stream_) {
+    GS_REQUIRE(A && B && C && M >= 1 && N >= 1 && K >= 1 && ldc >= N, GS_EINVAL, "gs_gemm_f64: bad argument");
+    GemmEpilogue epi;
+    epi.coef = coef;
+    epi.E1 = E1;
+    epi.E2 = E2;
+    // (beta != 0 or an epilogue rules out the split-K path with its atomic epilogue on a zeroed C)
+    gemm_f64(M, N, K, A, a_i, a_t, B, b_t, b_j, C, ldc, (hipStream_t)stream_, alpha, beta, epi, /*allow_split=*/true,
+             /*c_is_zero=*/false);
+    GS_HIP_CHECK(hipGetLastError());
+    return GS_OK;
+}
+
 int gs_jacobi_small(const double *B, int p, double *U, double *theta, int *info_host, void *stream_) {
     GS_REQUIRE(B && U && theta, GS_EINVAL, "gs_jacobi_small: NULL argument");
     hipStream_t stream = (hipStream_t)stream_;
@@ -1262,6 +1319,10 @@ int gs_ipca_lowrank_export(gs_ipca_t *h, double *state, void *stream_) {
         GS_HIP_CHECK(hipMemsetAsync(state, 0, (size_t)gs_ipca_lowrank_nbytes(h), stream));
         return GS_OK;
     }
+    {
+        const int rcp = faithful_resolve(h, stream);
+        if (rcp != GS_OK) return rcp;
+    }
     // a deferred diagonalisation is folded back first: the state leaves as unit components + eigenvalues
     if (h->pending_diag && h->mode == GS_MODE_SMALLSIDE) {
         int rc = smallside_materialize(h->ss, h->comp32, h->lam, &h->last_sweeps, stream);
@@ -1286,6 +1347,10 @@ int gs_ipca_lowrank_merge(gs_ipca_t *h, const double *states, int nstates, void 
     GS_REQUIRE(h->mode == GS_MODE_FAITHFUL || h->mode == GS_MODE_SMALLSIDE, GS_ESTATE,
                "gs_ipca_lowrank_merge: GS_MODE_FAITHFUL / GS_MODE_SMALLSIDE handles only");
     hipStream_t stream = (hipStream_t)stream_;
+    {
+        const int rcp = faithful_resolve(h, stream);      // (the merge replaces the state: finish what is in flight first)
+        if (rcp != GS_OK) return rcp;
+    }
     const int64_t d = h->d, len = lowrank_len(h);
     const int k = h->k, P = nstates, R = P * (k + 1);
     // sample counts on the host

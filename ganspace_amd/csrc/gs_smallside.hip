@@ -394,35 +394,34 @@ __global__ __launch_bounds__(256, 2) void tn_gemm_kernel(const float *__restrict
     const int64_t colB = tj * kRT + c4 * 4;
     const bool okB = colB < d;
 
-    float4 ra[4], rb[4];
-    auto fetch = [&](int t0) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            // rows t >= r of Ct are zero (the coefficient kernels write 0 there, the buffer is cleared per block): the
-            // product needs no mask, and no select on a freshly loaded value stalls the other loads
-            const int t = t0 + rr + 8 * i;
-            const int tc = t < r ? t : r - 1;
-            ra[i] = *reinterpret_cast<const float4 *>(Ct + (int64_t)(t < r ? t : r) * kp + colA);
-            rb[i] = *reinterpret_cast<const float4 *>(M + mblk(tc, okB ? colB : 0, ldm));
-        }
-    };
-    auto stash = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            *reinterpret_cast<float4 *>(&lds[buf][0][rr + 8 * i][c4 * 4]) = ra[i];
-            *reinterpret_cast<float4 *>(&lds[buf][1][rr + 8 * i][c4 * 4]) = rb[i];
-        }
-    };
+    // (named registers and macros instead of arrays captured by lambdas: the arrays were materialised in 80 B of scratch)
+    float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
+    // rows t >= r of Ct are zero (the coefficient kernels write 0 there, the buffer is cleared per block): the product
+    // needs no mask, and no select on a freshly loaded value stalls the other loads
+#define GS_TN_FETCH1(i, t0)                                                                              \
+    {                                                                                                    \
+        const int t_ = (t0) + rr + 8 * (i);                                                              \
+        const int tc_ = t_ < r ? t_ : r - 1;                                                             \
+        ra##i = *reinterpret_cast<const float4 *>(Ct + (int64_t)(t_ < r ? t_ : r) * kp + colA);          \
+        rb##i = *reinterpret_cast<const float4 *>(M + mblk(tc_, okB ? colB : 0, ldm));                   \
+    }
+#define GS_TN_FETCH(t0) GS_TN_FETCH1(0, t0) GS_TN_FETCH1(1, t0) GS_TN_FETCH1(2, t0) GS_TN_FETCH1(3, t0)
+#define GS_TN_STASH1(i, buf)                                                        \
+    *reinterpret_cast<float4 *>(&lds[buf][0][rr + 8 * (i)][c4 * 4]) = ra##i;        \
+    *reinterpret_cast<float4 *>(&lds[buf][1][rr + 8 * (i)][c4 * 4]) = rb##i;
+#define GS_TN_STASH(buf) GS_TN_STASH1(0, buf) GS_TN_STASH1(1, buf) GS_TN_STASH1(2, buf) GS_TN_STASH1(3, buf)
     f32x16 acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};
     const int nst = (r + 31) / 32;
     const int arow = lane >> 5;
     const int acol = wi * 64 + (lane & 31), bcol = wj * 64 + (lane & 31);
-    fetch(0);
-    stash(0);
+    GS_TN_FETCH(0)
+    GS_TN_STASH(0)
     __syncthreads();
     for (int s = 0; s < nst; ++s) {
         const int buf = s & 1;
-        if (s + 1 < nst) fetch((s + 1) * 32);
+        // (unconditional: past the last stage the clamped rows are fetched again and stashed into the buffer nobody reads
+        //  any more)
+        GS_TN_FETCH((s + 1) * 32)
         const float *A = &lds[buf][0][arow][acol];
         const float *B = &lds[buf][1][arow][bcol];
 #pragma unroll
@@ -434,9 +433,13 @@ __global__ __launch_bounds__(256, 2) void tn_gemm_kernel(const float *__restrict
             acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc10, 0, 0, 0);
             acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc11, 0, 0, 0);
         }
-        if (s + 1 < nst) stash(buf ^ 1);
+        GS_TN_STASH(buf ^ 1)
         __syncthreads();
     }
+#undef GS_TN_FETCH
+#undef GS_TN_FETCH1
+#undef GS_TN_STASH
+#undef GS_TN_STASH1
     const int row_base = ti * kRT + wi * 64 + 4 * (lane >> 5);
     const int64_t col0 = tj * kRT + wj * 64 + (lane & 31), col1 = col0 + 32;
 #pragma unroll
@@ -755,16 +758,11 @@ int smallside_update(SmallSide &ss, const float *X, int64_t rows, int64_t ldx, d
     } else {
         const bool x6 = ss.precision == GS_PREC_BF16X6;
         const size_t lds = (size_t)2 * (x6 ? 3 : 2) * 2 * kPanelB;
-        static bool attr6 = false, attr3 = false;
-        if (x6 && !attr6) {
-            GS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(rowgram_bf16_kernel<6>),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            attr6 = true;
-        }
-        if (!x6 && !attr3) {
-            GS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(rowgram_bf16_kernel<3>),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            attr3 = true;
+        static LdsOptIn once6, once3;
+        {
+            const int rco = x6 ? lds_opt_in(once6, reinterpret_cast<const void *>(rowgram_bf16_kernel<6>), lds)
+                               : lds_opt_in(once3, reinterpret_cast<const void *>(rowgram_bf16_kernel<3>), lds);
+            if (rco != GS_OK) return rco;
         }
         if (x6)
             hipLaunchKernelGGL(rowgram_bf16_kernel<6>, dim3(rgrid), dim3(256), lds, stream, ss.M, d, (int64_t)rp, ss.slab,
@@ -782,8 +780,8 @@ int smallside_update(SmallSide &ss, const float *X, int64_t rows, int64_t ldx, d
     GS_HIP_CHECK(hipMemsetAsync(ss.Ct, 0, sizeof(float) * (size_t)rp * kp, stream));
     bool done = false;
     ss.last_mults = 0;
-    static const bool no_subspace = getenv("GS_EIGH_FULL") != nullptr;
-    static const bool eager = getenv("GS_FAITHFUL_EAGER") != nullptr;
+    static const bool no_subspace = gs_knob("GS_EIGH_FULL") != nullptr;
+    static const bool eager = gs_knob("GS_FAITHFUL_EAGER") != nullptr;
     const int64_t ntn = ceil_div(d, kRT);
     // From the fifth block on: carry W = Q^T M for an orthonormal basis Q of T's leading invariant subspace (rows
     // whose Gram matrix is the truncated operator - exactly what the next block stacks on top of its data) and leave

@@ -159,6 +159,12 @@ void gemm_f64(int M, int N, int K, const double *A, int64_t a_i, int64_t a_t, co
               int64_t b_j, double *C, int64_t ldc, hipStream_t stream, double alpha, double beta,
               const GemmEpilogue &epi, bool allow_split, bool c_is_zero) {
     if (M <= 0 || N <= 0) return;
+    // round 4: the f64 matrix pipe (gs_dense64.hip); the VALU kernel below stays for A/B runs of the measurement build
+    static const bool valu = gs_knob("GS_GEMM_VALU") != nullptr;
+    if (!valu) {
+        mm64(M, N, K, A, a_i, a_t, B, b_t, b_j, C, ldc, stream, alpha, beta, epi, allow_split, c_is_zero);
+        return;
+    }
     const bool small_tiles = ceil_div(M, 64) * ceil_div(N, 64) < 64;
     const int TMv = small_tiles ? 32 : 64;
     const int64_t tiles = ceil_div(M, TMv) * ceil_div(N, TMv);
@@ -166,7 +172,7 @@ void gemm_f64(int M, int N, int K, const double *A, int64_t a_i, int64_t a_t, co
     int splits = 1;
     // experiment knob: workgroups a split-K launch aims for
     static const int target_wgs = []() {
-        const char *e = getenv("GS_GEMM_TARGET_WGS");
+        const char *e = gs_knob("GS_GEMM_TARGET_WGS");
         return e ? atoi(e) : 640;      // (160 -> 640: small-side block at d = 131 072 7.3 -> 6.9 ms, profiles/r03_probes.md)
     }();
     if (allow_split && beta == 0.0 && tiles < 128 && K >= 256) {
@@ -508,6 +514,8 @@ void graph_cache_free(GraphCache &gc) {
 
 void subspace_workspace_free(SubspaceWorkspace &ws) {
     graph_cache_free(ws.graphs);
+    if (ws.inv_host) (void)hipHostFree(ws.inv_host);
+    if (ws.inv_event) (void)hipEventDestroy(ws.inv_event);
     double *ptrs[] = {ws.pool, ws.G, ws.H, ws.B, ws.U, ws.theta, ws.Rm, ws.Dinv};
     for (double *p : ptrs)
         if (p) (void)hipFree(p);
@@ -516,9 +524,14 @@ void subspace_workspace_free(SubspaceWorkspace &ws) {
 }
 
 int ring_reset(SubspaceWorkspace &ws, hipStream_t stream) {
-    if (!g_dry_run) GS_HIP_CHECK(hipMemsetAsync(ws.pool, 0, sizeof(double) * ws.pool_elems, stream));
-    for (int i = 0; i < ws.ring_n; ++i) ws.ring_clean[i] = true;
-    for (int i = 0; i < SubspaceWorkspace::kHRing; ++i) ws.h_clean[i] = true;
+    // Round 3 zeroed the whole pool here (one memset instead of a zeroing launch per split-K product).  The matrix-pipe
+    // products (mm64) split K inside the workgroup and write their tile once, so nothing needs a zeroed slot any more
+    // (a product that does split K over workgroups - K >= 1024 with few tiles - zeroes its own output): the memset
+    // was 6-8 us of every solve.  The VALU kernel of the measurement build still wants it.
+    static const bool valu = gs_knob("GS_GEMM_VALU") != nullptr;
+    if (valu && !g_dry_run) GS_HIP_CHECK(hipMemsetAsync(ws.pool, 0, sizeof(double) * ws.pool_elems, stream));
+    for (int i = 0; i < ws.ring_n; ++i) ws.ring_clean[i] = valu;
+    for (int i = 0; i < SubspaceWorkspace::kHRing; ++i) ws.h_clean[i] = valu;
     ws.ring_next = 0;
     ws.h_next = 0;
     return GS_OK;
@@ -542,7 +555,7 @@ double *hring_take(SubspaceWorkspace &ws, bool *clean_out) {
 
 int subspace_dim(int n, int k, int guards) {
     static const int extra_env = []() {
-        const char *e = getenv("GS_SUBSPACE_EXTRA");     // experiment knob: guard columns beyond k
+        const char *e = gs_knob("GS_SUBSPACE_EXTRA");     // experiment knob: guard columns beyond k
         return e ? atoi(e) : 0;
     }();
     // guard columns: the iteration converges like (lambda_{p+1} / lambda_k)^products, every product / CholeskyQR /
@@ -567,7 +580,7 @@ int eigh_topk_subspace(SubspaceWorkspace &ws, const double *A, int n, int64_t ld
                        hipStream_t stream) {
     const int p = subspace_dim(n, k, ws.guards);
     GS_REQUIRE(p > 0 && n <= ws.n_cap && p <= ws.p_cap, GS_EINVAL, "eigh_topk_subspace: bad sizes");
-    static const bool legacy = getenv("GS_SUBSPACE_LEGACY") != nullptr;
+    static const bool legacy = gs_knob("GS_SUBSPACE_LEGACY") != nullptr;
     if (p <= 128 && !legacy)
         return eigh_topk_cheb(ws, A, n, lda, k, V0, k0, ldv0, Vk, ldv, lam, iters_out, converged, stream);
     const int64_t ld = ws.pp;

@@ -629,6 +629,8 @@ __global__ void topk_seed_kernel(double *__restrict__ Q, int n, int64_t ldq, con
     if (j < k0) Q[(int64_t)i * ldq + j] = V0 ? V0[(int64_t)j * ldv + i] : (i == j ? 1.0 : 0.0);
 }
 
+__global__ void invsub_loewdin2_kernel(double *__restrict__ H, int64_t ld, int k, double *__restrict__ emax);
+
 static size_t jacobi_lds_bytes() {
     return sizeof(double) * ((size_t)kJacLd * kJacLd + kJacLd) + sizeof(int) * kJacLd + 32;
 }
@@ -636,22 +638,19 @@ static size_t jacobi_lds_bytes() {
 // LDS opt-in of the single-workgroup kernels, once per process and BEFORE any of them is launched inside a stream
 // capture (subspace_workspace_alloc calls this)
 int topk_prepare_kernels() {
-    static bool done = false;
-    if (done) return GS_OK;
-    GS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(chol_blocked_kernel),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)kCholLdsBytes));
-#define GS_JAC_ATTR(NT, LP)                                                                         \
-    GS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(jacobi_lds_kernel<NT, LP>),    \
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)jacobi_lds_bytes()))
-    GS_JAC_ATTR(4, 8);
-    GS_JAC_ATTR(8, 8);
-    GS_JAC_ATTR(12, 8);
-    GS_JAC_ATTR(16, 8);
-    GS_JAC_ATTR(4, 16);
-    GS_JAC_ATTR(8, 16);
+    static LdsOptIn o_chol, o_j48, o_j88, o_j128, o_j168, o_j416, o_j816, o_l2;
+    int rc = lds_opt_in(o_chol, reinterpret_cast<const void *>(chol_blocked_kernel), kCholLdsBytes);
+#define GS_JAC_ATTR(once, NT, LP) \
+    if (rc == GS_OK) rc = lds_opt_in(once, reinterpret_cast<const void *>(jacobi_lds_kernel<NT, LP>), jacobi_lds_bytes())
+    GS_JAC_ATTR(o_j48, 4, 8);
+    GS_JAC_ATTR(o_j88, 8, 8);
+    GS_JAC_ATTR(o_j128, 12, 8);
+    GS_JAC_ATTR(o_j168, 16, 8);
+    GS_JAC_ATTR(o_j416, 4, 16);
+    GS_JAC_ATTR(o_j816, 8, 16);
 #undef GS_JAC_ATTR
-    done = true;
-    return GS_OK;
+    if (rc == GS_OK) rc = lds_opt_in(o_l2, reinterpret_cast<const void *>(invsub_loewdin2_kernel), sizeof(double) * 128 * 129);
+    return rc;
 }
 
 int chol_blocked_launch(const double *H, int64_t ldh, int p, double *Rm, int64_t ldr, double *Dinv, double *rdiag,
@@ -661,7 +660,7 @@ int chol_blocked_launch(const double *H, int64_t ldh, int p, double *Rm, int64_t
         int rcp = topk_prepare_kernels();
         if (rcp != GS_OK) return rcp;
     }
-    static const int debug = getenv("GS_TOPK_DEBUG") ? 1 : 0;
+    static const int debug = gs_knob("GS_TOPK_DEBUG") ? 1 : 0;
     GS_LAUNCH(chol_blocked_kernel, dim3(1), dim3(1024), kCholLdsBytes, stream, H, ldh, p, Rm, ldr, Dinv,
                        rdiag, debug);
     GS_HIP_CHECK(hipGetLastError());
@@ -675,7 +674,7 @@ static int jacobi_launch_nt(const double *B, int64_t ldb, int p, double *U, int6
         int rcp = topk_prepare_kernels();
         if (rcp != GS_OK) return rcp;
     }
-    static const int debug = getenv("GS_TOPK_DEBUG") ? 1 : 0;
+    static const int debug = gs_knob("GS_TOPK_DEBUG") ? 1 : 0;
     GS_LAUNCH((jacobi_lds_kernel<NT, LP>), dim3(1), dim3((p / 2) * LP), jacobi_lds_bytes(), stream, B, ldb, p, U, ldu,
               theta, info, debug);
     GS_HIP_CHECK(hipGetLastError());
@@ -688,7 +687,7 @@ int jacobi_small_launch(const double *B, int64_t ldb, int p, double *U, int64_t 
     // lanes per column pair: 8 (4 p threads, p / 8 rows per lane) or 16 (8 p threads, twice the waves per SIMD to hide
     // the LDS round trips of a round behind the other waves' rotations); GS_JACOBI_LP overrides
     static const int lp_env = []() {
-        const char *e = getenv("GS_JACOBI_LP");
+        const char *e = gs_knob("GS_JACOBI_LP");
         return e ? atoi(e) : 0;
     }();
     const int lp = lp_env == 8 || lp_env == 16 ? lp_env : kJacobiDefaultLP;
@@ -712,9 +711,17 @@ int orth_fast(SubspaceWorkspace &ws, const double *Y, double *Qout, int n, int p
     bool clean = false;
     double *H = hring_take(ws, &clean);
     gemm_f64(p, p, n, Y, 1, ld, Y, ld, 1, H, ld, stream, 1.0, 0.0, none, true, clean);
-    int rc = chol_blocked_launch(H, ld, p, ws.Rm, ld, ws.Dinv, ws.theta + 2 * ws.pp, stream);
+    static const bool old_chol = gs_knob("GS_CHOL_R3") != nullptr;      // round-3 factorisation + row-parallel solve
+    if (old_chol) {
+        int rc = chol_blocked_launch(H, ld, p, ws.Rm, ld, ws.Dinv, ws.theta + 2 * ws.pp, stream);
+        if (rc != GS_OK) return rc;
+        return trsm_rows_launch(Y, Qout, ld, n, p, ws.Rm, ws.Dinv, stream);
+    }
+    // one single-workgroup launch leaves R^-1; Q = Y R^-1 is then a plain product on the matrix pipe
+    int rc = chol_inv_launch(H, ld, p, ws.Rm, ld, ws.theta + 2 * ws.pp, stream);
     if (rc != GS_OK) return rc;
-    return trsm_rows_launch(Y, Qout, ld, n, p, ws.Rm, ws.Dinv, stream);
+    gemm_f64(n, p, p, Y, ld, 1, ws.Rm, ld, 1, Qout, ld, stream, 1.0, 0.0, none, false);
+    return GS_OK;
 }
 
 // ---- invariant-subspace iteration (faithful recurrence, diagonalisation deferred) ------------------------------
@@ -741,32 +748,231 @@ __global__ __launch_bounds__(256) void invsub_resid_kernel(const double *__restr
 }
 
 // Vk rows <- columns of Q (zero beyond n), Bk <- (B + B^T) / 2
+//   (only if the device-side acceptance test passed: verdict[0] != 0)
 __global__ void invsub_emit_kernel(const double *__restrict__ Q, int64_t ld, int n, int k, double *__restrict__ Vk,
                                    int64_t ldv, const double *__restrict__ B, int64_t ldb, double *__restrict__ Bk,
-                                   int64_t ldbk) {
+                                   int64_t ldbk, const double *__restrict__ verdict) {
+    if (verdict[0] == 0.0) return;
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     const int i = blockIdx.y;
     if (e < ldv) Vk[(int64_t)i * ldv + e] = (e < n) ? Q[(int64_t)e * ld + i] : 0.0;
     if (e < k) Bk[(int64_t)i * ldbk + e] = 0.5 * (B[(int64_t)i * ldb + e] + B[(int64_t)e * ldb + i]);
 }
 
-// H = Q^T Q  ->  1.5 I - 0.5 H  (in place)
-__global__ void invsub_loewdin_kernel(double *__restrict__ H, int64_t ld, int k) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    const int i = blockIdx.y;
-    if (j < k) H[(int64_t)i * ld + j] = (i == j ? 1.5 : 0.0) - 0.5 * H[(int64_t)i * ld + j];
+// H = Q^T Q (k x k, k <= 128), E = H - I small:  H <- I - E / 2 + 3 E^2 / 8  =  (I + E)^-1/2 + O(E^3), so that Q H is
+// orthonormal to ~|E|^3: the symmetric (Loewdin) correction to second order.  One workgroup; E^2 on the f64 matrix pipe
+// with E in LDS.  emax[0] = max |E_ij| for the host's acceptance test.
+__global__ __launch_bounds__(1024) void invsub_loewdin2_kernel(double *__restrict__ H, int64_t ld, int k,
+                                                               double *__restrict__ emax) {
+    extern __shared__ __attribute__((aligned(16))) double lsm[];
+    const int kp = (k + 15) & ~15, lde = kp + 1;
+    double *E = lsm;                      // [kp][kp + 1]
+    __shared__ double wmax[16];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lg = lane >> 4;
+    double mx = 0.0;
+    for (int e = tid; e < kp * kp; e += 1024) {
+        const int i = e / kp, j = e - i * kp;
+        double v = 0.0;
+        if (i < k && j < k) v = H[(int64_t)i * ld + j] - (i == j ? 1.0 : 0.0);
+        E[i * lde + j] = v;
+        mx = fmax(mx, fabs(v));
+    }
+    for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o));
+    if (lane == 0) wmax[wave] = mx;
+    __syncthreads();
+    if (tid == 0) {
+        double m = 0.0;
+        for (int w = 0; w < 16; ++w) m = fmax(m, wmax[w]);
+        emax[0] = m;
+    }
+    const int nt = kp >> 4;
+    for (int tile = wave; tile < nt * nt; tile += 16) {
+        const int i0 = 16 * (tile / nt), j0 = 16 * (tile % nt);
+        typedef double d4 __attribute__((ext_vector_type(4)));
+        d4 acc = {0.0, 0.0, 0.0, 0.0};
+        for (int k0 = 0; k0 < kp; k0 += 16) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const int kk = k0 + 4 * lg + m;
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(E[(i0 + li) * lde + kk], E[kk * lde + j0 + li], acc, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = i0 + lg + 4 * r, j = j0 + li;
+            if (i < k && j < k) H[(int64_t)i * ld + j] = (i == j ? 1.0 : 0.0) - 0.5 * E[i * lde + j] + 0.375 * acc[r];
+        }
+    }
 }
 
-int invsub_iterate(SubspaceWorkspace &ws, const double *A, int n, int64_t lda, int k, double *Vk, int64_t ldv,
-                   double *Bk, int64_t ldbk, double blocks_seen, int *mults_out, int *converged, hipStream_t stream,
-                   bool identity_start) {
+// The acceptance test of an invariant-subspace attempt, on the device - so that the result can be emitted (or not) without
+// the host in the loop, and the host reads the verdict whenever it gets to it (the next block's Gram launch is already
+// queued by then).  theta = [ diag(B) | squared residuals | diag(R) of the last CholeskyQR | ... | emax at 3 pp + 14 ].
+//   verdict = { accepted, rel = worst residual / target, lambda_1 / lambda_k per product, lambda_k, theta_1 }
+// Target: ||A Q - Q B|| per column <= tol_rel lambda_k - relative to the SMALLEST wanted eigenvalue (the subspace is carried
+// from block to block; an error relative to lambda_1 would swamp the trailing components of a steep spectrum) - floored at
+// what float64 products resolve, 3e-14 theta_1.  R_ii ~ lambda_i^jj after jj products.
+__global__ __launch_bounds__(128) void invsub_judge_kernel(const double *__restrict__ theta, int pp, int k, int jj_last,
+                                                           double tol_rel, int loewdin, double *__restrict__ verdict) {
+    __shared__ double s_th1[128], s_w2[128], s_rmax[128], s_rmin[128];
+    __shared__ int s_bad[128];
+    const int t = threadIdx.x;
+    double th1 = 0.0, w2 = 0.0, rmax = 0.0, rmin = 1e300;
+    int bad = 0;
+    for (int i = t; i < k; i += 128) {
+        const double bd = theta[i], rs = theta[pp + i], rd = theta[2 * pp + i];
+        if (!(rs == rs) || !(rd > 0.0)) bad = 1;          // NaN, or a dead pivot (rank lost)
+        th1 = bd > th1 ? bd : th1;
+        w2 = rs > w2 ? rs : w2;
+        rmax = rd > rmax ? rd : rmax;
+        rmin = rd < rmin ? rd : rmin;
+    }
+    s_th1[t] = th1;
+    s_w2[t] = w2;
+    s_rmax[t] = rmax;
+    s_rmin[t] = rmin;
+    s_bad[t] = bad;
+    __syncthreads();
+    for (int o = 64; o > 0; o >>= 1) {
+        if (t < o) {
+            s_th1[t] = fmax(s_th1[t], s_th1[t + o]);
+            s_w2[t] = fmax(s_w2[t], s_w2[t + o]);
+            s_rmax[t] = fmax(s_rmax[t], s_rmax[t + o]);
+            s_rmin[t] = fmin(s_rmin[t], s_rmin[t + o]);
+            s_bad[t] |= s_bad[t + o];
+        }
+        __syncthreads();
+    }
+    if (t == 0) {
+        th1 = s_th1[0];
+        bool sane = !s_bad[0] && th1 > 0.0;
+        if (loewdin && !(theta[3 * pp + 14] <= 1.5e-4)) sane = false;     // the symmetric correction was not small: O(E^3) > 1e-12
+        double rel = 1e300, ratio1 = 0.0, lamk = 0.0;
+        if (sane) {
+            const double ej = 1.0 / (double)jj_last;
+            lamk = pow(s_rmin[0], ej);
+            ratio1 = pow(s_rmax[0] / s_rmin[0], ej);
+            double target = tol_rel * lamk;
+            if (target < 3e-14 * th1) target = 3e-14 * th1;
+            rel = sqrt(s_w2[0]) / target;
+        }
+        verdict[0] = (sane && rel <= 1.0) ? 1.0 : 0.0;
+        verdict[1] = rel;
+        verdict[2] = ratio1;
+        verdict[3] = lamk;
+        verdict[4] = th1;
+        verdict[5] = sane ? 1.0 : 0.0;
+    }
+}
+
+namespace {
+
+// one attempt of the iteration, enqueued: products / CholeskyQR steps / Rayleigh quotient / residuals / device-side
+// verdict / predicated emit / verdict -> pinned host memory / event
+int invsub_enqueue_attempt(SubspaceWorkspace &ws, hipStream_t stream) {
+    InvsubPending &st = ws.inv;
+    const int n = st.n, k = st.k;
+    const int64_t ld = ws.pp;
+    GemmEpilogue none;
+    const int P = st.P, j = st.j;
+    // expected loss of orthogonality of the last CholeskyQR pass: cond(Y)^2 eps (unknown spectrum: assume the worst)
+    {
+        int rem = P, jl = 1;
+        while (rem > 0) {
+            jl = j < rem ? j : rem;
+            rem -= jl;
+        }
+        st.jj_last = jl;
+    }
+    const double e_est = ws.inv_ratio1 > 1.0 ? std::pow(ws.inv_ratio1, 2.0 * st.jj_last) * 1e-16 : 1.0;
+    st.pass2 = e_est > 1e-12;
+    // second-order symmetric correction while the expected |Q^T Q - I| leaves |E|^3 below 1e-12 (the kernel reports
+    // the |E| it saw: a larger one fails the acceptance test); a second CholeskyQR pass otherwise
+    st.loewdin = st.pass2 && e_est <= 1e-4;
+    double *verdict = ws.theta + 3 * ws.pp + 16;
+    auto segment = [&]() -> int {
+        if (st.attempt == 0) {
+            int rcr = ring_reset(ws, stream);
+            if (rcr != GS_OK) return rcr;
+            st.Qc = ring_take(ws, nullptr);
+            GS_LAUNCH(topk_seed_kernel, dim3((unsigned)ceil_div(k, 64), (unsigned)n), dim3(64), 0, stream, st.Qc, n, ld,
+                      st.identity_start ? (const double *)nullptr : st.Vk, k, st.ldv);
+        }
+        int rem = P;
+        while (rem > 0) {
+            const int jj = j < rem ? j : rem;
+            double *cur = st.Qc;
+            for (int s2 = 0; s2 < jj; ++s2) {
+                bool clean = false;
+                double *nxt = ring_take(ws, &clean);
+                gemm_f64(n, k, n, st.A, st.lda, 1, cur, ld, 1, nxt, ld, stream, 1.0, 0.0, none, true, clean);
+                cur = nxt;
+                ++st.used;
+            }
+            double *o = ring_take(ws, nullptr);
+            int rc = orth_fast(ws, cur, o, n, k, stream);   // R diagonal -> theta + 2 pp
+            if (rc != GS_OK) return rc;
+            st.Qc = o;
+            rem -= jj;
+        }
+        // a second pass when the first one cannot have left the basis orthonormal to ~1e-12 (cond^2 eps)
+        if (st.pass2) {
+            bool clean = false;
+            double *H = hring_take(ws, &clean);
+            double *o = ring_take(ws, nullptr);
+            gemm_f64(k, k, n, st.Qc, 1, ld, st.Qc, ld, 1, H, ld, stream, 1.0, 0.0, none, true, clean);
+            if (st.loewdin) {
+                // E = Q^T Q - I is small: the symmetric (Loewdin) correction Q <- Q (I - E / 2 + 3 E^2 / 8) leaves O(E^3) -
+                // one small single-workgroup kernel + a product instead of a second Cholesky + triangular solve; any
+                // orthonormal basis of the same span will do here
+                const int kp16 = (k + 15) & ~15;
+                GS_LAUNCH(invsub_loewdin2_kernel, dim3(1), dim3(1024), sizeof(double) * (size_t)kp16 * (kp16 + 1), stream, H,
+                          ld, k, ws.theta + 3 * ws.pp + 14);
+                gemm_f64(n, k, k, st.Qc, ld, 1, H, ld, 1, o, ld, stream, 1.0, 0.0, none, false);
+            } else {
+                int rc = chol_inv_launch(H, ld, k, ws.Rm, ld, ws.theta, stream);   // keeps theta + 2 pp
+                if (rc != GS_OK) return rc;
+                gemm_f64(n, k, k, st.Qc, ld, 1, ws.Rm, ld, 1, o, ld, stream, 1.0, 0.0, none, false);
+            }
+            st.Qc = o;
+        }
+        bool cleany = false, cleanb = false;
+        double *Yb = ring_take(ws, &cleany), *Zb = ring_take(ws, nullptr);
+        st.Bm = hring_take(ws, &cleanb);
+        gemm_f64(n, k, n, st.A, st.lda, 1, st.Qc, ld, 1, Yb, ld, stream, 1.0, 0.0, none, true, cleany);     // Y = A Q
+        ++st.used;
+        gemm_f64(k, k, n, st.Qc, 1, ld, Yb, ld, 1, st.Bm, ld, stream, 1.0, 0.0, none, true, cleanb);     // B = Q^T Y
+        gemm_f64(n, k, k, st.Qc, ld, 1, st.Bm, ld, 1, Zb, ld, stream, 1.0, 0.0, none, false);            // Z = Q B
+        GS_LAUNCH(invsub_resid_kernel, dim3((unsigned)k), dim3(256), 0, stream, Yb, Zb, ld, st.Bm, ld, n, ws.theta + ws.pp,
+                  ws.theta);
+        GS_LAUNCH(invsub_judge_kernel, dim3(1), dim3(128), 0, stream, ws.theta, ws.pp, k, st.jj_last, 1e-9, st.loewdin ? 1 : 0,
+                  verdict);
+        // optimistic: the new state leaves for the caller's arrays if the device-side test passed
+        GS_LAUNCH(invsub_emit_kernel, dim3((unsigned)ceil_div((int)(st.ldv > k ? st.ldv : k), 256), (unsigned)k), dim3(256), 0,
+                  stream, st.Qc, ld, n, k, st.Vk, st.ldv, st.Bm, ld, st.Bk, st.ldbk, verdict);
+        return GS_OK;
+    };
+    const int rcs = run_as_graph(ws.graphs, graph_key({3, st.attempt, P, j, st.pass2 ? (st.loewdin ? 1 : 2) : 0, st.identity_start,
+                                                       n, k, ws.ring_next, ws.h_next, st.lda, st.ldv, (int64_t)(intptr_t)st.A,
+                                                       (int64_t)(intptr_t)st.Vk, (int64_t)(intptr_t)st.Qc}), stream, segment);
+    if (rcs != GS_OK) return rcs;
+    GS_HIP_CHECK(hipMemcpyAsync(ws.inv_host, verdict, sizeof(double) * 8, hipMemcpyDeviceToHost, stream));
+    GS_HIP_CHECK(hipEventRecord(ws.inv_event, stream));
+    return GS_OK;
+}
+
+}  // namespace
+
+// Schedule and attempt 0 of the invariant-subspace step, enqueued only.  *started = 0 (nothing enqueued): the schedule
+// would cost more than the Rayleigh-Ritz solver.  Otherwise invsub_finish must follow (any time later, before A, Vk or
+// Bk are touched by anyone else).
+int invsub_begin(SubspaceWorkspace &ws, const double *A, int n, int64_t lda, int k, double *Vk, int64_t ldv, double *Bk,
+                 int64_t ldbk, double blocks_seen, hipStream_t stream, bool identity_start, int *started) {
     GS_REQUIRE(k >= 1 && k <= kCholP && k <= ws.p_cap && n <= ws.n_cap && blocks_seen >= 1.0, GS_EINVAL,
                "invsub_iterate: bad sizes");
-    const int64_t ld = ws.pp;
+    GS_REQUIRE(!ws.inv.active, GS_ESTATE, "invsub_begin: the previous step has not been finished");
+    *started = 0;
     const double tol_rel = 1e-9;
-    GemmEpilogue none;
-    *converged = 0;
-    if (mults_out) *mults_out = 0;
     const double ln_gap = std::log(blocks_seen + 1.0);   // lambda_k / lambda_{k+1} >= t + 1
     // products that reach the target from an O(1) start if the gap is what the block count promises (the target is
     // relative to lambda_k, the start residual to lambda_1); the schedule carried over from the previous block is
@@ -788,135 +994,90 @@ int invsub_iterate(SubspaceWorkspace &ws, const double *A, int n, int64_t lda, i
         ws.inv_plan = 0;
         return GS_OK;
     }
-    double *Qc = nullptr;
-    int used = 0;
-    const int P0 = P;
-    std::vector<double> host(3 * (size_t)ws.pp);
-    double *Bm = nullptr;
-    for (int attempt = 0; attempt < 3; ++attempt) {
-        int jj_last = 1;
-        // expected loss of orthogonality of the last CholeskyQR pass: cond(Y)^2 eps (unknown spectrum: assume the worst)
-        {
-            int rem = P, jl = 1;
-            while (rem > 0) {
-                jl = j < rem ? j : rem;
-                rem -= jl;
-            }
-            jj_last = jl;
-        }
-        const double e_est = ws.inv_ratio1 > 1.0 ? std::pow(ws.inv_ratio1, 2.0 * jj_last) * 1e-16 : 1.0;
-        const bool pass2 = e_est > 1e-12;
-        const bool loewdin = pass2 && e_est <= 1e-7;
-        // ---- the whole attempt (products, CholeskyQR steps, Rayleigh quotient, residuals) as ONE graph -------------
-        auto segment = [&]() -> int {
-            if (attempt == 0) {
-                int rcr = ring_reset(ws, stream);     // every block below comes out of the zeroed ring
-                if (rcr != GS_OK) return rcr;
-                Qc = ring_take(ws, nullptr);
-                GS_LAUNCH(topk_seed_kernel, dim3((unsigned)ceil_div(k, 64), (unsigned)n), dim3(64), 0, stream, Qc, n, ld,
-                          identity_start ? (const double *)nullptr : Vk, k, ldv);
-            }
-            int rem = P;
-            while (rem > 0) {
-                const int jj = j < rem ? j : rem;
-                double *cur = Qc;
-                for (int s2 = 0; s2 < jj; ++s2) {
-                    bool clean = false;
-                    double *nxt = ring_take(ws, &clean);
-                    gemm_f64(n, k, n, A, lda, 1, cur, ld, 1, nxt, ld, stream, 1.0, 0.0, none, true, clean);
-                    cur = nxt;
-                    ++used;
-                }
-                double *o = ring_take(ws, nullptr);
-                int rc = orth_fast(ws, cur, o, n, k, stream);   // R diagonal -> theta + 2 pp
-                if (rc != GS_OK) return rc;
-                Qc = o;
-                rem -= jj;
-            }
-            // a second pass when the first one cannot have left the basis orthonormal to ~1e-12 (cond^2 eps)
-            if (pass2) {
-                bool clean = false;
-                double *H = hring_take(ws, &clean);
-                double *o = ring_take(ws, nullptr);
-                gemm_f64(k, k, n, Qc, 1, ld, Qc, ld, 1, H, ld, stream, 1.0, 0.0, none, true, clean);
-                if (loewdin) {
-                    // E = Q^T Q - I is tiny: one step of the symmetric (Loewdin / Newton-Schulz) correction
-                    // Q <- Q (I - E / 2) leaves E^2 - a GEMM with a k x k matrix instead of a second single-workgroup
-                    // Cholesky + triangular solve (56 -> 13 us); any orthonormal basis of the same span will do here
-                    GS_LAUNCH(invsub_loewdin_kernel, dim3((unsigned)ceil_div(k, 64), (unsigned)k), dim3(64), 0, stream, H, ld, k);
-                    gemm_f64(n, k, k, Qc, ld, 1, H, ld, 1, o, ld, stream, 1.0, 0.0, none, false);
-                } else {
-                    int rc = chol_blocked_launch(H, ld, k, ws.Rm, ld, ws.Dinv, ws.theta, stream);   // keeps theta + 2 pp
-                    if (rc != GS_OK) return rc;
-                    rc = trsm_rows_launch(Qc, o, ld, n, k, ws.Rm, ws.Dinv, stream);
-                    if (rc != GS_OK) return rc;
-                }
-                Qc = o;
-            }
-            bool cleany = false, cleanb = false;
-            double *Yb = ring_take(ws, &cleany), *Zb = ring_take(ws, nullptr);
-            Bm = hring_take(ws, &cleanb);
-            gemm_f64(n, k, n, A, lda, 1, Qc, ld, 1, Yb, ld, stream, 1.0, 0.0, none, true, cleany);     // Y = A Q
-            ++used;
-            gemm_f64(k, k, n, Qc, 1, ld, Yb, ld, 1, Bm, ld, stream, 1.0, 0.0, none, true, cleanb);     // B = Q^T Y
-            gemm_f64(n, k, k, Qc, ld, 1, Bm, ld, 1, Zb, ld, stream, 1.0, 0.0, none, false);            // Z = Q B
-            GS_LAUNCH(invsub_resid_kernel, dim3((unsigned)k), dim3(256), 0, stream, Yb, Zb, ld, Bm, ld, n, ws.theta + ws.pp,
-                      ws.theta);
-            return GS_OK;
-        };
-        const int rcs = run_as_graph(ws.graphs, graph_key({3, attempt, P, j, pass2 ? (loewdin ? 1 : 2) : 0, identity_start,
-                                                           n, k, ws.ring_next, ws.h_next, lda, ldv, (int64_t)(intptr_t)A,
-                                                           (int64_t)(intptr_t)Vk, (int64_t)(intptr_t)Qc}), stream, segment);
-        if (rcs != GS_OK) return rcs;
-        GS_HIP_CHECK(hipMemcpyAsync(host.data(), ws.theta, sizeof(double) * 3 * ws.pp, hipMemcpyDeviceToHost, stream));
-        GS_HIP_CHECK(hipStreamSynchronize(stream));
-        const double *bdiag = host.data(), *resid = host.data() + ws.pp, *rdiag = host.data() + 2 * ws.pp;
-        double th1 = 0.0, worst2 = 0.0, rmax = 0.0, rmin = 1e300;
-        bool sane = true;
-        for (int i = 0; i < k; ++i) {
-            if (!(resid[i] == resid[i]) || !(rdiag[i] > 0.0)) sane = false;   // NaN, or a dead pivot (rank lost)
-            th1 = bdiag[i] > th1 ? bdiag[i] : th1;
-            worst2 = resid[i] > worst2 ? resid[i] : worst2;
-            rmax = rdiag[i] > rmax ? rdiag[i] : rmax;
-            rmin = rdiag[i] < rmin ? rdiag[i] : rmin;
-        }
-        if (!sane || !(th1 > 0.0)) break;
-        // R_ii ~ lambda_i^jj after jj products: the target is relative to the SMALLEST wanted eigenvalue (the subspace
-        // is carried from block to block; an error relative to lambda_1 would swamp the trailing components of a
-        // steep spectrum), floored at what float64 products can resolve
-        const double lamk = std::pow(rmin, 1.0 / jj_last);
-        const double ratio1 = std::pow(rmax / rmin, 1.0 / jj_last);
-        double target = tol_rel * lamk;
-        if (target < 3e-14 * th1) target = 3e-14 * th1;
-        const double rel = std::sqrt(worst2) / target;
+    if (ws.inv_host == nullptr) {
+        GS_HIP_CHECK(hipHostMalloc((void **)&ws.inv_host, sizeof(double) * 8, hipHostMallocDefault));
+        GS_HIP_CHECK(hipEventCreateWithFlags(&ws.inv_event, hipEventDisableTiming));
+    }
+    InvsubPending &st = ws.inv;
+    st = InvsubPending();
+    st.A = A;
+    st.n = n;
+    st.lda = lda;
+    st.k = k;
+    st.Vk = Vk;
+    st.ldv = ldv;
+    st.Bk = Bk;
+    st.ldbk = ldbk;
+    st.identity_start = identity_start;
+    st.ln_gap = ln_gap;
+    st.blocks_seen = blocks_seen;
+    st.P = P;
+    st.P0 = P;
+    st.j = j;
+    st.attempt = 0;
+    const int rc = invsub_enqueue_attempt(ws, stream);
+    if (rc != GS_OK) return rc;
+    st.active = true;
+    *started = 1;
+    return GS_OK;
+}
+
+// Host side of the step: wait for the verdict of the attempt in flight; on a miss continue from the current basis with
+// the product count the measured residual asks for (two more attempts, synchronously).  *converged = 1: Vk / Bk hold the
+// new state (the device emitted them); 0: untouched - the caller falls back to the Rayleigh-Ritz solver.
+int invsub_finish(SubspaceWorkspace &ws, hipStream_t stream, int *mults_out, int *converged) {
+    *converged = 0;
+    if (mults_out) *mults_out = 0;
+    InvsubPending &st = ws.inv;
+    if (!st.active) return GS_OK;
+    static const bool debug = gs_knob("GS_TOPK_DEBUG") != nullptr;
+    for (;;) {
+        GS_HIP_CHECK(hipEventSynchronize(ws.inv_event));
+        const double accepted = ws.inv_host[0], rel = ws.inv_host[1], ratio1 = ws.inv_host[2], sane = ws.inv_host[5];
+        if (sane == 0.0) break;
         ws.inv_ratio1 = ratio1;
-        static const bool debug = getenv("GS_TOPK_DEBUG") != nullptr;
         if (debug)
-            fprintf(stderr, "invsub: t=%.0f attempt=%d P=%d j=%d pass2=%d used=%d rel=%.2e ratio1=%.2e lamk/th1=%.2e\n",
-                    blocks_seen, attempt, P, j, (int)pass2, used, rel, ratio1, lamk / th1);
-        if (rel <= 1.0) {
+            fprintf(stderr, "invsub: t=%.0f attempt=%d P=%d j=%d pass2=%d loewdin=%d used=%d rel=%.2e ratio1=%.2e lamk/th1=%.2e\n",
+                    st.blocks_seen, st.attempt, st.P, st.j, (int)st.pass2, (int)st.loewdin, st.used, rel, ratio1,
+                    ws.inv_host[3] / ws.inv_host[4]);
+        if (accepted != 0.0) {
             *converged = 1;
-            GS_LAUNCH(invsub_emit_kernel, dim3((unsigned)ceil_div((int)(ldv > k ? ldv : k), 256), (unsigned)k),
-                               dim3(256), 0, stream, Qc, ld, n, k, Vk, ldv, Bm, ld, Bk, ldbk);
-            GS_HIP_CHECK(hipGetLastError());
-            if (attempt == 0) {
+            if (st.attempt == 0) {
                 // a wide margin shortens the next block's schedule (its gap is wider still)
                 int dec = 0;
-                if (rel < 1.0 / 30.0) dec = (int)std::floor(std::log(1.0 / (30.0 * (rel > 1e-7 ? rel : 1e-7))) / ln_gap);
-                ws.inv_plan = P0 - dec > 1 ? P0 - dec : 1;
+                if (rel < 1.0 / 30.0) dec = (int)std::floor(std::log(1.0 / (30.0 * (rel > 1e-7 ? rel : 1e-7))) / st.ln_gap);
+                ws.inv_plan = st.P0 - dec > 1 ? st.P0 - dec : 1;
             } else {
-                ws.inv_plan = used - 1;
+                ws.inv_plan = st.used - 1;
             }
             break;
         }
-        if (attempt == 2) break;
-        const double need = std::ceil(std::log(10.0 * rel) / ln_gap);
-        P = need < 1.0 ? 1 : (need > 12.0 ? 12 : (int)need);
+        if (st.attempt == 2) break;
+        const double need = std::ceil(std::log(10.0 * rel) / st.ln_gap);
+        st.P = need < 1.0 ? 1 : (need > 12.0 ? 12 : (int)need);
+        ++st.attempt;
+        const int rc = invsub_enqueue_attempt(ws, stream);
+        if (rc != GS_OK) {
+            st.active = false;
+            return rc;
+        }
     }
     if (!*converged) ws.inv_plan = 0;
-    ws.inv_last_products = used;
-    if (mults_out) *mults_out = used;
+    ws.inv_last_products = st.used;
+    if (mults_out) *mults_out = st.used;
+    st.active = false;
     return GS_OK;
+}
+
+int invsub_iterate(SubspaceWorkspace &ws, const double *A, int n, int64_t lda, int k, double *Vk, int64_t ldv,
+                   double *Bk, int64_t ldbk, double blocks_seen, int *mults_out, int *converged, hipStream_t stream,
+                   bool identity_start) {
+    *converged = 0;
+    if (mults_out) *mults_out = 0;
+    int started = 0;
+    const int rc = invsub_begin(ws, A, n, lda, k, Vk, ldv, Bk, ldbk, blocks_seen, stream, identity_start, &started);
+    if (rc != GS_OK || !started) return rc;
+    return invsub_finish(ws, stream, mults_out, converged);
 }
 
 static double cheb_T(int m, double x) { return x <= 1.0 ? 1.0 : std::cosh((double)m * std::acosh(x)); }

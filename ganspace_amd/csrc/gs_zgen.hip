@@ -114,11 +114,117 @@ struct Mt19937 {
             }
         }
     }
+
+    // `count` values of scipy.stats.truncnorm.rvs(a, b, random_state=RandomState(seed)) for a < 0 < b, cast to float32 and
+    // multiplied by `scale` (BigGAN's truncated_noise_sample, models/biggan/pytorch_biggan/pytorch_pretrained_biggan/
+    // utils.py:21-33 with a, b = -2, 2).  SciPy 1.15 has no sampler of its own for this distribution: rv_generic._rvs
+    // draws U = random_state.uniform(size) - one 53-bit double per value, two 32-bit draws each - and returns
+    // truncnorm._ppf(U, a, b), which for a < 0 is
+    //     ndtri_exp( logsumexp([ log_ndtr(a), log(U) + log(ndtr(b) - ndtr(a)) ]) ).
+    // Restated operation by operation: SciPy's two-element logsumexp is  log1p(exp(lo - hi)) + log(1) + hi  (the largest
+    // element is taken out of the sum), ndtri_exp / ndtri are the Cephes rational approximations (below).  libm's exp,
+    // log1p, expm1, sqrt and log are what SciPy's compiled code calls; NumPy's own SIMD log (np.log on the array U) differs
+    // from libm's in ~0.4 % of the draws by one ulp of the float64 intermediate - invisible after the float32 cast
+    // except once in ~1e9 values (tests/test_host_logic.py pins the float32 rows against SciPy itself).
+    void fill_truncnorm(float *dst, int64_t count, double log_cdf_a, double log_mass, float scale) {
+        constexpr int CB = N / 2;
+        int64_t p = 0;
+        while (p < count) {
+            next_block();
+            const int64_t n = count - p < CB ? count - p : CB;
+            for (int64_t j = 0; j < n; ++j) {
+                const double u = ((double)(int32_t)(out[2 * j] >> 5) * 67108864.0 + (double)(int32_t)(out[2 * j + 1] >> 6)) /
+                                 9007199254740992.0;
+                dst[p + j] = scale * (float)truncnorm_ppf_left(u, log_cdf_a, log_mass);
+            }
+            p += n;
+        }
+    }
+
+    static double polevl(double x, const double *c, int n) {      // Cephes polevl: c[0] x^n + ... + c[n]
+        double a = c[0];
+        for (int i = 1; i <= n; ++i) a = a * x + c[i];
+        return a;
+    }
+    static double p1evl(double x, const double *c, int n) {       // ... with an implicit leading coefficient 1
+        double a = x + c[0];
+        for (int i = 1; i < n; ++i) a = a * x + c[i];
+        return a;
+    }
+    // Cephes ndtri (inverse of the normal CDF; scipy.special.ndtri), coefficients of cephes/ndtri.c
+    static double ndtri(double y0) {
+        static const double P0[5] = {-5.99633501014107895267E1, 9.80010754185999661536E1, -5.66762857469070293439E1,
+                                     1.39312609387279679503E1, -1.23916583867381258016E0};
+        static const double Q0[8] = {1.95448858338141759834E0, 4.67627912898881538453E0,  8.63602421390890590575E1,
+                                     -2.25462687854119370527E2, 2.00260212380060660359E2, -8.20372256168333339912E1,
+                                     1.59056225126211695515E1, -1.18331621121330003142E0};
+        if (y0 == 0.0) return -INFINITY;
+        if (y0 == 1.0) return INFINITY;
+        if (!(y0 > 0.0 && y0 < 1.0)) return NAN;
+        bool negate = true;
+        double y = y0;
+        if (y > 1.0 - 0.13533528323661269189) {       // exp(-2)
+            y = 1.0 - y;
+            negate = false;
+        }
+        if (y > 0.13533528323661269189) {
+            y = y - 0.5;
+            const double y2 = y * y;
+            const double x = y + y * (y2 * polevl(y2, P0, 4) / p1evl(y2, Q0, 8));
+            return x * 2.50662827463100050242E0;      // sqrt(2 pi)
+        }
+        const double x = std::sqrt(-2.0 * std::log(y));
+        const double t = tail(x);
+        return negate ? -t : t;
+    }
+    // x0 - x1 of Cephes ndtri's tail branch for x = sqrt(-2 log y)
+    static double tail(double x) {
+        static const double P1[9] = {4.05544892305962419923E0, 3.15251094599893866154E1,  5.71628192246421288162E1,
+                                     4.40805073893200834700E1, 1.46849561928858024014E1,  2.18663306850790267539E0,
+                                     -1.40256079171354495875E-1, -3.50424626827848203418E-2, -8.57456785154685413611E-4};
+        static const double Q1[8] = {1.57799883256466749731E1,  4.53907635128879210584E1,  4.13172038254672030440E1,
+                                     1.50425385692907503408E1,  2.50464946208309415979E0,  -1.42182922854787788574E-1,
+                                     -3.80806407691578277194E-2, -9.33259480895457427372E-4};
+        static const double P2[9] = {3.23774891776946035970E0, 6.91522889068984211695E0, 3.93881025292474443415E0,
+                                     1.33303460815807542389E0, 2.01485389549179081538E-1, 1.23716634817820021358E-2,
+                                     3.01581553508235416007E-4, 2.65806974686737550832E-6, 6.23974539184983293730E-9};
+        static const double Q2[8] = {6.02427039364742014255E0, 3.67983563856160859403E0, 1.37702099489081330271E0,
+                                     2.16236993594496635890E-1, 1.34204006088543189037E-2, 3.28014464682127739104E-4,
+                                     2.89247864745380683936E-6, 6.79019408009981274425E-9};
+        const double x0 = x - std::log(x) / x;
+        const double z = 1.0 / x;
+        const double x1 = (x < 8.0) ? z * polevl(z, P1, 8) / p1evl(z, Q1, 8) : z * polevl(z, P2, 8) / p1evl(z, Q2, 8);
+        return x0 - x1;
+    }
+    // scipy.special.ndtri_exp (scipy/special/_ndtri_exp.pxd): ndtri(exp(y)) without forming exp(y) where it would lose bits
+    static double ndtri_exp(double y) {
+        if (y < -1.7976931348623157e308) return -INFINITY;
+        if (y < -2.0) {
+            const double x = (y >= -1.7976931348623157e308 * 0.5) ? std::sqrt(-2.0 * y) : 1.4142135623730951 * std::sqrt(-y);
+            return -tail(x);                          // x1 - x0
+        }
+        if (y > -0.14541345786885906) return -ndtri(-std::expm1(y));      // log1p(-exp(-2))
+        return ndtri(std::exp(y));
+    }
+    static double truncnorm_ppf_left(double u, double log_cdf_a, double log_mass) {
+        const double c = std::log(u) + log_mass;
+        double lse;
+        if (c == log_cdf_a) {
+            lse = std::log(2.0) + c;                  // both elements are the maximum: log1p(0 / 2) + log(2) + max
+        } else {
+            const double hi = c > log_cdf_a ? c : log_cdf_a, lo = c > log_cdf_a ? log_cdf_a : c;
+            lse = (std::log1p(std::exp(lo - hi)) + 0.0) + hi;
+        }
+        return ndtri_exp(lse) * 1.0 + 0.0;            // (vals * scale + loc of rv_generic.rvs: turns -0.0 into 0.0)
+    }
 };
 
 }  // namespace
 
 struct gs_zgen {
+    int kind = 0;                      // 0: standard normals, 1: truncated normals
+    double log_cdf_a = 0.0, log_mass = 0.0;
+    float scale = 1.0f;
     std::vector<uint32_t> seeds;
     int64_t count = 0;                 // normals per seed
     std::vector<float *> slots;        // ring of caller-owned batch buffers, batch i -> slots[i % size]
@@ -146,7 +252,10 @@ void zgen_worker(gs_zgen *z) {
         }
         rng.seed(z->seeds[(size_t)i]);
         float *out = z->slots[(size_t)(i % ring)];
-        rng.fill_float(out, z->count);
+        if (z->kind == 1)
+            rng.fill_truncnorm(out, z->count, z->log_cdf_a, z->log_mass, z->scale);
+        else
+            rng.fill_float(out, z->count);
         {
             std::lock_guard<std::mutex> lk(z->mu);
             z->done[(size_t)i] = 1;
@@ -167,14 +276,28 @@ int gs_zgen_fill(uint32_t seed, int64_t count, float *out_host) {
     return GS_OK;
 }
 
-int gs_zgen_start(const uint32_t *seeds_host, int64_t n_batches, int64_t count, float *const *slots_host, int n_slots,
-                  int threads, gs_zgen_t **out) {
+int gs_zgen_fill_truncnorm(uint32_t seed, int64_t count, double log_cdf_a, double log_mass, float scale, float *out_host) {
+    GS_REQUIRE(out_host != nullptr && count >= 0 && log_cdf_a < 0.0 && log_mass < 0.0, GS_EINVAL,
+               "gs_zgen_fill_truncnorm: bad argument");
+    Mt19937 rng;
+    rng.seed(seed);
+    rng.fill_truncnorm(out_host, count, log_cdf_a, log_mass, scale);
+    return GS_OK;
+}
+
+static int zgen_start_impl(const uint32_t *seeds_host, int64_t n_batches, int64_t count, float *const *slots_host,
+                           int n_slots, int threads, int kind, double log_cdf_a, double log_mass, float scale,
+                           gs_zgen_t **out) {
     GS_REQUIRE(out != nullptr, GS_EINVAL, "gs_zgen_start: out is NULL");
     *out = nullptr;
     GS_REQUIRE(seeds_host && slots_host && n_batches >= 0 && count >= 1 && n_slots >= 1, GS_EINVAL,
                "gs_zgen_start: bad argument");
     gs_zgen *z = new (std::nothrow) gs_zgen();
     GS_REQUIRE(z != nullptr, GS_ENOMEM, "gs_zgen_start: out of host memory");
+    z->kind = kind;
+    z->log_cdf_a = log_cdf_a;
+    z->log_mass = log_mass;
+    z->scale = scale;
     z->seeds.assign(seeds_host, seeds_host + n_batches);
     z->count = count;
     z->slots.assign(slots_host, slots_host + n_slots);
@@ -200,6 +323,17 @@ int gs_zgen_start(const uint32_t *seeds_host, int64_t n_batches, int64_t count, 
     }
     *out = z;
     return GS_OK;
+}
+
+int gs_zgen_start(const uint32_t *seeds_host, int64_t n_batches, int64_t count, float *const *slots_host, int n_slots,
+                  int threads, gs_zgen_t **out) {
+    return zgen_start_impl(seeds_host, n_batches, count, slots_host, n_slots, threads, 0, 0.0, 0.0, 1.0f, out);
+}
+
+int gs_zgen_start_truncnorm(const uint32_t *seeds_host, int64_t n_batches, int64_t count, float *const *slots_host,
+                            int n_slots, int threads, double log_cdf_a, double log_mass, float scale, gs_zgen_t **out) {
+    GS_REQUIRE(log_cdf_a < 0.0 && log_mass < 0.0, GS_EINVAL, "gs_zgen_start_truncnorm: log-probabilities must be negative");
+    return zgen_start_impl(seeds_host, n_batches, count, slots_host, n_slots, threads, 1, log_cdf_a, log_mass, scale, out);
 }
 
 int gs_zgen_wait(gs_zgen_t *z, int64_t batch, float **slot_host) {

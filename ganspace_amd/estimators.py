@@ -16,9 +16,12 @@ attribute names (``mean_``, ``components_``, ``explained_variance_`` ...), which
 
 ``'pca'``         the reference's whole-matrix ``PCAEstimator`` (estimators.py:84-118) on the device:
                   the same Gram kernel over all rows, one eigensolve; cache key ``pca-full_c{k}``.
-``'fbpca'``       the reference's ``FacebookPCAEstimator`` (estimators.py:124-160: randomized PCA of the
-                  *uncentred* matrix, ``raw=True``) as its n_iter -> infinity limit: the leading right singular
-                  vectors of X from the uncentred Gram; cache key ``fbpca_c{k}_it2_l{2k}``.
+``'fbpca'``       the reference's ``FacebookPCAEstimator`` (estimators.py:124-160): the randomized range finder itself
+                  (``fbpca.pca(X, k, n_iter=2, raw=True, l=2k)`` of the *uncentred* matrix) as ``gs_randomized_pca`` -
+                  2 (n_iter + 1) passes over X on the f32 MFMA, float64 CholeskyQR of the bases, Rayleigh-Ritz from the
+                  l x l side, test matrix from NumPy's global stream as fbpca draws it; cache key
+                  ``fbpca_c{k}_it2_l{2k}``.  (fbpca is not installed here: parity is pinned to a restatement of its
+                  published algorithm, ``oracle/fbpca_port.py``, not to the package.)
 ``'ica'`` / ``'spca'``  are not batch estimators and not PCA; ``get_estimator`` hands them to the CPU
                   pass-through in ``ganspace_amd/cpu_estimators.py`` (scikit-learn, the reference's own
                   arithmetic) so that every name the reference accepts still works.
@@ -189,17 +192,18 @@ class _DeviceIncrementalPCA:
     def transform(self, X):
         """``(X - mean_) @ components_.T`` on the device; returns a host ndarray ``[m, k]``."""
         torch = _torch()
-        self._results()
-        Xd = self._as_device_rows(X)
-        self._results()                    # finalizes (the faithful mode defers its diagonalisation until here)
+        r = self._results()                # finalizes once (the faithful mode defers its diagonalisation until here)
+        Xd = self._as_device_rows(X).contiguous()
+        # the components stay where gs_ipca_finalize left them (device, float32 [k, d]): only the k projections of the
+        # mean travel - X @ C^T - mean @ C^T, the second term evaluated once per fit in float64 from the host copies
         comp, mean = C.c_void_p(), C.c_void_p()
         _lib.check(self._lib.gs_ipca_components_device(self._h, C.byref(comp), C.byref(mean)))
         k, d = self.n_components, self._d
         if d % 4 != 0:
             raise NotImplementedError("transform() needs n_features to be a multiple of 4")
-        Xd = Xd.contiguous()
-        c = torch.from_numpy(self._results()["components_"]).to(Xd.device)
-        bias = -(c.double() @ torch.from_numpy(self._results()["mean_"]).to(Xd.device)).float().contiguous()
+        if "_proj_bias" not in r:
+            r["_proj_bias"] = -(r["components_"].astype(np.float64) @ r["mean_"]).astype(np.float32)
+        bias = torch.from_numpy(r["_proj_bias"]).to(Xd.device)
         out = torch.empty((Xd.shape[0], k), dtype=torch.float32, device=Xd.device)
         _lib.check(self._lib.gs_linear_forward(C.c_void_p(Xd.data_ptr()), comp, C.c_void_p(bias.data_ptr()),
                                                C.c_void_p(out.data_ptr()), Xd.shape[0], d, k,
@@ -384,7 +388,7 @@ class _WholeMatrixPCA:
             if e.code == _lib.GS_ENOTIMPL:
                 raise RuntimeError(
                     f"whole-matrix PCA of a [{n}, {d}] matrix: feat_dim > {self.GRAM_SIDE_MAX_FEATURES} is solved from "
-                    "the rows x rows side, which holds n_components + rows + 1 <= 32768; use the batch estimator "
+                    "the rows x rows side, which holds n_components + rows + 1 <= 16384; use the batch estimator "
                     "'ipca' (small-side recurrence, any number of rows) for more samples") from e
             raise
         comp = torch.from_numpy(np.array(inc.components_, dtype=np.float32)).to(Xd.device)
@@ -399,8 +403,16 @@ class _WholeMatrixPCA:
         Xd = self._device_rows(X)
         n, d = Xd.shape
         k = self.n_components
+        d_true = d
         if d % 4 != 0:
-            raise RuntimeError(f"whole-matrix estimators need feat_dim % 4 == 0 on the device (got {d})")
+            # the moment / projection kernels read float4 rows: zero-pad the features to a multiple of 4.  A constant-zero
+            # feature has zero mean, zero variance and zero weight in every component (centred or not), so the padded
+            # problem IS the original one; the reference estimators accept any width (estimators.py:84-160)
+            d = d + (4 - d % 4)
+            Xp = torch.zeros((n, d), dtype=Xd.dtype, device=Xd.device)
+            Xp[:, :d_true] = Xd
+            Xd = Xp
+        self._d_true = d_true
         comp = self._components(Xd).contiguous()                     # [k, d] float32 on the device
         s1, s2 = _column_moments(self._lib, Xd)
         mean = s1 / n
@@ -411,8 +423,8 @@ class _WholeMatrixPCA:
         self.stdev = proj.double().std(dim=0, unbiased=False).cpu().numpy()   # np.dot(components_, X.T).std(axis=1)
         order = np.argsort(self.stdev)[::-1]                         # estimators.py:103-106
         self.stdev = self.stdev[order]
-        self.transformer.components_ = comp.cpu().numpy()[order].astype(np.float32)
-        self.transformer.mean_ = mean[None, :].astype(np.float32)
+        self.transformer.components_ = comp.cpu().numpy()[order][:, :d_true].astype(np.float32)
+        self.transformer.mean_ = mean[None, :d_true].astype(np.float32)
         c64 = self.transformer.components_.astype(np.float64)
         gram = c64 @ c64.T
         off = np.abs(gram - np.diag(np.diag(gram))).max() if k > 1 else 0.0
@@ -458,11 +470,16 @@ class FacebookPCAEstimator(_WholeMatrixPCA):
         torch = _torch()
         n, d = Xd.shape
         k, l = self.n_components, self.l
-        if l >= n / 1.25 or l >= d / 1.25:
+        if l >= n / 1.25 or l >= getattr(self, "_d_true", d) / 1.25:
             return self._exact_components(Xd, centre=False)
         if l > 256:
             raise RuntimeError(f"fbpca on the device handles l = 2 * n_components <= 256 (got {l})")
-        omega = np.random.uniform(low=-1.0, high=1.0, size=(d, l) if n >= d else (l, n))
+        # (features zero-padded to a multiple of 4 by fit(): the draw has the shape fbpca would use for the TRUE width, the
+        #  padded rows of the test matrix are zero - they only ever multiply zero columns)
+        d_true = getattr(self, "_d_true", d)
+        omega = np.random.uniform(low=-1.0, high=1.0, size=(d_true, l) if n >= d_true else (l, n))
+        if n >= d_true and d_true != d:
+            omega = np.concatenate([omega, np.zeros((d - d_true, l))], axis=0)
         om = torch.from_numpy(omega).to(Xd.device)
         comp = torch.empty((k, d), dtype=torch.float32, device=Xd.device)
         sv = torch.empty(k, dtype=torch.float64, device=Xd.device)

@@ -142,3 +142,24 @@ def jacobi_small(B):
     info = (C.c_int * 2)()
     _lib.check(lib.gs_jacobi_small(_p(B), p, _p(U), _p(theta), C.cast(info, C.c_void_p), _lib.current_stream_ptr()))
     return theta, U, info[0], bool(info[1])
+
+
+def gemm_f64(A, B, alpha=1.0, beta=0.0, C=None, coef=None, E1=None, E2=None):
+    """``C = alpha A @ B + beta C`` (or ``coef[0] A @ B + coef[1] E1 + coef[2] E2``) in float64 on the f64 matrix
+    pipe; ``A`` / ``B`` may be arbitrary strided 2-D views (transposes are free)."""
+    import torch
+    lib = _lib.load()
+    _need_cuda(A, B, C, coef, E1, E2)
+    assert A.dtype == torch.float64 and B.dtype == torch.float64 and A.dim() == 2 and B.dim() == 2
+    M, K = A.shape
+    K2, N = B.shape
+    assert K == K2
+    if C is None:
+        C = torch.zeros((M, N), dtype=torch.float64, device=A.device)
+    assert C.stride(1) == 1 and C.shape == (M, N)
+    for E in (E1, E2):
+        assert E is None or (E.shape == C.shape and E.stride() == C.stride())
+    _lib.check(lib.gs_gemm_f64(M, N, K, _p(A), A.stride(0), A.stride(1), _p(B), B.stride(0), B.stride(1), _p(C),
+                               C.stride(0), float(alpha), float(beta), _p(coef), _p(E1), _p(E2),
+                               _lib.current_stream_ptr()))
+    return C

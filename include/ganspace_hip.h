@@ -211,6 +211,14 @@ int gs_eigh_topk(const double *A, int n, int k, const double *V0, int k0, double
  *                  info_host (2 ints) = {sweeps, 1 if the sweep limit was hit}.                                       */
 int gs_cholqr(const double *Y, int n, int p, double *Q, double *rdiag, void *stream);
 int gs_jacobi_small(const double *B, int p, double *U, double *theta, int *info_host, void *stream);
+/* gs_gemm_f64:     the float64 product of those chains on the f64 matrix pipe (v_mfma_f64_16x16x4_f64; csrc/gs_dense64.hip):
+ *                  C [M*N] (row-major, ldc) = alpha sum_t A(i,t) B(t,j) + beta C with A(i,t) = A[i*a_i + t*a_t],
+ *                  B(t,j) = B[t*b_t + j*b_j] - any element strides, so transposed operands need no copy.  coef (3 doubles
+ *                  on the DEVICE, may be NULL) selects the three-term form C = coef[0] A B + coef[1] E1 + coef[2] E2 of the
+ *                  Chebyshev filter instead (E1 / E2 laid out like C, may be NULL); alpha / beta are then ignored.        */
+int gs_gemm_f64(int M, int N, int K, const double *A, int64_t a_i, int64_t a_t, const double *B, int64_t b_t, int64_t b_j,
+                double *C, int64_t ldc, double alpha, double beta, const double *coef, const double *E1, const double *E2,
+                void *stream);
 
 /* Replaces FacebookPCAEstimator.fit's `fbpca.pca(X, k, n_iter=2, raw=True, l=2k)` (estimators.py:137; fbpca 1.0's
  * randomized range finder with normalised power iterations - Halko / Martinsson / Tropp) for a whole sample matrix
@@ -245,6 +253,16 @@ typedef struct gs_zgen gs_zgen_t;
 int gs_zgen_fill(uint32_t seed, int64_t count, float *out_host);
 int gs_zgen_start(const uint32_t *seeds_host, int64_t n_batches, int64_t count, float *const *slots_host, int n_slots,
                   int threads, gs_zgen_t **out);
+/* The same for BigGAN.sample_latent (models/wrappers.py:562-569 -> truncated_noise_sample,
+ * models/biggan/pytorch_biggan/pytorch_pretrained_biggan/utils.py:21-33):
+ *   out = scale * float32(scipy.stats.truncnorm.rvs(a, b, size=count, random_state=RandomState(seed)))   for a < 0 < b,
+ * i.e. one 53-bit uniform per value through truncnorm's inverse CDF (SciPy's logsumexp / ndtri_exp / Cephes ndtri chain
+ * restated; float32 rows identical to SciPy's up to the host-dependent last bit of NumPy's SIMD log, see csrc/gs_zgen.hip).
+ * The interval is passed as log_cdf_a = log Phi(a) and log_mass = log(Phi(b) - Phi(a)) (a, b = -2, 2:
+ * -0x1.e43f625df3b24p+1, -0x1.7d7bfd8ad78c5p-5).                                                                 */
+int gs_zgen_fill_truncnorm(uint32_t seed, int64_t count, double log_cdf_a, double log_mass, float scale, float *out_host);
+int gs_zgen_start_truncnorm(const uint32_t *seeds_host, int64_t n_batches, int64_t count, float *const *slots_host,
+                            int n_slots, int threads, double log_cdf_a, double log_mass, float scale, gs_zgen_t **out);
 int gs_zgen_wait(gs_zgen_t *z, int64_t batch, float **slot_host);
 int gs_zgen_release(gs_zgen_t *z, int64_t upto);
 int gs_zgen_finish(gs_zgen_t *z);

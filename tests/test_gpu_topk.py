@@ -159,3 +159,37 @@ def test_eigh_topk_white_noise_falls_back(dev):
     rs = np.random.RandomState(5)
     X = rs.standard_normal((4000, 512))
     _check_topk(dev, X.T @ X, 80, expect_converged=False, ncheck=1)
+
+
+@pytest.mark.parametrize("M,N,K,ta,tb", [(512, 96, 512, False, False), (96, 96, 512, True, False),
+                                         (512, 96, 96, False, False), (2081, 80, 2081, False, False),
+                                         (80, 80, 2081, True, False), (80, 512, 80, False, False),
+                                         (33, 17, 5, False, True), (1, 1, 1, False, False), (100, 260, 37, True, True),
+                                         (2100, 2100, 64, False, True), (130, 131, 4100, True, False)])
+def test_gemm_f64_mfma_matches_numpy(dev, M, N, K, ta, tb):
+    """The f64 matrix-pipe product (`mm64_kernel`, v_mfma_f64_16x16x4_f64) of the solver chains, every operand layout
+    (strided views: no transposed copies), ragged shapes, both tile arrangements and the split-K path."""
+    from ganspace_amd import ops
+    rs = np.random.RandomState(M + 3 * N + 7 * K)
+    # asymmetric operands: a transposed C-write or a swapped operand map cannot cancel out
+    A = rs.standard_normal((M, K)) * np.linspace(1.0, 2.0, K)[None, :] + np.arange(M)[:, None] * 1e-3
+    B = rs.standard_normal((K, N)) + np.arange(N)[None, :] * 1e-2
+    At = torch.from_numpy(np.ascontiguousarray(A.T)).to(dev).T if ta else torch.from_numpy(A).to(dev)
+    Bt = torch.from_numpy(np.ascontiguousarray(B.T)).to(dev).T if tb else torch.from_numpy(B).to(dev)
+    ref = A @ B
+    scale = np.abs(A) @ np.abs(B) + 1e-300
+    C = ops.gemm_f64(At, Bt).cpu().numpy()
+    assert (np.abs(C - ref) / scale).max() < 1e-14
+    # alpha / beta form on a padded C
+    C0 = rs.standard_normal((M, N + 3))
+    Cd = torch.from_numpy(C0).to(dev)
+    ops.gemm_f64(At, Bt, alpha=-0.5, beta=2.0, C=Cd[:, :N])
+    out = Cd.cpu().numpy()
+    assert (np.abs(out[:, :N] - (2.0 * C0[:, :N] - 0.5 * ref)) / (scale + np.abs(C0[:, :N]))).max() < 1e-14
+    assert (out[:, N:] == C0[:, N:]).all()
+    # three-term (Chebyshev) epilogue
+    E1, E2 = rs.standard_normal((M, N)), rs.standard_normal((M, N))
+    coef = np.array([0.75, -1.25, 0.5])
+    Ce = ops.gemm_f64(At, Bt, coef=torch.from_numpy(coef).to(dev), E1=torch.from_numpy(E1).to(dev),
+                      E2=torch.from_numpy(E2).to(dev)).cpu().numpy()
+    assert (np.abs(Ce - (0.75 * ref - 1.25 * E1 + 0.5 * E2)) / (scale + 2.0)).max() < 1e-14

@@ -180,3 +180,76 @@ def test_native_z_stream_ring_backpressure_and_order():
     # the generator front end used by decomposition._presample on hosts without a GPU
     out = list(_zgen.generate("stylegan", seeds[:5], 300, 64))
     assert all(o.tobytes() == _zgen.stylegan_z(s, 300, 64).tobytes() for s, o in zip(seeds, out))
+
+
+def test_native_truncnorm_matches_scipy_float32_rows():
+    """csrc/gs_zgen.hip restates ``scipy.stats.truncnorm.rvs(-2, 2, ..., random_state=RandomState(seed))`` (BigGAN's
+    ``truncated_noise_sample``, models/biggan/pytorch_biggan/pytorch_pretrained_biggan/utils.py:21-33): one uniform per
+    value through SciPy's logsumexp / ndtri_exp / Cephes-ndtri chain.  The float32 rows must equal SciPy's.  The
+    only operation that is not the same code is NumPy's SIMD ``np.log`` on the uniform array (libm's ``log`` here: the two
+    differ in ~0.4 % of the draws by one ulp of the float64 intermediate, which survives the float32 cast about once in
+    1e9 values): budget = at most 2 float32-ulp-sized mismatches per million values, none seen on the seeds below."""
+    import ctypes as C
+    from scipy.stats import truncnorm
+    from ganspace_amd import _lib, _zgen
+    lib = _lib.load()
+    la, lm = _zgen.TRUNCNORM_M2_P2
+    from scipy import special as sc
+    assert la == float(sc.log_ndtr(-2.0)) and lm == float(np.log1p(-sc.ndtr(-2.0) - sc.ndtr(-2.0)))
+    total = bad = 0
+    for seed, count, scale in [(1791095845, 2000 * 128, 1.0), (2135392491, 128 * 37 + 1, 0.8), (0, 1, 1.0), (1, 7, 0.5),
+                               (2 ** 31 - 2, 311, 1.0), (2 ** 32 - 1, 312, 1.0), (5, 313, 1.0), (6, 624, 1.0), (7, 625, 1.0),
+                               (8, 0, 1.0), (946286476, 100_000, 1.0)]:
+        out = np.full(count + 2, 7.0, np.float32)
+        assert lib.gs_zgen_fill_truncnorm(seed, count, la, lm, scale, out.ctypes.data_as(C.c_void_p)) == 0
+        ref = truncnorm.rvs(-2, 2, size=max(count, 1), random_state=np.random.RandomState(seed)).astype(np.float32)[:count]
+        ref = (np.float32(scale) * ref).astype(np.float32)
+        assert out[count] == 7.0 and out[count + 1] == 7.0
+        diff = out[:count] != ref
+        bad += int(diff.sum())
+        total += count
+        if diff.any():                      # a mismatch may only be the float32 neighbour
+            assert np.abs(out[:count][diff] - ref[diff]).max() <= np.spacing(np.abs(ref[diff]).max())
+        assert np.abs(out[:count]).max(initial=0.0) <= 2.0 * scale
+    assert bad <= max(2, 2 * total // 1_000_000), (bad, total)
+    assert lib.gs_zgen_fill_truncnorm(1, 4, 0.5, lm, 1.0, out.ctypes.data_as(C.c_void_p)) == -1      # log-probabilities are < 0
+
+
+def test_native_biggan_stream_equals_reference_protocol():
+    """The thread-pool front end for BigGAN latents (``NativeNormalStream(kind="biggan")``, used by ``_presample`` and the
+    regression): batches in seed order, equal to the reference's ``truncation * truncnorm.rvs(...)`` float32 batches."""
+    from ganspace_amd import _zgen
+    from oracle import zstream
+    seeds = [int(s) for s in np.random.RandomState(9).randint(0, 2 ** 31 - 1, size=23)]
+    got = list(_zgen.generate("biggan", seeds, 41, 128, 0.7))
+    assert len(got) == 23
+    for s, z in zip(seeds, got):
+        want = zstream.biggan_z_batch(s, 41, 128, 0.7)
+        assert z.shape == want.shape and (z != want).sum() <= 1 and np.abs(z - want).max() <= 1e-7
+
+
+def test_two_live_native_streams_do_not_share_a_ring():
+    """Two streams of the same shape alive at once (zip of two generators, a generator that was not exhausted) used to be
+    handed the SAME cached ring and overwrote each other's slots (round-3 advisor finding).  A ring belongs to one
+    stream at a time; it returns to the cache when its owner closes."""
+    from ganspace_amd import _zgen
+    seeds_a = [int(s) for s in np.random.RandomState(1).randint(0, 2 ** 31 - 1, size=20)]
+    seeds_b = [int(s) for s in np.random.RandomState(2).randint(0, 2 ** 31 - 1, size=20)]
+    ga = _zgen.generate("stylegan", seeds_a, 200, 32)
+    gb = _zgen.generate("stylegan", seeds_b, 200, 32)
+    for sa, sb, (za, zb) in zip(seeds_a, seeds_b, zip(ga, gb)):
+        assert za.tobytes() == _zgen.stylegan_z(sa, 200, 32).tobytes()
+        assert zb.tobytes() == _zgen.stylegan_z(sb, 200, 32).tobytes()
+    ga.close()                              # (suspended behind their last yield: closing runs their `finally: stream.close()`)
+    gb.close()
+    assert all(e[2] is False for e in _zgen._RING_CACHE.values())
+    s1 = _zgen.NativeNormalStream(seeds_a[:6], 200, 32, threads=2, pinned=False)
+    s2 = _zgen.NativeNormalStream(seeds_b[:6], 200, 32, threads=2, pinned=False)
+    assert s1._storage is not s2._storage
+    s1.close()
+    s2.close()
+    s3 = _zgen.NativeNormalStream(seeds_a[:6], 200, 32, threads=2, pinned=False)
+    assert not any(s3._storage is s._storage for s in (s1, s2)) or s3._ring[2]
+    assert s3._ring[2] is True
+    s3.close()
+    assert all(e[2] is False for e in _zgen._RING_CACHE.values())
