@@ -53,6 +53,8 @@ SIGNATURES = {
     "gs_gram_accumulate": (_int, [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp]),
     "gs_gram_accumulate_prec": (_int, [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _int, _vp]),
     "gs_gram_kernel_time": (_int, [_vp, _vp, _i64, _i64, _int, _vp, _vp, _vp]),
+    "gs_ipca_profile_launches": (_int, [_vp, _int]),
+    "gs_ipca_launch_profile": (_int, [_vp, _vp, _vp, _vp]),
     "gs_eigh_sym": (_int, [_vp, _vp, _int, _vp, _vp]),
     "gs_eigh_topk": (_int, [_vp, _int, _int, _vp, _int, _vp, _vp, _vp, _vp]),
     "gs_cholqr": (_int, [_vp, _int, _int, _vp, _vp, _vp]),

@@ -168,6 +168,14 @@ struct GramWorkspace {
     hipEvent_t ev_comp[2] = {nullptr, nullptr};    // slabs of set i are complete (recorded on the caller's stream)
     hipEvent_t ev_fold[2] = {nullptr, nullptr};    // slabs of set i are folded (recorded on aux)
     bool aux_busy[2] = {false, false};             // a fold on aux that the caller's stream has not waited for yet
+    // in-job timing of the compute launches (bench.py: `roofline.frac` is the launch as the JOB runs it, not a
+    // back-to-back microbenchmark): while `profile` is set every compute launch of gram_update is bracketed by a pair of
+    // timing events on its stream (<= kProfMax launches; the fold runs elsewhere and is not inside the pair)
+    static constexpr int kProfMax = 64;
+    bool profile = false;
+    int prof_n = 0;
+    int64_t prof_rows = 0;
+    hipEvent_t prof_ev[2 * kProfMax] = {};
     mutable unsigned long long pace_epoch = 0;     // per workspace: its launches are ordered on its stream, its words are its own
 };
 

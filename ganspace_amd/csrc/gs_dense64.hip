@@ -198,7 +198,7 @@ void mm64(int M, int N, int K, const double *A, int64_t a_i, int64_t a_t, const 
 // column: row j AND column j of R^-1 are zero, so column j of Y R^-1 is exactly zero and no later column uses it.
 constexpr int kCiP = 128;
 constexpr int kCiLd = 129;
-constexpr size_t kCiLdsBytes = sizeof(double) * ((size_t)kCiP * kCiLd + 16 * 17 + 3 * kCiP);
+constexpr size_t kCiLdsBytes = sizeof(double) * ((size_t)kCiP * kCiLd + 2 * 16 * 17 + 3 * kCiP);
 __global__ __launch_bounds__(1024) void chol_inv_kernel(const double *__restrict__ H, int64_t ldh, int p,
                                                          double *__restrict__ Rinv, int64_t ldr,
                                                          double *__restrict__ rdiag, int debug) {
@@ -209,75 +209,116 @@ __global__ __launch_bounds__(1024) void chol_inv_kernel(const double *__restrict
     double *rd = ed + kCiP;                     // [128]       diagonal of R (0 = dead)
     double *refd = rd + kCiP;                   // [128]       original diagonal of H
     const long long dbg_c0 = debug ? clock64() : 0;
-    long long dbg_leaf = 0, dbg_panel = 0, dbg_trail = 0;
+    long long dbg_leaf = 0, dbg_panel = 0, dbg_trail = 0, dbg_load = 0;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int li = lane & 15, lg = lane >> 4;
     const int nblk = (p + 15) >> 4, pend = nblk * 16;
-    for (int e = tid; e < pend * pend; e += 1024) {
-        const int i = e / pend, j = e - i * pend;
-        double v = 0.0;
-        if (i <= j) v = (j < p) ? H[(int64_t)i * ldh + j] : (i == j ? 1.0 : 0.0);
-        Hs[i * kCiLd + j] = v;
+    {
+        // thread = (column j, row phase): 16 independent loads in flight per thread, one round trip for the whole matrix
+        const int j = tid & 127, i0 = tid >> 7;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int i = i0 + 8 * q;
+            double v = 0.0;
+            if (i <= j && j < p) v = H[(int64_t)i * ldh + j];
+            if (i == j && j >= p) v = 1.0;
+            if (i < pend && j < pend) Hs[i * kCiLd + j] = v;
+        }
     }
     if (tid < kCiP) refd[tid] = (tid < p) ? H[(int64_t)tid * ldh + tid] : 1.0;
     __syncthreads();
-    for (int J = 0; J < nblk; ++J) {
-        const int j0 = 16 * J, j1 = j0 + 16, rem = pend - j1;
-        long long dbg_t = debug ? clock64() : 0;
-        // ---- (a) diagonal block, one wave, branch-free: lane c < 16 column c of the block, lane 16 + c column c of the
-        //      identity.  Entries below the diagonal of a block column only ever see no-op or unread updates, so the
-        //      elimination step needs no row / column masks ----
-        if (tid < 64) {
-            const int c = tid & 15;
-            const bool aug = (tid & 16) != 0;
-            double col[16];
+    if (debug) dbg_load = clock64() - dbg_c0;
+
+    // (a) diagonal block J by ONE wave, branch-free: lane c < 16 column c of the block, lane 16 + c column c of the identity.
+    // Entries below the diagonal of a block column only ever see no-op or unread updates, so the elimination step needs
+    // no row / column masks.
+    auto leaf = [&](int J) {
+        const int j0 = 16 * J;
+        const int c = lane & 15;
+        const bool aug = (lane & 16) != 0;
+        double col[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            double v = (r == c) ? 1.0 : 0.0;
+            if (!aug) v = (r <= c) ? Hs[(j0 + r) * kCiLd + j0 + c] : 0.0;
+            col[r] = v;
+        }
+        const double ref = refd[j0 + c] * 1e-13;
+        unsigned dead_mask = 0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const double d = readlane64(col[j], j);
+            const double rf = readlane64(ref, j);
+            const bool dead = !(d > rf);                     // (wave-uniform)
+            double inv = __builtin_amdgcn_rsq(d);            // one Newton step on the ~2^-26 seed: ~3e-16 relative
+            inv = inv * (1.5 - (0.5 * d) * inv * inv);
+            inv = dead ? 0.0 : inv;
+            dead_mask |= dead ? (1u << j) : 0u;
+            double rjc = col[j] * inv;                        // row j of R / of R^-T at this lane's column
+            if (!aug) rjc = (c == j) ? (dead ? 1.0 : d * inv) : ((c > j) ? rjc : 0.0);
+            col[j] = rjc;
+#pragma unroll
+            for (int r = j + 1; r < 16; ++r) col[r] -= readlane64(rjc, r) * rjc;     // R[j][r] lives in lane r < 16
+        }
+        const bool dead_c = (dead_mask >> c) & 1u;
+        if (lane < 16) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (r <= c) Hs[(j0 + r) * kCiLd + j0 + c] = col[r];
+            rd[j0 + c] = dead_c ? 0.0 : col[c];
+        } else if (lane < 32) {
+            // lane 16 + c: column c of R_JJ^-T (rows r >= c)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                double v = (r == c) ? 1.0 : 0.0;
-                if (!aug) v = (r <= c) ? Hs[(j0 + r) * kCiLd + j0 + c] : 0.0;
-                col[r] = v;
-            }
-            const double ref = refd[j0 + c] * 1e-13;
-            unsigned dead_mask = 0;
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const double d = readlane64(col[j], j);
-                const double rf = readlane64(ref, j);
-                const bool dead = !(d > rf);                     // (wave-uniform)
-                double inv = __builtin_amdgcn_rsq(d);            // one Newton step on the ~2^-26 seed: ~3e-16 relative
-                inv = inv * (1.5 - (0.5 * d) * inv * inv);
-                inv = dead ? 0.0 : inv;
-                dead_mask |= dead ? (1u << j) : 0u;
-                double rjc = col[j] * inv;                        // row j of R / of R^-T at this lane's column
-                if (!aug) rjc = (c == j) ? (dead ? 1.0 : d * inv) : ((c > j) ? rjc : 0.0);
-                col[j] = rjc;
-#pragma unroll
-                for (int r = j + 1; r < 16; ++r) col[r] -= readlane64(rjc, r) * rjc;     // R[j][r] lives in lane r < 16
-            }
-            const bool dead_c = (dead_mask >> c) & 1u;
-            if (tid < 16) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    if (r <= c) Hs[(j0 + r) * kCiLd + j0 + c] = col[r];
-                rd[j0 + c] = dead_c ? 0.0 : col[c];
-            } else if (tid < 32) {
-                // lane 16 + c: column c of R_JJ^-T (rows r >= c)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const bool dead_r = (dead_mask >> r) & 1u;
-                    const double v = (r < c || dead_r || dead_c) ? 0.0 : col[r];
-                    Es[r * 17 + c] = v;
-                    if (r > c) Hs[(j0 + r) * kCiLd + j0 + c] = v;
-                    if (r == c) ed[j0 + c] = v;
-                }
+                const bool dead_r = (dead_mask >> r) & 1u;
+                const double v = (r < c || dead_r || dead_c) ? 0.0 : col[r];
+                Es[r * 17 + c] = v;
+                if (r > c) Hs[(j0 + r) * kCiLd + j0 + c] = v;
+                if (r == c) ed[j0 + c] = v;
             }
         }
-        __syncthreads();
-        if (debug) {
-            const long long t = clock64();
-            dbg_leaf += t - dbg_t;
-            dbg_t = t;
+    };
+    // (c) one 16 x 16 tile of the trailing update of block step J on the matrix pipe: X[r][c] -= sum_t R[j0 + t][r] rowJ[t][c]
+    // for the columns of the identity half (c < j1) and of the upper triangle (c >= r).  rowJ of the block's own columns
+    // (the identity half's R_JJ^-T) comes from EsJ.
+    auto trail_tile = [&](int J, int tr, int tc, const double *EsJ) {
+        const int j0 = 16 * J, j1 = j0 + 16;
+        const int r0 = j1 + 16 * tr, c0 = 16 * tc;
+        if (c0 >= j1 && c0 < r0) return;                          // strictly below the diagonal: still zero
+        const bool inJ = (c0 == j0);
+        d4_t acc;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] = Hs[(r0 + lg + 4 * r) * kCiLd + c0 + li];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const int k = 4 * lg + m;
+            const double a = -Hs[(j0 + k) * kCiLd + r0 + li];       // -R[j0 + k][r0 + i]
+            const double b = inJ ? EsJ[k * 17 + li] : Hs[(j0 + k) * kCiLd + c0 + li];
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
         }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int rr = r0 + lg + 4 * r, cc = c0 + li;
+            if (cc < j1 || cc >= rr) Hs[rr * kCiLd + cc] = acc[r];
+        }
+    };
+
+    // The chain of diagonal blocks is the critical path (16 dependent pivots each): wave 0 runs leaf(J + 1) as soon as it
+    // has updated that block's diagonal tile itself, WHILE the other waves do the rest of block step J's trailing update.
+    // leaf(J + 1) overwrites Es, which the trailing tiles of step J that lie in the block's own columns still read: they
+    // work from a copy (EsPrev) taken before.
+    double *EsPrev = Es + 0;                    // (aliases below: a second 16 x 17 area behind refd)
+    EsPrev = refd + kCiP;
+    long long dbg_t = debug ? clock64() : 0;
+    if (wave == 0) leaf(0);
+    __syncthreads();
+    if (debug) {
+        const long long t = clock64();
+        dbg_leaf += t - dbg_t;
+        dbg_t = t;
+    }
+    for (int J = 0; J < nblk; ++J) {
+        const int j0 = 16 * J, j1 = j0 + 16, rem = pend - j1;
         // ---- (b) panel on the matrix pipe: rows J of both halves <- R_JJ^-T (rows J); one 16-column tile per wave,
         //      tile q covers columns [16 q, 16 q + 16) for q < J (identity half) and [16 (q + 1), ...) beyond ----
         const int ntile_p = nblk - 1;
@@ -292,6 +333,7 @@ __global__ __launch_bounds__(1024) void chol_inv_kernel(const double *__restrict
                 pacc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, pacc, 0, 0, 0);
             }
         }
+        if (tid < 16 * 17) EsPrev[tid] = Es[tid];
         __syncthreads();
         if (wave < ntile_p) {
 #pragma unroll
@@ -304,46 +346,42 @@ __global__ __launch_bounds__(1024) void chol_inv_kernel(const double *__restrict
             dbg_t = t;
         }
         if (rem <= 0) break;
-        // ---- (c) trailing update on the matrix pipe, rows [j1, pend): X[r][c] -= sum_t R[j0 + t][r] rowJ[t][c] for the
-        //      columns of the identity half (c < j1) and of the upper triangle (c >= r); 16 x 16 tiles dealt to the waves ----
+        // ---- (c) + look-ahead ----
         {
             const int ntr = rem >> 4;
             const int ntiles = ntr * nblk;
-            for (int tile = wave; tile < ntiles; tile += 16) {
-                const int tr = tile / nblk, tc = tile - tr * nblk;
-                const int r0 = j1 + 16 * tr, c0 = 16 * tc;
-                if (c0 >= j1 && c0 < r0) continue;                        // strictly below the diagonal: still zero
-                const bool inJ = (c0 == j0);
-                d4_t acc;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) acc[r] = Hs[(r0 + lg + 4 * r) * kCiLd + c0 + li];
-#pragma unroll
-                for (int m = 0; m < 4; ++m) {
-                    const int k = 4 * lg + m;
-                    const double a = -Hs[(j0 + k) * kCiLd + r0 + li];       // -R[j0 + k][r0 + i]
-                    const double b = inJ ? Es[k * 17 + li] : Hs[(j0 + k) * kCiLd + c0 + li];
-                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
-                }
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int rr = r0 + lg + 4 * r, cc = c0 + li;
-                    if (cc < j1 || cc >= rr) Hs[rr * kCiLd + cc] = acc[r];
+            if (wave == 0) {
+                trail_tile(J, 0, J + 1, EsPrev);          // the next diagonal tile first ...
+                leaf(J + 1);                              // ... then its 16 pivots (one wave: LDS accesses of a wave are ordered)
+            } else {
+                for (int tile = wave - 1; tile < ntiles; tile += 15) {
+                    const int tr = tile / nblk, tc = tile - tr * nblk;
+                    if (tr == 0 && tc == J + 1) continue;             // wave 0's tile
+                    trail_tile(J, tr, tc, EsPrev);
                 }
             }
         }
         __syncthreads();
-        if (debug) dbg_trail += clock64() - dbg_t;
+        if (debug) {
+            const long long t = clock64();
+            dbg_trail += t - dbg_t;
+            dbg_t = t;
+        }
     }
     __syncthreads();
     // ---- R^-1 = (R^-T)^T ----
-    for (int e = tid; e < p * p; e += 1024) {
-        const int i = e / p, j = e - i * p;
-        Rinv[(int64_t)i * ldr + j] = (i < j) ? Hs[j * kCiLd + i] : (i == j ? ed[i] : 0.0);
+    {
+        const int j = tid & 127, i0 = tid >> 7;
+#pragma unroll 4
+        for (int q = 0; q < 16; ++q) {
+            const int i = i0 + 8 * q;
+            if (i < p && j < p) Rinv[(int64_t)i * ldr + j] = (i < j) ? Hs[j * kCiLd + i] : (i == j ? ed[i] : 0.0);
+        }
     }
     if (tid < p) rdiag[tid] = rd[tid];
     if (debug && tid == 0)
-        printf("[chol_inv p=%d] leaf %lld clk, panel %lld, trailing %lld; total %lld clk\n", p, dbg_leaf, dbg_panel, dbg_trail,
-               (long long)clock64() - dbg_c0);
+        printf("[chol_inv p=%d] load %lld clk, first leaf %lld, panels %lld, trailing + next leaf %lld; total %lld clk\n", p,
+               dbg_load, dbg_leaf, dbg_panel, dbg_trail, (long long)clock64() - dbg_c0);
 }
 
 int chol_inv_prepare() {

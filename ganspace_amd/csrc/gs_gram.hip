@@ -639,6 +639,8 @@ void gram_workspace_free(GramWorkspace &ws) {
         if (ws.colsum_partial[i]) (void)hipFree(ws.colsum_partial[i]);
     }
     if (ws.pace) (void)hipFree(ws.pace);
+    for (hipEvent_t e : ws.prof_ev)
+        if (e) (void)hipEventDestroy(e);
     ws = GramWorkspace();
 }
 
@@ -882,6 +884,29 @@ int gram_flush(GramWorkspace &ws, double *G64, double *S1, hipStream_t stream) {
     return GS_OK;
 }
 
+// bracket one compute launch with timing events while the workspace is being profiled (see GramWorkspace::profile)
+namespace {
+struct ProfScope {
+    GramWorkspace &ws;
+    hipStream_t stream;
+    int slot = -1;
+    ProfScope(GramWorkspace &w, hipStream_t s, int64_t rows) : ws(w), stream(s) {
+        if (!ws.profile || ws.prof_n >= GramWorkspace::kProfMax) return;
+        slot = ws.prof_n;
+        for (int e = 2 * slot; e < 2 * slot + 2; ++e)
+            if (ws.prof_ev[e] == nullptr && hipEventCreate(&ws.prof_ev[e]) != hipSuccess) {
+                slot = -1;
+                return;
+            }
+        if (hipEventRecord(ws.prof_ev[2 * slot], stream) != hipSuccess) slot = -1;
+        if (slot >= 0) ws.prof_rows += rows;
+    }
+    ~ProfScope() {
+        if (slot >= 0 && hipEventRecord(ws.prof_ev[2 * slot + 1], stream) == hipSuccess) ws.prof_n = slot + 1;
+    }
+};
+}  // namespace
+
 int gram_update(GramWorkspace &ws, const float *X, int64_t rows, int64_t ld, int64_t d, const float *shift,
                 double *G64, double *S1, bool accumulate, bool defer, hipStream_t stream) {
     if (rows <= 0) return GS_OK;
@@ -905,7 +930,10 @@ int gram_update(GramWorkspace &ws, const float *X, int64_t rows, int64_t ld, int
                 GS_HIP_CHECK(hipStreamWaitEvent(stream, ws.ev_fold[buf], 0));
                 ws.aux_busy[buf] = false;
             }
-            launch_partial(ws, g, buf, X + base * ld, n, ld, d, shift, FoldJob{}, stream);
+            {
+                ProfScope prof(ws, stream, n);
+                launch_partial(ws, g, buf, X + base * ld, n, ld, d, shift, FoldJob{}, stream);
+            }
             GS_HIP_CHECK(hipEventRecord(ws.ev_comp[buf], stream));
             GS_HIP_CHECK(hipStreamWaitEvent(ws.aux, ws.ev_comp[buf], 0));
             const int T32 = (int)ws.dp / kSubTile, ntiles = T32 * (T32 + 1) / 2;
@@ -924,7 +952,10 @@ int gram_update(GramWorkspace &ws, const float *X, int64_t rows, int64_t ld, int
         // the previous launch's slabs are folded by this launch's spare workgroups
         const FoldJob f = pending_job(ws, G64, S1);
         const int buf = ws.cur;
-        launch_partial(ws, g, buf, X + base * ld, n, ld, d, shift, f, stream);
+        {
+            ProfScope prof(ws, stream, n);
+            launch_partial(ws, g, buf, X + base * ld, n, ld, d, shift, f, stream);
+        }
         ws.pend_valid = true;
         ws.pend_buf = buf;
         ws.pend_nchunks = g.nchunks;

@@ -1098,6 +1098,30 @@ int gs_ipca_finalize(gs_ipca_t *h, float *components_host, double *singular_valu
 int gs_ipca_last_sweeps(const gs_ipca_t *h) { return h ? h->last_sweeps : GS_EINVAL; }
 int gs_ipca_last_mults(const gs_ipca_t *h) { return h ? h->last_mults : GS_EINVAL; }
 
+int gs_ipca_profile_launches(gs_ipca_t *h, int enable) {
+    GS_REQUIRE(h != nullptr, GS_EINVAL, "gs_ipca_profile_launches: NULL handle");
+    GS_REQUIRE(h->mode != GS_MODE_SMALLSIDE, GS_ENOTIMPL, "gs_ipca_profile_launches: Gram-side handles only");
+    h->gws.profile = enable != 0;
+    h->gws.prof_n = 0;
+    h->gws.prof_rows = 0;
+    return GS_OK;
+}
+
+int gs_ipca_launch_profile(gs_ipca_t *h, int *launches_host, double *total_ms_host, int64_t *rows_host) {
+    GS_REQUIRE(h != nullptr, GS_EINVAL, "gs_ipca_launch_profile: NULL handle");
+    double total = 0.0;
+    for (int i = 0; i < h->gws.prof_n; ++i) {
+        GS_HIP_CHECK(hipEventSynchronize(h->gws.prof_ev[2 * i + 1]));
+        float ms = 0.f;
+        GS_HIP_CHECK(hipEventElapsedTime(&ms, h->gws.prof_ev[2 * i], h->gws.prof_ev[2 * i + 1]));
+        total += (double)ms;
+    }
+    if (launches_host) *launches_host = h->gws.prof_n;
+    if (total_ms_host) *total_ms_host = total;
+    if (rows_host) *rows_host = h->gws.prof_rows;
+    return GS_OK;
+}
+
 int gs_ipca_components_device(gs_ipca_t *h, const float **components, const float **mean) {
     GS_REQUIRE(h != nullptr, GS_EINVAL, "gs_ipca_components_device: NULL handle");
     GS_REQUIRE(h->finalized && !h->pending_diag && !h->inv_pending, GS_ESTATE,

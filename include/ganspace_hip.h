@@ -187,6 +187,14 @@ int gs_gram_accumulate_prec(const float *X, int64_t rows, int64_t ld, int64_t d,
 int gs_gram_kernel_time(gs_ipca_t *h, const float *X, int64_t rows, int64_t ld, int iters,
                         float *avg_ms_host, int64_t *rows_timed_host, void *stream);
 
+/* In-job timing of the dominant kernel (bench.py's `roofline.frac`): while enabled, every partial-Gram compute launch
+ * that gs_ipca_update / _update_resident / _finalize issue for this handle is bracketed by a pair of HIP timing events
+ * on ITS stream (at most 64 launches; the float64 fold is outside the pair).  gs_ipca_launch_profile waits for them and
+ * returns the number of launches, the sum of their durations in ms and the rows they covered.  Enabling resets the
+ * counters.  A measurement hook: the events cost ~1 us per launch, so the timed job itself runs without them.           */
+int gs_ipca_profile_launches(gs_ipca_t *h, int enable);
+int gs_ipca_launch_profile(gs_ipca_t *h, int *launches_host, double *total_ms_host, int64_t *rows_host);
+
 /* Symmetric eigendecomposition, float64.  A: [n*n] symmetric (row- or column-major is
  * the same), overwritten with eigenvectors stored as ROWS (V[i*n + :] = i-th vector),
  * w[n] eigenvalue estimates, both sorted by decreasing w.  One-sided (Hestenes) Jacobi;

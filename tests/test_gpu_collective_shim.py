@@ -50,8 +50,9 @@ def test_exact_allreduce_entry_with_several_ranks(shim, tmp_path, P, empty):
         assert int(z[f"n{r}"]) == len(X)
         cos = O.signed_cosines(z[f"comp{r}"], ref["components_"])
         assert cos.min() > 1 - 1e-9, (r, cos)
-        np.testing.assert_allclose(z[f"sv{r}"], ref["singular_values_"], rtol=1e-9)
-        np.testing.assert_allclose(z[f"mean{r}"], X.mean(0), atol=1e-12)
+        # (the contraction is exact-float32 MFMA: singular values agree with the float64 PCA to f32-accumulation level)
+        np.testing.assert_allclose(z[f"sv{r}"], ref["singular_values_"], rtol=2e-7)
+        np.testing.assert_allclose(z[f"mean{r}"], X.mean(0), atol=1e-9)
         assert np.array_equal(z[f"comp{r}"], z["comp0"]) and np.array_equal(z[f"sv{r}"], z["sv0"])
 
 
