@@ -46,6 +46,7 @@ LAUNCH_ROWS = 131072              # rows per Gram launch when the estimator may 
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_HBM_GBS = 8000.0             # HBM3E spec
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # dense bf16 MFMA peak (the 2:1-sparsity headline figure is not used)
+T_BENCH0 = time.perf_counter()
 
 
 def log(*a):
@@ -101,7 +102,97 @@ def gram_kernel_us(lib, _lib, est, block, iters=50, reps=3):
     return seen[-1], rows.value
 
 
+def e2e_runs(dev, args):
+    """``get_or_compute`` for BASELINE config 3 (BigGAN-512 ``generator.gen_z``, n = 1e6, ``-b`` pinned to 2000: the README
+    command leaves it to the auto-tuner) and config 5 (StyleGAN2 ``convs.2``, d = 131 072, at the n the run
+    can afford: the conv prefix is PyTorch-ROCm).  Phase times from ``decomposition.LAST_TIMINGS``.  cfg3's activation is
+    affine in z, so the exact PCA of ALL n activations follows from the 128 x 128 latent covariance: an independent
+    float64 reference at the full n for the top components (parity with scikit-learn itself at reduced n:
+    tests/test_gpu_decomposition.py)."""
+    import contextlib
+    import shutil
+    import tempfile
+    from types import SimpleNamespace
+    from ganspace_amd import decomposition as dec
+    from ganspace_amd.config import Config
+    from ganspace_amd.wrappers import get_instrumented_model
+    res = {}
+    jobs = (("cfg3_biggan512_gen_z", dict(model="BigGAN-512", layer="generator.gen_z", output_class=250, n=1_000_000,
+                                          batch_size=2000, components=K_COMP, estimator="ipca")),
+            ("cfg5_stylegan2_convs2", dict(model="StyleGAN2", layer="convs.2", output_class="ffhq", n=args.e2e_cfg5_n,
+                                           batch_size=250, components=K_COMP, estimator="ipca")))
+    for name, kw in jobs:
+        run_dir = tempfile.mkdtemp(prefix="gs_bench_e2e_")
+        try:
+            cfg = Config(**kw)
+            t0 = time.perf_counter()
+            inst = get_instrumented_model(cfg.model, cfg.output_class, cfg.layer, dev)
+            torch.cuda.synchronize()
+            t_model = time.perf_counter() - t0
+            dec.PROFILE = True
+            with contextlib.redirect_stdout(sys.stderr):
+                path = dec.get_or_compute(cfg, inst, submit_config=SimpleNamespace(run_dir_root=run_dir, run_dir=run_dir))
+            dec.PROFILE = False
+            t = {k_: (round(v, 4) if isinstance(v, float) else v) for k_, v in dec.LAST_TIMINGS.items()}
+            data = np.load(path, allow_pickle=False)
+            entry = {"config": {k_: v for k_, v in kw.items()}, "model_setup_s": round(t_model, 3), "phases": t,
+                     "samples_per_s_total": round(t["n"] / t["T_total_s"], 1),
+                     "samples_per_s_fit_loop": round(t["n"] / t["T_fit_loop_s"], 1),
+                     "npz_keys_ok": sorted(data.files) == sorted(["act_comp", "act_mean", "act_stdev", "lat_comp", "lat_mean",
+                                                                  "lat_stdev", "var_ratio", "random_stdevs"]),
+                     "all_finite": bool(all(np.isfinite(data[f]).all() for f in data.files))}
+            if name.startswith("cfg3"):
+                # activation = Wz z + const (class fixed): covariance = Wz Cov(z) Wz^T; its leading eigenvectors from the
+                # 128 x 128 side in float64.  z = the very latents the run used (same seed protocol, regenerated)
+                model = inst.model
+                g = model.model.generator.gen_z
+                Wz = g.weight.detach().double()[:, :128]                       # cond = cat(z, embedding)
+                plan = dec._Plan.make(cfg.n, cfg.batch_size, cfg.components)
+                lshape = model.get_latent_shape()          # (draws from the global stream: before the seeding, as in compute())
+                torch.manual_seed(dec.SEED_SAMPLING)
+                np.random.seed(dec.SEED_SAMPLING)
+                lat, _ = dec._presample(model, plan, lshape, dev)
+                zz = lat.reshape(lat.shape[0], -1)[:plan.N].double()
+                zc = zz - zz.mean(0)
+                Sz = (zc.T @ zc) / (plan.N - 1)
+                Lz = torch.linalg.cholesky(Sz)
+                Mz = Wz @ Lz                                                    # [d, 128]: covariance = Mz Mz^T
+                w, U = torch.linalg.eigh(Mz.T @ Mz)
+                top = torch.argsort(w, descending=True)[:cfg.components]
+                comp_ref = (Mz @ U[:, top] / torch.sqrt(w[top])).T.cpu().numpy()
+                # The random-init gen_z has a nearly flat spectrum (128 comparable singular values), so single directions
+                # are not identifiable - IPCA's own rank-80 truncation alone moves them.  What IS determined: every
+                # component lies in the 128-dimensional range of Wz, and the leading variances are those of the exact PCA
+                Qw, _ = torch.linalg.qr(Wz)                                      # [d, 128] orthonormal basis of the range
+                comp = torch.from_numpy(data["act_comp"].reshape(cfg.components, -1)).to(dev).double()
+                inside = torch.linalg.norm(comp @ Qw, dim=1).cpu().numpy()
+                ev_ref = np.sqrt(w[top].cpu().numpy())
+                entry["vs_exact_pca_of_all_n_activations"] = {
+                    "how": "activation is affine in z: exact PCA of all n activations = eigenpairs of Wz Cov(z) Wz^T, from the "
+                           "128 x 128 side in float64 (z regenerated with the run's seed protocol)",
+                    "components_norm_inside_range_of_Wz_min": round(float(inside.min()), 9),
+                    "stdev_top20_max_rel_err": float(np.abs(data["act_stdev"][:20] / ev_ref[:20] - 1).max()),
+                    "spectrum_flatness_sigma1_over_sigma80": round(float(ev_ref[0] / ev_ref[-1]), 3),
+                    "note": "per-direction cosines are meaningless on this near-flat spectrum (random-init weights); the "
+                            "per-direction parity of this path against scikit-learn's arithmetic is "
+                            "tests/test_gpu_decomposition.py::test_cfg3_biggan_gen_z_small_side"}
+                del comp_ref
+                del lat, zz, zc
+            res[name] = entry
+            inst.close()
+            del inst
+        except Exception as ex:                                   # an extra must never take the headline line down
+            res[name] = {"error": repr(ex)}
+            dec.PROFILE = False
+        finally:
+            shutil.rmtree(run_dir, ignore_errors=True)
+            torch.cuda.empty_cache()
+    return res
+
+
 def main():
+    global T_BENCH0
+    T_BENCH0 = time.perf_counter()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -112,8 +203,12 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-blocks", type=int, default=16)
     ap.add_argument("--no-wide", action="store_true", help="skip the cfg3/cfg5-shape small-side timings")
-    ap.add_argument("--wide-cpu-budget-s", type=float, default=45.0,
-                    help="host seconds per wide shape for the scikit-learn baseline (>= 2 blocks are always timed)")
+    ap.add_argument("--budget-s", type=float, default=330.0,
+                    help="wall-clock budget of the whole run: the wide shapes' scikit-learn baselines (26 s per 2000-row block at "
+                         "d = 131 072) come last and stop taking blocks when the next one would not fit (>= 2 are always timed)")
+    ap.add_argument("--wide-cpu-blocks", type=int, default=6, help="blocks of that baseline (first + steady-state ones)")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end get_or_compute runs of cfg3 / cfg5")
+    ap.add_argument("--e2e-cfg5-n", type=int, default=20_000, help="samples of the cfg5 end-to-end run (conv prefix in PyTorch)")
     ap.add_argument("--wide-cpu-threads", type=int, default=32, help="BLAS threads of that baseline")
     ap.add_argument("--no-extras", action="store_true", help="headline + roofline only (profiling runs)")
     args = ap.parse_args()
@@ -154,6 +249,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    ar_events = []
+
     def run(est, nsteps, finish=True):
         if est.mode == "exact":
             # (the product's W-space loop does the same: decomposition._fit_blocks hands over views of the resident
@@ -165,7 +262,13 @@ def main():
                 assert est.fit_partial(blocks[i % n_blocks])
         if finish:
             if dist is not None and args.mode == "exact":
+                # (events, no host synchronisation: the exchange's share of the timed region is read afterwards)
+                ar_events.clear()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
                 gdist.allreduce_estimator(est, d=D)
+                e1.record()
+                ar_events.extend((e0, e1))
             est.get_components()           # eigensolve (exact mode) + D2H of the results
 
     # ---- warm-up (untimed) ------------------------------------------------------------------
@@ -180,12 +283,25 @@ def main():
     run(est, K)
     barrier()
     dt = time.perf_counter() - t0
+    dt_local = dt
     if dist is not None:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     samples = K * BLOCKS_PER_STEP * NB * world
     value = samples / dt
+    # what a scaling curve needs to explain itself: the exchange step's share of the timed region on every rank, and every
+    # rank's pre-sampling time (the ranks of one node share its host cores for the z stream)
+    multi = None
+    if dist is not None:
+        ar_s = ar_events[0].elapsed_time(ar_events[1]) * 1e-3 if len(ar_events) == 2 else 0.0
+        mine = {"rank": rank, "allreduce_s": round(ar_s, 6), "T_sample_s": round(t_sample, 4), "timed_region_s": round(dt_local, 6)}
+        gathered = [None] * world
+        dist.all_gather_object(gathered, mine)
+        multi = {"per_rank": gathered, "allreduce_s_max": max(g["allreduce_s"] for g in gathered),
+                 "T_sample_s_max": max(g["T_sample_s"] for g in gathered),
+                 "note": "allreduce_s = HIP events around distributed.allreduce_estimator inside the timed region (header "
+                         "all-reduce, re-centring, packed scatter all-reduce, import); T_sample_s is outside it"}
     if rank == 0 and os.environ.get("GS_BENCH_DUMP"):       # test hook: the components the timed job produced
         np.save(os.environ["GS_BENCH_DUMP"], est.get_components()[0])
 
@@ -201,6 +317,25 @@ def main():
     est2.get_components()
     torch.cuda.synchronize()
     t_final = time.perf_counter() - t0
+    # ---- the job once more with a pair of HIP events around every Gram compute launch it issues (gs_ipca_profile_launches):
+    #      the duration of the dominant kernel AS THE JOB RUNS IT - after a host-side phase, between folds and event waits -
+    #      which is what `ms_per_step` contains; the back-to-back microbenchmark below is the steady-state figure
+    est3 = IPCAEstimator(K_COMP, args.mode)
+    est3.transformer._ensure(D)
+    _lib.check(lib.gs_ipca_profile_launches(est3.transformer._h, 1))
+    torch.cuda.synchronize()
+    run(est3, K, finish=True)
+    torch.cuda.synchronize()
+    pl_n, pl_ms, pl_rows = C.c_int(0), C.c_double(0.0), C.c_int64(0)
+    _lib.check(lib.gs_ipca_launch_profile(est3.transformer._h, C.cast(C.byref(pl_n), C.c_void_p),
+                                          C.cast(C.byref(pl_ms), C.c_void_p), C.cast(C.byref(pl_rows), C.c_void_p)))
+    _lib.check(lib.gs_ipca_profile_launches(est3.transformer._h, 0))
+    injob = None
+    if pl_n.value > 0 and pl_ms.value > 0:
+        injob = {"launches": pl_n.value, "rows": pl_rows.value, "total_ms": pl_ms.value,
+                 "tflops": pl_rows.value * D * (D + 1) / (pl_ms.value * 1e-3) / 1e12,
+                 "gbs": pl_rows.value * D * 4 / (pl_ms.value * 1e-3) / 1e9}
+    del est3
 
     # ---- roofline of the dominant kernel of the timed region (the partial X^T X MFMA kernel: one launch per
     #      block, K x 5 launches), HIP events on its stream ----------------------------------------------------
@@ -234,9 +369,18 @@ def main():
     except Exception:
         pass
     frac_of_region = (n_launches * us * 1e-6) / (t_updates + t_final) if (t_updates + t_final) > 0 else None
+    # `achieved` / `frac`: the kernel inside the job (events around the job's own launches); the steady-state microbenchmark
+    # (50 back-to-back launches, third repetition) is reported next to it, not instead of it
+    job_tf = injob["tflops"] if injob else ach_tf
     roofline = {"bound": "mfma", "kernel": "gram_f32_wide_kernel" if args.mode == "exact" else "gram_partial_kernel<true, false>",
-                "achieved": round(ach_tf, 2),
-                "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach_tf / PEAK_F32_MFMA_TFLOPS, 4),
+                "achieved": round(job_tf, 2),
+                "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(job_tf / PEAK_F32_MFMA_TFLOPS, 4),
+                "frac_source": ("HIP events around the %d Gram launches of one run of the timed job (%d rows, %.3f ms in "
+                                "total; gs_ipca_profile_launches)" % (injob["launches"], injob["rows"], injob["total_ms"]))
+                               if injob else "steady-state microbenchmark (no in-job profile)",
+                "in_job_avg_launch_us": None if not injob else round(injob["total_ms"] * 1e3 / injob["launches"], 2),
+                "steady_state_microbenchmark": {"achieved": round(ach_tf, 2), "frac": round(ach_tf / PEAK_F32_MFMA_TFLOPS, 4),
+                                                "avg_launch_us": round(us, 2), "rows_per_launch": rows_l},
                 "traffic": traffic, "traffic_source": "profiles/gram_pmc_latest.json (rocprofv3 --pmc: FETCH_SIZE x2 + WRITE_SIZE)",
                 "traffic_note": traffic_note,
                 "avg_launch_us": round(us, 2), "avg_launch_us_first_repetition": round(us_first, 2),
@@ -245,7 +389,8 @@ def main():
                 "rows_per_launch": rows_l, "launches_in_timed_region": n_launches,
                 "share_of_timed_region": None if frac_of_region is None else round(frac_of_region, 3),
                 "algorithmic_flops_per_launch": flops, "algorithmic_bytes_per_launch": bytes_,
-                "hbm_achieved_GBs": round(ach_gbs, 1), "hbm_frac_of_8TBs": round(ach_gbs / PEAK_HBM_GBS, 4),
+                "hbm_achieved_GBs": round(injob["gbs"] if injob else ach_gbs, 1),
+                "hbm_frac_of_8TBs": round((injob["gbs"] if injob else ach_gbs) / PEAK_HBM_GBS, 4),
                 "clock_note": "peak = 2.4 GHz x 256 CU x 4 SIMD x 64 flop/clk; the s_memtime traces of this kernel "
                               "(DESIGN.md 5) show ~2.05 GHz under ITS load (MFMA + LDS + VALU mix) - a property of the "
                               "kernel's power draw, not a chip limit (a pure MFMA loop holds 155 TF, MI355X_MICROARCH.md)"}
@@ -268,6 +413,8 @@ def main():
                       "eigh_products": int(lib.gs_ipca_last_mults(est2.transformer._h)),
                       "eigh_sweeps": int(lib.gs_ipca_last_sweeps(est2.transformer._h))},
     }
+    if multi is not None:
+        out["multi_gpu"] = multi
 
     extras = rank == 0 and world == 1 and not args.no_extras
     # ---- CPU baseline + cos-sim on a bounded sample (rank 0, N=1 only) -----------------------------
@@ -420,6 +567,8 @@ def main():
                 e2.get_components()
                 torch.cuda.synchronize()
                 cos[mode]["samples_per_s"] = round(nb * NB / (time.perf_counter() - t0), 1)
+        cos["sample"] = (f"the first {nb} blocks ({nb * NB} rows) on both sides: scikit-learn on the host is the slow side; the "
+                         "n = 1e6 comparison with scikit-learn runs in tests/test_gpu_decomposition.py (cfg2_full)")
         out["cos_sim_vs_reference"] = cos
         out["vs_cpu_baseline"] = round(value / out["cpu_baseline"]["value"], 1)
 
@@ -541,12 +690,8 @@ def main():
                     del X
             # pass 2: the float64 oracle on the same (regenerated) blocks
             orc = SmallSideTorchOracle(K_COMP)
-            host_blocks = []
-            cpu_keep = 6 if not args.no_cpu_baseline else 0      # first block + up to five steady-state blocks
             for i, X in enumerate(lowrank_plus_noise_blocks(dd, n_wide, rows=2000, device=dev)):
                 orc.partial_fit(X)
-                if i < cpu_keep:
-                    host_blocks.append(X.cpu().numpy())
                 del X
             r_ = K_COMP + 2000 + 1
             # executed work of a steady-state block, triangle convention (as the headline's roofline): T = M M^T over its
@@ -571,42 +716,59 @@ def main():
                              "singular_values_max_rel_err": float(np.abs(e.transformer.singular_values_ /
                                                                          orc.singular_values_ - 1).max())}
             del ests, orc
-            if host_blocks:
-                # scikit-learn (the reference's arithmetic) on the host: first block + steady-state blocks until five are
-                # timed or the budget is spent; the n = 1e6 job (500 blocks) is extrapolated
-                sk = reference_cpu.make_reference_ipca(K_COMP)
-                per, spent = [], 0.0
-                with reference_cpu.blas_threads(args.wide_cpu_threads):
-                    for hb in host_blocks:
-                        if len(per) >= 2 and spent + per[-1] > args.wide_cpu_budget_s:
-                            break
-                        t0 = time.perf_counter()
-                        sk.partial_fit(hb)
-                        per.append(time.perf_counter() - t0)
-                        spent += per[-1]
-                nb_cpu = len(per)
-                e = IPCAEstimator(K_COMP, "faithful")
-                for hb in host_blocks[:nb_cpu]:
-                    e.fit_partial(torch.from_numpy(hb).to(dev))
-                c = signed_cosines(e.get_components()[0], sk.components_)
-                steady_cpu = float(np.mean(per[1:]))
-                t_job = per[0] + 499 * steady_cpu
-                entry["cpu_baseline"] = {"value": round(1e6 / t_job, 2), "unit": "samples/s", "kind": "reference",
-                                         "cores": args.wide_cpu_threads, "first_block_s": round(per[0], 2),
-                                         "steady_block_s": round(steady_cpu, 2), "steady_blocks_timed": nb_cpu - 1,
-                                         "sample": f"{nb_cpu} blocks of 2000 x {dd} (sklearn IncrementalPCA.partial_fit), "
-                                                   "n = 1e6 (500 blocks) extrapolated"}
-                entry["vs_sklearn_at_reduced_n"] = {"n": nb_cpu * 2000,
-                                                    "all80_min_signed_cos": round(float(c.min()), 8),
-                                                    "top20_min_signed_cos": round(float(c[:20].min()), 8)}
-                entry["vs_cpu_baseline"] = round(entry["f32"]["samples_per_s"] / entry["cpu_baseline"]["value"], 1)
-                del e, sk
-            del host_blocks
             entry["ms_per_block"] = entry["f32"]["ms_per_block"]
             entry["samples_per_s"] = entry["f32"]["samples_per_s"]
             wide[name] = entry
             torch.cuda.empty_cache()
         out["wide_feature_shapes"] = wide
+
+    # ---- end to end, BASELINE configs 3 and 5 through the product's own get_or_compute (decomposition.py:226-341 of the
+    #      reference: pre-sampling, "Fitting batches" loop with the hooked generator, read-out, regression back to latent
+    #      space, .npz), phase by phase (ganspace_amd.decomposition.LAST_TIMINGS) ---------------------------------------
+    if extras and not args.no_e2e:
+        out["end_to_end_cfg3_cfg5"] = e2e_runs(dev, args)
+
+    # ---- the wide shapes' CPU baselines, LAST and alone on the host (beside the GPU legs they ran 2-5x slower and slowed
+    #      the host-bound GPU legs down in turn): scikit-learn's IncrementalPCA.partial_fit - the reference's arithmetic,
+    #      /root/reference/estimators.py:68-76 - on CPU-seeded blocks of the same synthetic workload, first block + up to
+    #      `--wide-cpu-blocks - 1` steady-state blocks (SURVEY.md 8d asks for >= 5) while the run's budget lasts; the n = 1e6
+    #      job (500 blocks) is extrapolated.  The same blocks then go through the device estimator for the cosine ----------
+    if extras and not args.no_wide and not args.no_cpu_baseline:
+        from oracle import reference_cpu
+        from oracle.ipca import signed_cosines
+        from oracle.smallside_torch import lowrank_plus_noise_blocks
+        for name, dd in (("cfg3_shape_d32768", 32768), ("cfg5_shape_d131072", 131072)):
+            entry = out.get("wide_feature_shapes", {}).get(name)
+            if entry is None:
+                continue
+            sk = reference_cpu.make_reference_ipca(K_COMP)
+            per = []
+            with reference_cpu.blas_threads(args.wide_cpu_threads):
+                for X in lowrank_plus_noise_blocks(dd, args.wide_cpu_blocks, rows=2000, device="cpu"):
+                    guess = per[-1] if len(per) >= 2 else (per[0] if per else 0.0)
+                    if len(per) >= 2 and (time.perf_counter() - T_BENCH0) + guess > args.budget_s:
+                        break
+                    hb = X.numpy()
+                    t0 = time.perf_counter()
+                    sk.partial_fit(hb)
+                    per.append(time.perf_counter() - t0)
+                    del X, hb
+            steady_cpu = float(np.mean(per[1:]))
+            t_job = per[0] + 499 * steady_cpu
+            entry["cpu_baseline"] = {"value": round(1e6 / t_job, 2), "unit": "samples/s", "kind": "reference",
+                                     "cores": args.wide_cpu_threads, "first_block_s": round(per[0], 2),
+                                     "steady_block_s": round(steady_cpu, 2), "steady_blocks_timed": len(per) - 1,
+                                     "seconds_per_block": [round(x, 2) for x in per],
+                                     "sample": f"{len(per)} blocks of 2000 x {dd} (sklearn IncrementalPCA.partial_fit, alone on the "
+                                               "host at the end of the run), n = 1e6 (500 blocks) extrapolated"}
+            entry["vs_cpu_baseline"] = round(entry["f32"]["samples_per_s"] / entry["cpu_baseline"]["value"], 1)
+            e = IPCAEstimator(K_COMP, "faithful")
+            for X in lowrank_plus_noise_blocks(dd, len(per), rows=2000, device="cpu"):
+                e.fit_partial(X.to(dev))
+            c = signed_cosines(e.get_components()[0], sk.components_)
+            entry["vs_sklearn_at_reduced_n"] = {"n": len(per) * 2000, "all80_min_signed_cos": round(float(c.min()), 8),
+                                                "top20_min_signed_cos": round(float(c[:20].min()), 8)}
+            del e, sk
 
     if rank == 0:
         print(json.dumps(out), flush=True)

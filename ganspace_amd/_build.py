@@ -121,10 +121,16 @@ def build(force: bool = False, verbose: bool = True, measure: bool = False) -> s
         with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 1)) as pool:
             usages = list(pool.map(compile_one, jobs))
         import json
+        usage_path = os.path.join(libdir, "kernel_usage.json")
         merged = {}
+        if not force and os.path.exists(usage_path):      # (an incremental build recompiles only some translation units)
+            try:
+                merged = json.load(open(usage_path))
+            except Exception:
+                merged = {}
         for u in usages:
             merged.update(u)
-        with open(os.path.join(libdir, "kernel_usage.json"), "w") as f:     # (read by tests/test_abi.py)
+        with open(usage_path, "w") as f:     # (read by tests/test_abi.py)
             json.dump(merged, f, indent=0, sort_keys=True)
     cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", out]
     if verbose:

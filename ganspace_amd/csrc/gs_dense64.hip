@@ -65,23 +65,31 @@ template <bool KSPLIT, int CH>
 __global__ __launch_bounds__(256) void mm64_kernel(int M, int N, int K, const double *__restrict__ A, int64_t a_i,
                                                    int64_t a_t, const double *__restrict__ B, int64_t b_t, int64_t b_j,
                                                    double *__restrict__ C, int64_t ldc, double alpha, double beta,
-                                                   int kchunk, GemmEpilogue epi) {
+                                                   int kchunk, int ntc, int nrl, GemmEpilogue epi) {
     __shared__ double red[KSPLIT ? 4 * 256 : 1];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int li = lane & 15, g = lane >> 4;
     int i0, j0, kb, ke;
+    // XCD-aware tile order (1-D grid; workgroup b runs on XCD b % 8): XCD x takes the row tiles x, x + 8, ... with all their
+    // column tiles, so each XCD's L2 holds ITS rows of A - the solver chains multiply the same A dozens of times (42
+    // products per cold solve), and with the plain 2-D order every XCD streamed all of A through its L2 for every product
+    const int xcd = blockIdx.x & 7, wq = blockIdx.x >> 3;
+    const int ct = wq % ntc, w2 = wq / ntc;
+    const int rt = xcd + 8 * (w2 % nrl), zi = w2 / nrl;
+    constexpr int TS = KSPLIT ? 16 : 32;
+    if (rt * TS >= M) return;                       // (row-tile count not a multiple of 8: the padding workgroups leave)
     {
-        const int zb = blockIdx.z * kchunk;
+        const int zb = zi * kchunk;
         const int ze = (zb + kchunk < K) ? zb + kchunk : K;
         if (KSPLIT) {
-            i0 = blockIdx.y * 16;
-            j0 = blockIdx.x * 16;
+            i0 = rt * 16;
+            j0 = ct * 16;
             const int kw = (((ze - zb) + 15) >> 4 << 4) >> 2;       // quarter of the range, a multiple of 4
             kb = zb + wave * kw;
             ke = (kb + kw < ze) ? kb + kw : ze;
         } else {
-            i0 = blockIdx.y * 32 + (wave >> 1) * 16;
-            j0 = blockIdx.x * 32 + (wave & 1) * 16;
+            i0 = rt * 32 + (wave >> 1) * 16;
+            j0 = ct * 32 + (wave & 1) * 16;
             kb = zb;
             ke = ze;
         }
@@ -112,13 +120,13 @@ __global__ __launch_bounds__(256) void mm64_kernel(int M, int N, int K, const do
             }
         }
     }
-    const bool split = gridDim.z > 1;
+    const bool split = kchunk < K;
     auto emit = [&](int r, int c, double v) {
         if (r >= M || c >= N) return;
         double *dst = C + (int64_t)r * ldc + c;
         if (epi.coef != nullptr) {
             double o = epi.coef[0] * v;
-            if (!split || blockIdx.z == 0) {
+            if (!split || zi == 0) {
                 if (epi.E1) o += epi.coef[1] * epi.E1[(int64_t)r * ldc + c];
                 if (epi.E2) o += epi.coef[2] * epi.E2[(int64_t)r * ldc + c];
             }
@@ -163,28 +171,30 @@ void mm64(int M, int N, int K, const double *A, int64_t a_i, int64_t a_t, const 
     zs = (int)ceil_div(K, kchunk);
     if (zs > 1 && !c_is_zero)
         GS_LAUNCH(mm64_zero_kernel, dim3((unsigned)ceil_div(N, 256), (unsigned)M), dim3(256), 0, stream, C, N, ldc);
+    const int ts = ksplit ? 16 : 32;
+    const int ntc = (int)ceil_div(N, ts), nrl = (int)ceil_div(ceil_div(M, ts), 8);
+    const dim3 grid((unsigned)(8 * nrl * ntc * zs));
     if (ksplit) {
-        const dim3 grid((unsigned)ceil_div(N, 16), (unsigned)ceil_div(M, 16), (unsigned)zs);
         if (kchunk <= 128)
             GS_LAUNCH((mm64_kernel<true, 32>), grid, dim3(256), 0, stream, M, N, K, A, a_i, a_t, B, b_t, b_j, C, ldc, alpha,
-                      beta, kchunk, epi);
+                      beta, kchunk, ntc, nrl, epi);
         else
             GS_LAUNCH((mm64_kernel<true, 128>), grid, dim3(256), 0, stream, M, N, K, A, a_i, a_t, B, b_t, b_j, C, ldc, alpha,
-                      beta, kchunk, epi);
+                      beta, kchunk, ntc, nrl, epi);
     } else {
-        const dim3 grid((unsigned)ceil_div(N, 32), (unsigned)ceil_div(M, 32), (unsigned)zs);
         if (kchunk <= 32)
             GS_LAUNCH((mm64_kernel<false, 32>), grid, dim3(256), 0, stream, M, N, K, A, a_i, a_t, B, b_t, b_j, C, ldc, alpha,
-                      beta, kchunk, epi);
+                      beta, kchunk, ntc, nrl, epi);
         else
             GS_LAUNCH((mm64_kernel<false, 128>), grid, dim3(256), 0, stream, M, N, K, A, a_i, a_t, B, b_t, b_j, C, ldc, alpha,
-                      beta, kchunk, epi);
+                      beta, kchunk, ntc, nrl, epi);
     }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
 // H = R^T R (p x p Gram matrix, p <= 128)  ->  Rinv = R^-1 (upper triangular, row-major, zeros below the diagonal),
-// rdiag[j] = R_jj (0 = numerically dependent column).  ONE workgroup of 1024 threads, matrix in LDS.
+// rdiag[j] = R_jj (0 = numerically dependent column).  ONE workgroup of 512 threads (8 waves: 256 VGPRs each - the diagonal-block
+// wave keeps two 16-double arrays live), matrix in LDS.
 //
 // Forward elimination of [H | I] leaves [R | R^-T]: the identity half is lower triangular throughout, so it lives in the
 // strictly lower triangle of the LDS image (the factorisation only touches the upper one) plus a separate diagonal.
@@ -198,10 +208,98 @@ void mm64(int M, int N, int K, const double *A, int64_t a_i, int64_t a_t, const 
 // column: row j AND column j of R^-1 are zero, so column j of Y R^-1 is exactly zero and no later column uses it.
 constexpr int kCiP = 128;
 constexpr int kCiLd = 129;
+
+// (a) of chol_inv_kernel: the 16 x 16 diagonal block at j0 and its identity block, ONE wave, branch-free: lane c < 16 holds
+// column c of the block, lane 16 + c column c of the identity, all 16 rows in registers.  Entries below the diagonal of a
+// block column only ever see no-op or unread updates, so the elimination step needs no row / column masks.
+// (Alone this code takes 2 800 clk per block, tools/ubench/chol_leaf.hip; inside the 1024-thread kernel its v_readlane
+//  results compete with the kernel's live scalars - the timing instrumentation of the measurement build is therefore a
+//  template parameter, not a run-time flag.)
+template <bool STAMP = false>
+__device__ __forceinline__ void chol_leaf16(double *__restrict__ Hs, double *__restrict__ Es, double *__restrict__ ed,
+                                            double *__restrict__ rd, const double *__restrict__ refd, int j0, int lane,
+                                            long long *stamps = nullptr) {
+    if (STAMP) stamps[0] = clock64();
+    const int c = lane & 15;
+    const bool aug = (lane & 16) != 0;
+    double col[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        double v = (r == c) ? 1.0 : 0.0;
+        if (!aug) v = (r <= c) ? Hs[(j0 + r) * kCiLd + j0 + c] : 0.0;
+        col[r] = v;
+    }
+    const double ref = refd[j0 + c] * 1e-13;
+    unsigned dead_mask = 0;
+    if (STAMP) stamps[1] = clock64();
+    // The 16 pivots are a dependency chain: pivot -> rsqrt -> row j -> ONE multiply-add -> next pivot.  Only the update of
+    // row j + 1 sits on that chain; the next pivot's reciprocal square root is started right behind it, and the other
+    // 14 - j row updates of pivot j (independent of each other and of that rsqrt) fill its latency.  All v_readlanes of a
+    // pivot come first (distinct scalar registers: no write-after-read stalls between consecutive elements); the
+    // scheduling barriers keep the compiler from sinking the row updates into one long multiply-add chain in front of
+    // each pivot (a left-looking order, 3x slower).
+    double d = readlane64(col[0], 0);
+    bool dead = !(d > readlane64(ref, 0));               // (wave-uniform)
+    double inv = __builtin_amdgcn_rsq(d);                // one Newton step on the ~2^-26 seed: ~3e-16 relative
+    inv = inv * (1.5 - (0.5 * d) * inv * inv);
+    inv = dead ? 0.0 : inv;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        dead_mask |= dead ? (1u << j) : 0u;
+        double rjc = col[j] * inv;                        // row j of R / of R^-T at this lane's column
+        // (the pivot index as an opaque per-lane value: with the literal j the compiler evaluates the 2 x 16 lane masks
+        //  c == j / c > j of the unrolled loop up front, keeps them in scalar register pairs and spills ~100 of them)
+        int jv = j;
+        asm volatile("" : "+v"(jv));
+        if (!aug) rjc = (c == jv) ? (dead ? 1.0 : d * inv) : ((c > jv) ? rjc : 0.0);
+        col[j] = rjc;
+        double row[16];
+#pragma unroll
+        for (int r = j + 1; r < 16; ++r) row[r] = readlane64(rjc, r);     // R[j][r] lives in lane r < 16
+        __builtin_amdgcn_sched_barrier(0);
+        double d_next = 1.0, inv_next = 0.0;
+        bool dead_next = false;
+        if (j + 1 < 16) {
+            col[j + 1] -= row[j + 1] * rjc;
+            d_next = readlane64(col[j + 1], j + 1);
+            dead_next = !(d_next > readlane64(ref, j + 1));
+            inv_next = __builtin_amdgcn_rsq(d_next);
+            inv_next = inv_next * (1.5 - (0.5 * d_next) * inv_next * inv_next);
+            inv_next = dead_next ? 0.0 : inv_next;
+        }
+#pragma unroll
+        for (int r = j + 2; r < 16; ++r) col[r] -= row[r] * rjc;
+        __builtin_amdgcn_sched_barrier(0);
+        d = d_next;
+        inv = inv_next;
+        dead = dead_next;
+    }
+    if (STAMP) stamps[2] = clock64();
+    // Results to LDS, 16 unpredicated stores for both halves at once (16 + 32 predicated ones took as long as the 16
+    // pivots): lanes 0-15 store their whole column into the block - the sub-diagonal garbage is overwritten when the kernel
+    // copies R_JJ^-T (Es) into the block's lower triangle after the next barrier -, lanes 16-31 store column c of R_JJ^-T
+    // into Es (zeros above the diagonal and in dead rows / columns).
+    const bool dead_c = (dead_mask >> c) & 1u;
+    if (lane < 32) {
+        double *base = aug ? Es + c : Hs + j0 * kCiLd + j0 + c;
+        const int stride = aug ? 17 : kCiLd;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const bool dead_r = (dead_mask >> r) & 1u;
+            const bool zero = aug && (r < c || dead_r || dead_c);
+            base[r * stride] = zero ? 0.0 : col[r];
+        }
+        if (!aug) rd[j0 + c] = dead_c ? 0.0 : col[c];
+    }
+    if (STAMP) stamps[3] = clock64();
+}
 constexpr size_t kCiLdsBytes = sizeof(double) * ((size_t)kCiP * kCiLd + 2 * 16 * 17 + 3 * kCiP);
-__global__ __launch_bounds__(1024) void chol_inv_kernel(const double *__restrict__ H, int64_t ldh, int p,
+template <bool debug>
+__global__ __launch_bounds__(512) void chol_inv_kernel(const double *__restrict__ H, int64_t ldh, int p,
                                                          double *__restrict__ Rinv, int64_t ldr,
-                                                         double *__restrict__ rdiag, int debug) {
+                                                         double *__restrict__ rdiag, int ablate) {
+    // (ablate: measurement build only, results wrong by design - bit 0 no diagonal-block pivots, bit 1 no trailing tiles,
+    //  bit 2 no panels; always 0 in the production library)
     extern __shared__ __attribute__((aligned(16))) double cis[];
     double *Hs = cis;                           // [128][129]  upper: H -> R;  strictly lower: R^-T
     double *Es = Hs + kCiP * kCiLd;             // [16][17]    R_JJ^-T of the current block (full 16 x 16, zeros above the diagonal)
@@ -214,69 +312,25 @@ __global__ __launch_bounds__(1024) void chol_inv_kernel(const double *__restrict
     const int li = lane & 15, lg = lane >> 4;
     const int nblk = (p + 15) >> 4, pend = nblk * 16;
     {
-        // thread = (column j, row phase): 16 independent loads in flight per thread, one round trip for the whole matrix
+        // thread = (column j, row phase): 32 independent loads in flight per thread, one round trip for the whole matrix
         const int j = tid & 127, i0 = tid >> 7;
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const int i = i0 + 8 * q;
+        for (int q = 0; q < 32; ++q) {
+            const int i = i0 + 4 * q;
             double v = 0.0;
             if (i <= j && j < p) v = H[(int64_t)i * ldh + j];
             if (i == j && j >= p) v = 1.0;
             if (i < pend && j < pend) Hs[i * kCiLd + j] = v;
         }
     }
-    if (tid < kCiP) refd[tid] = (tid < p) ? H[(int64_t)tid * ldh + tid] : 1.0;
+    __syncthreads();
+    if (tid < kCiP) refd[tid] = (tid < pend) ? Hs[tid * kCiLd + tid] : 1.0;      // original diagonal (padding: 1)
     __syncthreads();
     if (debug) dbg_load = clock64() - dbg_c0;
 
-    // (a) diagonal block J by ONE wave, branch-free: lane c < 16 column c of the block, lane 16 + c column c of the identity.
-    // Entries below the diagonal of a block column only ever see no-op or unread updates, so the elimination step needs
-    // no row / column masks.
+    long long lstamp[4] = {0, 0, 0, 0};
     auto leaf = [&](int J) {
-        const int j0 = 16 * J;
-        const int c = lane & 15;
-        const bool aug = (lane & 16) != 0;
-        double col[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            double v = (r == c) ? 1.0 : 0.0;
-            if (!aug) v = (r <= c) ? Hs[(j0 + r) * kCiLd + j0 + c] : 0.0;
-            col[r] = v;
-        }
-        const double ref = refd[j0 + c] * 1e-13;
-        unsigned dead_mask = 0;
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const double d = readlane64(col[j], j);
-            const double rf = readlane64(ref, j);
-            const bool dead = !(d > rf);                     // (wave-uniform)
-            double inv = __builtin_amdgcn_rsq(d);            // one Newton step on the ~2^-26 seed: ~3e-16 relative
-            inv = inv * (1.5 - (0.5 * d) * inv * inv);
-            inv = dead ? 0.0 : inv;
-            dead_mask |= dead ? (1u << j) : 0u;
-            double rjc = col[j] * inv;                        // row j of R / of R^-T at this lane's column
-            if (!aug) rjc = (c == j) ? (dead ? 1.0 : d * inv) : ((c > j) ? rjc : 0.0);
-            col[j] = rjc;
-#pragma unroll
-            for (int r = j + 1; r < 16; ++r) col[r] -= readlane64(rjc, r) * rjc;     // R[j][r] lives in lane r < 16
-        }
-        const bool dead_c = (dead_mask >> c) & 1u;
-        if (lane < 16) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                if (r <= c) Hs[(j0 + r) * kCiLd + j0 + c] = col[r];
-            rd[j0 + c] = dead_c ? 0.0 : col[c];
-        } else if (lane < 32) {
-            // lane 16 + c: column c of R_JJ^-T (rows r >= c)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const bool dead_r = (dead_mask >> r) & 1u;
-                const double v = (r < c || dead_r || dead_c) ? 0.0 : col[r];
-                Es[r * 17 + c] = v;
-                if (r > c) Hs[(j0 + r) * kCiLd + j0 + c] = v;
-                if (r == c) ed[j0 + c] = v;
-            }
-        }
+        if (!(ablate & 1)) chol_leaf16<debug>(Hs, Es, ed, rd, refd, 16 * J, lane, lstamp);
     };
     // (c) one 16 x 16 tile of the trailing update of block step J on the matrix pipe: X[r][c] -= sum_t R[j0 + t][r] rowJ[t][c]
     // for the columns of the identity half (c < j1) and of the upper triangle (c >= r).  rowJ of the block's own columns
@@ -284,7 +338,7 @@ __global__ __launch_bounds__(1024) void chol_inv_kernel(const double *__restrict
     auto trail_tile = [&](int J, int tr, int tc, const double *EsJ) {
         const int j0 = 16 * J, j1 = j0 + 16;
         const int r0 = j1 + 16 * tr, c0 = 16 * tc;
-        if (c0 >= j1 && c0 < r0) return;                          // strictly below the diagonal: still zero
+        if ((c0 >= j1 && c0 < r0) || (ablate & 2)) return;        // strictly below the diagonal: still zero
         const bool inJ = (c0 == j0);
         d4_t acc;
 #pragma unroll
@@ -324,7 +378,7 @@ __global__ __launch_bounds__(1024) void chol_inv_kernel(const double *__restrict
         const int ntile_p = nblk - 1;
         d4_t pacc = {0.0, 0.0, 0.0, 0.0};
         const int pc0 = 16 * (wave < J ? wave : wave + 1);
-        if (wave < ntile_p) {
+        if (wave < ntile_p && !(ablate & 4)) {
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
                 const int k = 4 * lg + m;
@@ -334,7 +388,15 @@ __global__ __launch_bounds__(1024) void chol_inv_kernel(const double *__restrict
             }
         }
         if (tid < 16 * 17) EsPrev[tid] = Es[tid];
-        __syncthreads();
+        if (tid < 256) {
+            // R_JJ^-T into its final place: the block's strictly lower triangle and the separate diagonal
+            const int r = tid >> 4, c = tid & 15;
+            const double v = Es[r * 17 + c];
+            if (r > c) Hs[(j0 + r) * kCiLd + j0 + c] = v;
+            if (r == c) ed[j0 + c] = v;
+        }
+        // (no barrier between the products and these stores: a wave only reads the rows-J cells of ITS column tile - and Es,
+        //  which nobody writes in this phase - and overwrites exactly those cells; the data dependence orders it)
         if (wave < ntile_p) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) Hs[(j0 + lg + 4 * r) * kCiLd + pc0 + li] = pacc[r];
@@ -354,7 +416,7 @@ __global__ __launch_bounds__(1024) void chol_inv_kernel(const double *__restrict
                 trail_tile(J, 0, J + 1, EsPrev);          // the next diagonal tile first ...
                 leaf(J + 1);                              // ... then its 16 pivots (one wave: LDS accesses of a wave are ordered)
             } else {
-                for (int tile = wave - 1; tile < ntiles; tile += 15) {
+                for (int tile = wave - 1; tile < ntiles; tile += 7) {
                     const int tr = tile / nblk, tc = tile - tr * nblk;
                     if (tr == 0 && tc == J + 1) continue;             // wave 0's tile
                     trail_tile(J, tr, tc, EsPrev);
@@ -373,20 +435,22 @@ __global__ __launch_bounds__(1024) void chol_inv_kernel(const double *__restrict
     {
         const int j = tid & 127, i0 = tid >> 7;
 #pragma unroll 4
-        for (int q = 0; q < 16; ++q) {
-            const int i = i0 + 8 * q;
+        for (int q = 0; q < 32; ++q) {
+            const int i = i0 + 4 * q;
             if (i < p && j < p) Rinv[(int64_t)i * ldr + j] = (i < j) ? Hs[j * kCiLd + i] : (i == j ? ed[i] : 0.0);
         }
     }
     if (tid < p) rdiag[tid] = rd[tid];
     if (debug && tid == 0)
-        printf("[chol_inv p=%d] load %lld clk, first leaf %lld, panels %lld, trailing + next leaf %lld; total %lld clk\n", p,
-               dbg_load, dbg_leaf, dbg_panel, dbg_trail, (long long)clock64() - dbg_c0);
+        printf("[chol_inv p=%d] load %lld clk, first leaf %lld, panels %lld, trailing + next leaf %lld; total %lld clk; last leaf: "
+               "fetch %lld, pivots %lld, store %lld\n", p, dbg_load, dbg_leaf, dbg_panel, dbg_trail, (long long)clock64() - dbg_c0,
+               lstamp[1] - lstamp[0], lstamp[2] - lstamp[1], lstamp[3] - lstamp[2]);
 }
 
 int chol_inv_prepare() {
-    static LdsOptIn once;
-    return lds_opt_in(once, reinterpret_cast<const void *>(chol_inv_kernel), kCiLdsBytes);
+    static LdsOptIn once, once_dbg;
+    const int rc = lds_opt_in(once, reinterpret_cast<const void *>(chol_inv_kernel<false>), kCiLdsBytes);
+    return rc != GS_OK ? rc : lds_opt_in(once_dbg, reinterpret_cast<const void *>(chol_inv_kernel<true>), kCiLdsBytes);
 }
 
 int chol_inv_launch(const double *H, int64_t ldh, int p, double *Rinv, int64_t ldr, double *rdiag, hipStream_t stream) {
@@ -396,7 +460,11 @@ int chol_inv_launch(const double *H, int64_t ldh, int p, double *Rinv, int64_t l
         if (rcp != GS_OK) return rcp;
     }
     static const int debug = gs_knob("GS_TOPK_DEBUG") ? 1 : 0;
-    GS_LAUNCH(chol_inv_kernel, dim3(1), dim3(1024), kCiLdsBytes, stream, H, ldh, p, Rinv, ldr, rdiag, debug);
+    static const int ablate = gs_knob("GS_CHOL_ABLATE") ? atoi(gs_knob("GS_CHOL_ABLATE")) : 0;
+    if (debug)
+        GS_LAUNCH(chol_inv_kernel<true>, dim3(1), dim3(512), kCiLdsBytes, stream, H, ldh, p, Rinv, ldr, rdiag, ablate);
+    else
+        GS_LAUNCH(chol_inv_kernel<false>, dim3(1), dim3(512), kCiLdsBytes, stream, H, ldh, p, Rinv, ldr, rdiag, ablate);
     GS_HIP_CHECK(hipGetLastError());
     return GS_OK;
 }

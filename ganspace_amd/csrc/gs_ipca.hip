@@ -77,6 +77,14 @@ struct gs_ipca {
     // (invsub_begin / invsub_finish): the next call - whatever it is - resolves it first (faithful_resolve)
     bool inv_pending = false;
     bool inv_pending_warm = false;
+    // FAITHFUL: the Gram launch of a block runs on the caller's stream, everything that closes the block (statistics,
+    // assembly, subspace step) on `aux`, so that block t + 1's contraction - the one kernel that fills the chip - overlaps
+    // block t's chain of small dependent launches.  ev_gram: G64 / S1 of the block are final (caller's stream -> aux);
+    // ev_asm: the block is assembled and the next shift is in place (aux -> caller's stream: the next Gram launch may
+    // overwrite G64 / S1); ev_chain: end of what has been enqueued on aux (readers join through it).
+    hipEvent_t ev_gram = nullptr, ev_asm = nullptr, ev_chain = nullptr;
+    bool chain_live = false;     // aux holds work the caller's stream has not joined yet
+    bool asm_live = false;       // ev_asm has been recorded and not yet waited for
 };
 
 namespace {
@@ -470,11 +478,16 @@ void install_solver_epilogue(gs_ipca *h) {
 // FAITHFUL: read the verdict of the step the last update left in flight.  Accepted: the device has already written the
 // new (Vk, Bk).  Not accepted after the retries: the Rayleigh-Ritz solver runs on the assembled matrix, which is still
 // in h->W (nothing touches it before this call).
-int faithful_resolve(gs_ipca *h, hipStream_t stream) {
+// the stream a FAITHFUL handle closes its blocks on: its own (chain_stream != user) unless it has none
+hipStream_t chain_stream(gs_ipca *h, hipStream_t user) {
+    return (h->mode == GS_MODE_FAITHFUL && h->aux != nullptr && h->ev_chain != nullptr) ? h->aux : user;
+}
+
+int faithful_resolve_on(gs_ipca *h, hipStream_t cs) {
     if (!h->inv_pending) return GS_OK;
     h->inv_pending = false;
     int mults = 0, converged = 0;
-    int rc = invsub_finish(h->sws, stream, &mults, &converged);
+    int rc = invsub_finish(h->sws, cs, &mults, &converged);
     if (rc != GS_OK) return rc;
     if (converged) {
         h->pending_diag = true;
@@ -483,7 +496,21 @@ int faithful_resolve(gs_ipca *h, hipStream_t stream) {
         h->sws.guards_valid = false;   // the Rayleigh-Ritz solver's guard columns belong to an older matrix
         return GS_OK;
     }
-    return solve_topk(h, h->inv_pending_warm, h->m2, (int)h->d, stream);
+    return solve_topk(h, h->inv_pending_warm, h->m2, (int)h->d, cs);
+}
+
+// Everything but gs_ipca_update: finish what is in flight on the handle's own stream and order `user` behind it
+int faithful_resolve(gs_ipca *h, hipStream_t user) {
+    hipStream_t cs = chain_stream(h, user);
+    int rc = faithful_resolve_on(h, cs);
+    if (rc != GS_OK) return rc;
+    if (cs != user && h->chain_live) {
+        GS_HIP_CHECK(hipEventRecord(h->ev_chain, cs));
+        GS_HIP_CHECK(hipStreamWaitEvent(user, h->ev_chain, 0));
+        h->chain_live = false;
+        h->asm_live = false;           // (ev_chain lies behind ev_asm on the same stream)
+    }
+    return GS_OK;
 }
 
 // FAITHFUL with the diagonalisation deferred: (Vk, Bk) -> eigenpairs of Bk rotate the basis into the components
@@ -725,7 +752,10 @@ int gs_ipca_create(int64_t d, int k, int mode, int precision, int device, gs_ipc
     h->n2 = (int)d;
     if (hipStreamCreateWithFlags(&h->aux, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_in, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&h->ev_out, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&h->ev_out, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_gram, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_asm, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_chain, hipEventDisableTiming) != hipSuccess) {
         (void)hipGetLastError();          // no private stream: calls on the null stream simply run without graphs
         if (h->aux) (void)hipStreamDestroy(h->aux);
         h->aux = nullptr;
@@ -801,7 +831,7 @@ int gs_ipca_create(int64_t d, int k, int mode, int precision, int device, gs_ipc
 int gs_ipca_destroy(gs_ipca_t *h) {
     if (!h) return GS_OK;
     (void)hipSetDevice(h->device);
-    if (h->inv_pending) (void)hipDeviceSynchronize();      // a subspace step in flight still uses the buffers freed below
+    if (h->inv_pending || h->chain_live) (void)hipDeviceSynchronize();   // work in flight still uses the buffers freed below
     gram_workspace_free(h->gws);
     eigh_workspace_free(h->ews);
     smallside_free(h->ss);
@@ -814,8 +844,8 @@ int gs_ipca_destroy(gs_ipca_t *h) {
         (void)hipStreamSynchronize(h->aux);
         (void)hipStreamDestroy(h->aux);
     }
-    if (h->ev_in) (void)hipEventDestroy(h->ev_in);
-    if (h->ev_out) (void)hipEventDestroy(h->ev_out);
+    for (hipEvent_t e : {h->ev_in, h->ev_out, h->ev_gram, h->ev_asm, h->ev_chain})
+        if (e) (void)hipEventDestroy(e);
     delete h;
     return GS_OK;
 }
@@ -825,9 +855,12 @@ int gs_ipca_reset(gs_ipca_t *h) {
     if (h->inv_pending) {
         // a subspace step in flight writes into Vk / Bk when it is accepted: let it finish, then forget it
         int mults = 0, converged = 0;
-        (void)invsub_finish(h->sws, nullptr, &mults, &converged);
+        (void)invsub_finish(h->sws, chain_stream(h, nullptr), &mults, &converged);
         h->inv_pending = false;
     }
+    if (h->aux && (h->chain_live || h->asm_live)) (void)hipStreamSynchronize(h->aux);
+    h->chain_live = false;
+    h->asm_live = false;
     h->n_seen = 0;
     h->blocks = 0;
     h->finalized = false;
@@ -913,10 +946,24 @@ int gs_ipca_update(gs_ipca_t *h, const float *X, int64_t rows, int64_t ld, void 
     // This block's Gram launch goes out BEFORE the host waits for the verdict of the previous block's subspace step: the
     // launch only needs the shift (final since the previous call) and its own accumulators, and the GPU has it to chew
     // on while the host reads the verdict and enqueues the next chain
-    int rc = gram_update(h->gws, X, rows, ld, d, h->shift, h->G64, h->S1, false, /*defer=*/false, stream);
+    // ... and runs on the CALLER's stream, while the chain that closes a block runs on the handle's own: block t + 1's
+    // contraction overlaps block t's small dependent launches (see gs_ipca::ev_gram / ev_asm).
+    hipStream_t user = stream;
+    hipStream_t cs = scope.forked ? stream : chain_stream(h, stream);
+    if (cs != user && h->asm_live) {
+        GS_HIP_CHECK(hipStreamWaitEvent(user, h->ev_asm, 0));      // G64 / S1 / shift are free again
+        h->asm_live = false;
+    }
+    int rc = gram_update(h->gws, X, rows, ld, d, h->shift, h->G64, h->S1, false, /*defer=*/false, user);
     if (rc != GS_OK) return rc;
-    rc = faithful_resolve(h, stream);
+    if (cs != user) {
+        GS_HIP_CHECK(hipEventRecord(h->ev_gram, user));
+        GS_HIP_CHECK(hipStreamWaitEvent(cs, h->ev_gram, 0));
+        h->chain_live = true;
+    }
+    rc = faithful_resolve_on(h, cs);
     if (rc != GS_OK) return rc;
+    stream = cs;
     const double n0 = (double)h->n_seen, m = (double)rows;
     hipLaunchKernelGGL(faithful_stats_kernel, dim3((unsigned)ceil_div(d, 256)), dim3(256), 0, stream, h->S1,
                        h->shift, h->mean, h->vec, d, dp, n0, m);
@@ -936,6 +983,10 @@ int gs_ipca_update(gs_ipca_t *h, const float *X, int64_t rows, int64_t ld, void 
     // the shift of the NEXT block's Gram launch (only needs the mean: ahead of the solver chain)
     hipLaunchKernelGGL(mean_to_shift_kernel, dim3((unsigned)ceil_div(dp, 256)), dim3(256), 0, stream, h->mean,
                        h->shift, d, dp);
+    if (cs != user) {
+        GS_HIP_CHECK(hipEventRecord(h->ev_asm, cs));
+        h->asm_live = true;
+    }
     if (!eager && h->sws.Q != nullptr && h->k <= 128 && n0 >= 4.0 * m) {
         // enqueue the step and return: the acceptance test and the emit run on the device, the verdict is read by the next
         // call on this handle (faithful_resolve), behind that call's Gram launch

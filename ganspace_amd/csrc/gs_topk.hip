@@ -891,12 +891,20 @@ int invsub_enqueue_attempt(SubspaceWorkspace &ws, hipStream_t stream) {
     st.loewdin = st.pass2 && e_est <= 1e-4;
     double *verdict = ws.theta + 3 * ws.pp + 16;
     auto segment = [&]() -> int {
+        // the start basis Q0 = rows of Vk is read in place by the first product (B(t, j) = Vk[j ldv + t]: the products
+        // take any element strides) - no transposing copy; only the identity start of the small side is written out
+        bool from_vk = false;
         if (st.attempt == 0) {
             int rcr = ring_reset(ws, stream);
             if (rcr != GS_OK) return rcr;
-            st.Qc = ring_take(ws, nullptr);
-            GS_LAUNCH(topk_seed_kernel, dim3((unsigned)ceil_div(k, 64), (unsigned)n), dim3(64), 0, stream, st.Qc, n, ld,
-                      st.identity_start ? (const double *)nullptr : st.Vk, k, st.ldv);
+            if (st.identity_start) {
+                st.Qc = ring_take(ws, nullptr);
+                GS_LAUNCH(topk_seed_kernel, dim3((unsigned)ceil_div(k, 64), (unsigned)n), dim3(64), 0, stream, st.Qc, n, ld,
+                          (const double *)nullptr, k, st.ldv);
+            } else {
+                st.Qc = nullptr;
+                from_vk = true;
+            }
         }
         int rem = P;
         while (rem > 0) {
@@ -905,7 +913,12 @@ int invsub_enqueue_attempt(SubspaceWorkspace &ws, hipStream_t stream) {
             for (int s2 = 0; s2 < jj; ++s2) {
                 bool clean = false;
                 double *nxt = ring_take(ws, &clean);
-                gemm_f64(n, k, n, st.A, st.lda, 1, cur, ld, 1, nxt, ld, stream, 1.0, 0.0, none, true, clean);
+                if (from_vk) {
+                    gemm_f64(n, k, n, st.A, st.lda, 1, st.Vk, 1, st.ldv, nxt, ld, stream, 1.0, 0.0, none, true, clean);
+                    from_vk = false;
+                } else {
+                    gemm_f64(n, k, n, st.A, st.lda, 1, cur, ld, 1, nxt, ld, stream, 1.0, 0.0, none, true, clean);
+                }
                 cur = nxt;
                 ++st.used;
             }
@@ -1081,6 +1094,7 @@ int invsub_iterate(SubspaceWorkspace &ws, const double *A, int n, int64_t lda, i
 }
 
 static double cheb_T(int m, double x) { return x <= 1.0 ? 1.0 : std::cosh((double)m * std::acosh(x)); }
+
 
 // Same contract as eigh_topk_subspace (gs_subspace.hip); requires subspace_dim(n, k) <= 128.
 int eigh_topk_cheb(SubspaceWorkspace &ws, const double *A, int n, int64_t lda, int k, const double *V0, int k0,

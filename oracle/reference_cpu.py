@@ -73,3 +73,39 @@ def host_threads():
     except Exception:
         pass
     return os.cpu_count() or 1
+
+
+def _wide_baseline_main(argv):
+    """``python -m oracle.reference_cpu <feat_dim> <k> <blocks> <blas_threads> <out.json> [out_components.npy]``
+
+    bench.py's wide-feature CPU baseline as a child process (it runs beside the GPU legs of the bench: ``blocks`` x
+    26 s at d = 131 072 would otherwise be most of the run): scikit-learn's ``IncrementalPCA.partial_fit`` - the
+    reference's arithmetic, ``/root/reference/estimators.py:68-76`` - on the CPU-seeded synthetic blocks of SURVEY.md 8d
+    item 5 (``oracle.smallside_torch.lowrank_plus_noise_blocks(device="cpu")``: the parent regenerates the same blocks
+    for the cosine check), seconds per block to ``out.json``."""
+    import json
+    import os
+    import torch
+    from oracle.smallside_torch import lowrank_plus_noise_blocks
+    d, k, nb, threads, out = int(argv[0]), int(argv[1]), int(argv[2]), int(argv[3]), argv[4]
+    torch.set_num_threads(max(1, min(threads, 16)))
+    sk = make_reference_ipca(k)
+    per = []
+    with blas_threads(threads):
+        for X in lowrank_plus_noise_blocks(d, nb, rows=2000, device="cpu"):
+            hb = X.numpy()
+            t0 = time.perf_counter()
+            sk.partial_fit(hb)
+            per.append(time.perf_counter() - t0)
+            with open(out + ".partial", "w") as f:           # (a parent that runs out of patience reads what is there)
+                json.dump({"seconds_per_block": per, "blas_threads": threads, "feat_dim": d, "done": False}, f)
+    if len(argv) > 5:
+        np.save(argv[5], sk.components_.astype(np.float32))
+    with open(out, "w") as f:
+        json.dump({"seconds_per_block": per, "blas_threads": threads, "feat_dim": d, "done": True,
+                   "host_cpu_count": os.cpu_count()}, f)
+
+
+if __name__ == "__main__":
+    import sys
+    _wide_baseline_main(sys.argv[1:])

@@ -86,3 +86,48 @@ def test_product_package_never_imports_the_oracle():
                                      flags=re.M), f
                 if f != "estimators.py":
                     assert "cpu_estimators" not in txt, f
+
+
+def test_hot_kernels_have_no_scratch_and_products_use_the_f64_matrix_pipe(lib):
+    """The build records every kernel's resources (``-Rpass-analysis=kernel-resource-usage`` ->
+    ``ganspace_amd/lib/kernel_usage.json``) and FAILS when a kernel on the no-scratch list spills: the LDS-DMA Gram kernel
+    counts its VMEM operations (``s_waitcnt vmcnt(N)``), so a scratch reload makes it wrong, not slow (round-3 finding).
+    Here: the record exists, covers the hot kernels, and none of them touches scratch."""
+    import json
+    from ganspace_amd import _build
+    path = os.path.join(os.path.dirname(_build.lib_path()), "kernel_usage.json")
+    if not os.path.exists(path):
+        _build.build(force=True)
+    usage = json.load(open(path))
+    hot = {k: u for k, u in usage.items() if _build.NO_SCRATCH.search(k)}
+    for needle in ("gram_f32_wide_kernel", "gram_bf16_glds_kernel", "gram_partial_kernel", "rowgram_kernel", "tn_gemm_kernel",
+                   "linear_act_fast_kernel", "mm64_kernel", "chol_inv_kernel"):
+        assert any(needle in k for k in hot), f"{needle} missing from the resource record"
+    for k, u in hot.items():
+        assert u.get("scratch", 0) == 0 and u.get("vgpr_spill", 0) == 0, (k, u)
+    # the guard itself: a spilling kernel on the list must fail the build
+    remarks = ("x.hip:1:1: remark: Function Name: _ZN2gs11mm64_kernelILb1ELi32EEEv [-Rpass-analysis=kernel-resource-usage]\n"
+               "x.hip:1:1: remark:     VGPRs: 128 [-Rpass-analysis=kernel-resource-usage]\n"
+               "x.hip:1:1: remark:     ScratchSize [bytes/lane]: 24 [-Rpass-analysis=kernel-resource-usage]\n"
+               "x.hip:1:1: remark:     VGPRs Spill: 6 [-Rpass-analysis=kernel-resource-usage]\n")
+    parsed = _build._kernel_usage(remarks)
+    (name, u), = parsed.items()
+    assert _build.NO_SCRATCH.search(name) and u["scratch"] == 24 and u["vgpr_spill"] == 6
+
+
+def test_measurement_switches_are_compiled_out_of_the_production_library():
+    """The A/B switches of the kernels (``gs_knob`` in csrc/gs_common.h) read the environment only in the side-by-side
+    measurement build (``-DGS_MEASURE_BUILD`` -> ``ganspace_amd/lib_measure/``): no ``getenv`` of a ``GS_*`` switch is left
+    in the sources outside that macro."""
+    csrc = os.path.join(ROOT, "ganspace_amd", "csrc")
+    offenders = []
+    for f in sorted(os.listdir(csrc)):
+        txt = open(os.path.join(csrc, f)).read()
+        for m in re.finditer(r"\bgetenv\(\"(GS_[A-Z0-9_]+)\"\)", txt):
+            # gs_common.h defines gs_knob itself; GS_GRAM_ABLATE sits behind its own -DGS_GRAM_ABLATE_BUILD
+            if f == "gs_common.h" or m.group(1) == "GS_GRAM_ABLATE":
+                continue
+            offenders.append((f, m.group(1)))
+    assert not offenders, offenders
+    common = open(os.path.join(csrc, "gs_common.h")).read()
+    assert "#ifdef GS_MEASURE_BUILD" in common and "inline const char *gs_knob(const char *) { return nullptr; }" in common

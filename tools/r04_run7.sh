@@ -1,0 +1,23 @@
+#!/bin/bash
+set -u
+R=$GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp && cd "$R"
+O=gpurun_out/r04g; mkdir -p $O
+M=$R/ganspace_amd/lib_measure/libganspace_hip.so
+GANSPACE_HIP_LIB=$M GS_TOPK_DEBUG=1 timeout 300 python tools/finalize_trace.py 10 2 exact 2>&1 | grep "chol_inv\|jacobi" | head -3
+GANSPACE_HIP_LIB=$M GS_TOPK_DEBUG=1 GS_JACOBI_LP=8 timeout 300 python tools/finalize_trace.py 10 2 exact 2>&1 | grep "jacobi\|exact fin" | head -4
+timeout 300 python tools/finalize_trace.py 100 3 both > $O/finalize.log 2>&1; grep "exact fin\|faithful" $O/finalize.log | cut -c1-200
+timeout 600 python -m pytest tests/test_gpu_topk.py tests/test_gpu_collective_shim.py -x -q > $O/t1.log 2>&1; echo "rc=$?"; grep -E "passed|failed|error|Error" $O/t1.log | tail -5
+( time timeout 1200 python bench.py > $O/bench.json 2> $O/bench.err ) 2>&1 | grep real; echo "bench rc=$?"
+python - <<'PY'
+import json
+d=json.load(open("gpurun_out/r04g/bench.json"))
+print("value",d["value"],"ms/step",d["ms_per_step"],"roofline frac",d["roofline"]["frac"],d["roofline"].get("in_job_avg_launch_us"))
+print("breakdown",d["breakdown"])
+for k in ("faithful_mode_same_job",):
+    print(k, json.dumps(d.get(k))[:600])
+e=d.get("end_to_end_cfg3_cfg5",{})
+for k,v in e.items(): print(k, json.dumps(v)[:1400])
+for k,v in d.get("wide_feature_shapes",{}).items():
+    print(k, v.get("ms_per_block"), v["bf16x6"]["ms_per_block"], json.dumps(v.get("cpu_baseline"))[:500], json.dumps(v.get("vs_sklearn_at_reduced_n")))
+PY
