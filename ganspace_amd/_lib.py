@@ -59,6 +59,7 @@ SIGNATURES = {
     "gs_eigh_topk": (_int, [_vp, _int, _int, _vp, _int, _vp, _vp, _vp, _vp]),
     "gs_cholqr": (_int, [_vp, _int, _int, _vp, _vp, _vp]),
     "gs_jacobi_small": (_int, [_vp, _int, _vp, _vp, _vp, _vp]),
+    "gs_eig_tridiag": (_int, [_vp, _int, _vp, _vp, _vp, _vp]),
     "gs_gemm_f64": (_int, [_int, _int, _int, _vp, _i64, _i64, _vp, _i64, _i64, _vp, _i64, C.c_double, C.c_double, _vp, _vp,
                             _vp, _vp]),
     "gs_mapping_forward": (_int, [_vp, _vp, _vp, _vp, _vp, _int, _int, _f32, _f32, _f32, _f32, _int, _i64, _vp]),

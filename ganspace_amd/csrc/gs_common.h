@@ -267,6 +267,10 @@ struct SubspaceWorkspace {
     InvsubPending inv;
     double *inv_host = nullptr;    // [8] pinned: verdict of the attempt in flight (invsub_judge_kernel)
     hipEvent_t inv_event = nullptr;
+    // projection step of eigh_topk_cheb: tridiagonalisation + bisection (gs_tridiag.hip) unless that solver reported
+    // clustered Ritz values on this workspace - then one-sided Jacobi from there on
+    double *td_scratch = nullptr;  // [(128 + 3) * 128] reflectors, diagonal, off-diagonal, taus
+    bool rr_force_jacobi = false;
     int warm_mults = 0;            // products the last converged warm-started solve used (schedule hint)
     // gs_topk.hip: filter schedule of the last converged warm-started solve (reused without a host round trip)
     bool plan_valid = false;
@@ -333,6 +337,11 @@ int chol_blocked_launch(const double *H, int64_t ldh, int p, double *Rm, int64_t
 int jacobi_small_launch(const double *B, int64_t ldb, int p, double *U, int64_t ldu, double *theta, int *info,
                         hipStream_t stream);
 int orth_fast(SubspaceWorkspace &ws, const double *Y, double *Qout, int n, int p, hipStream_t stream);
+//   tridiag_eig:   same contract as jacobi_small by Householder tridiagonalisation, bisection and twisted factorisations
+//                  (gs_tridiag.hip; p % 4 == 0); info = {1, status}: status 2 = clustered eigenvalues (use jacobi_small),
+//                  4 = non-finite.  scratch: (128 + 3) * 128 doubles.
+int tridiag_eig_launch(const double *B, int64_t ldb, int p, double *U, int64_t ldu, double *theta, int *info,
+                       double *scratch, hipStream_t stream);
 // legacy multi-launch CholeskyQR for 128 < p <= 256 columns (gs_subspace.hip): chol_factor_blocked factors ws.H
 // (p x p, leading dim ws.pp) into ws.Rm / ws.Dinv; cholqr_blocked = Gram GEMM + factor + row-parallel solve
 int chol_factor_blocked(SubspaceWorkspace &ws, int p, hipStream_t stream);

@@ -799,7 +799,12 @@ int gs_ipca_create(int64_t d, int k, int mode, int precision, int device, gs_ipc
     // ... and at d <= 1024 a product costs ~7 us while every orthonormalisation and the Rayleigh-Ritz Jacobi grow with
     // p^2 / p^3: 16 guards (42 products at p = 96) beat 48 (18 products at p = 128) on the cold exact solve of cfg2,
     // 1.73 vs 1.88 ms (profiles/r03_graphs_vs_streams.md)
-    h->sws.guards = (mode == GS_MODE_FAITHFUL || d <= 1024) ? 16 : 0;
+    // Round 4: the projection step is tridiagonalisation + bisection (gs_tridiag.hip), whose cost grows like p^2 per
+    // Householder step instead of the Jacobi kernel's 5 sweeps x p rounds, products and CholeskyQR steps cost a third less:
+    // for the cold exact solve the default 48 guards (p = 128, 18 products, 6 orthonormalisations) now beat 16 guards
+    // (p = 96, 42 products, 10 orthonormalisations), 1.23 vs 1.49 ms.  The faithful recurrence keeps 16 (its warm solves
+    // see a cliff right behind lambda_k).
+    h->sws.guards = (mode == GS_MODE_FAITHFUL) ? 16 : 0;
     h->dp = h->gws.dp;
     const int64_t dp = h->dp;
     alloc((void **)&h->shift, sizeof(float) * dp);
@@ -1321,6 +1326,30 @@ int gs_jacobi_small(const double *B, int p, double *U, double *theta, int *info_
     if (rc == GS_OK && hipMemcpyAsync(host, info, sizeof(int) * 2, hipMemcpyDeviceToHost, stream) != hipSuccess) rc = GS_EHIP;
     if (hipStreamSynchronize(stream) != hipSuccess) rc = GS_EHIP;
     (void)hipFree(info);
+    if (info_host) {
+        info_host[0] = host[0];
+        info_host[1] = host[1];
+    }
+    return rc;
+}
+
+int gs_eig_tridiag(const double *B, int p, double *U, double *theta, int *info_host, void *stream_) {
+    GS_REQUIRE(B && U && theta, GS_EINVAL, "gs_eig_tridiag: NULL argument");
+    hipStream_t stream = (hipStream_t)stream_;
+    int *info = nullptr;
+    double *scratch = nullptr;
+    GS_HIP_CHECK(hipMalloc(&info, sizeof(int) * 2));
+    if (hipMalloc(&scratch, sizeof(double) * (128 + 3) * 128) != hipSuccess) {
+        (void)hipFree(info);
+        set_error("gs_eig_tridiag: hipMalloc failed");
+        return GS_ENOMEM;
+    }
+    int rc = tridiag_eig_launch(B, p, p, U, p, theta, info, scratch, stream);
+    int host[2] = {0, 0};
+    if (rc == GS_OK && hipMemcpyAsync(host, info, sizeof(int) * 2, hipMemcpyDeviceToHost, stream) != hipSuccess) rc = GS_EHIP;
+    if (hipStreamSynchronize(stream) != hipSuccess) rc = GS_EHIP;
+    (void)hipFree(info);
+    (void)hipFree(scratch);
     if (info_host) {
         info_host[0] = host[0];
         info_host[1] = host[1];

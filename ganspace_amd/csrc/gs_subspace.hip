@@ -500,6 +500,7 @@ int subspace_workspace_alloc(SubspaceWorkspace &ws, int n, int p) {
     if (rc == GS_OK) rc = alloc(&ws.theta, 3 * (size_t)ws.pp + 32);
     if (rc == GS_OK) rc = alloc(&ws.Rm, ppp);
     if (rc == GS_OK) rc = alloc(&ws.Dinv, (size_t)(ws.pp / 16 + 1) * kCB * kCB);
+    if (rc == GS_OK) rc = alloc(&ws.td_scratch, (size_t)(128 + 3) * 128);
     if (rc == GS_OK && hipMemset(ws.Rm, 0, sizeof(double) * ppp) != hipSuccess) rc = GS_EHIP;
     if (rc == GS_OK) rc = eigh_workspace_alloc(ws.ews, ws.pp + 2);
     if (rc == GS_OK) rc = topk_prepare_kernels();
@@ -516,7 +517,7 @@ void subspace_workspace_free(SubspaceWorkspace &ws) {
     graph_cache_free(ws.graphs);
     if (ws.inv_host) (void)hipHostFree(ws.inv_host);
     if (ws.inv_event) (void)hipEventDestroy(ws.inv_event);
-    double *ptrs[] = {ws.pool, ws.G, ws.H, ws.B, ws.U, ws.theta, ws.Rm, ws.Dinv};
+    double *ptrs[] = {ws.pool, ws.G, ws.H, ws.B, ws.U, ws.theta, ws.Rm, ws.Dinv, ws.td_scratch};
     for (double *p : ptrs)
         if (p) (void)hipFree(p);
     eigh_workspace_free(ws.ews);

@@ -1262,7 +1262,12 @@ int eigh_topk_cheb(SubspaceWorkspace &ws, const double *A, int n, int64_t lda, i
             double *Bm = hring_take(ws, &cleanb);
             gemm_f64(n, p, n, A, lda, 1, Qc, ld, 1, Yb, ld, stream, 1.0, 0.0, none, true, cleany);   // Y = A Q
             gemm_f64(p, p, n, Qc, 1, ld, Yb, ld, 1, Bm, ld, stream, 1.0, 0.0, none, true, cleanb);   // B = Q^T Y
-            int rcj = jacobi_small_launch(Bm, ld, p, ws.U, ld, ws.theta, jinfo, stream);
+            // the p x p projected problem: tridiagonalisation + bisection + twisted factorisations (gs_tridiag.hip, ~90 us)
+            // instead of one-sided Jacobi (380 us at p = 96); clustered Ritz values send this workspace back to Jacobi
+            static const bool rr_jacobi = gs_knob("GS_RR_JACOBI") != nullptr;
+            const bool use_td = !rr_jacobi && !ws.rr_force_jacobi && ws.td_scratch != nullptr && (p % 4) == 0;
+            int rcj = use_td ? tridiag_eig_launch(Bm, ld, p, ws.U, ld, ws.theta, jinfo, ws.td_scratch, stream)
+                             : jacobi_small_launch(Bm, ld, p, ws.U, ld, ws.theta, jinfo, stream);
             if (rcj != GS_OK) return rcj;
             gemm_f64(n, p, p, Qc, ld, 1, ws.U, ld, 1, Zb, ld, stream, 1.0, 0.0, none, false);    // Z = Q U
             gemm_f64(n, k, p, Yb, ld, 1, ws.U, ld, 1, Wb, ld, stream, 1.0, 0.0, none, false);    // (A Q) U_k
@@ -1280,7 +1285,8 @@ int eigh_topk_cheb(SubspaceWorkspace &ws, const double *A, int n, int64_t lda, i
         };
         const int rcb = run_as_graph(ws.graphs, graph_key({2, deg, ncyc, n, p, k, ws.ring_next, ws.h_next, lda, ldv,
                                                            (int64_t)(intptr_t)A, (int64_t)(intptr_t)Vk,
-                                                           (int64_t)(intptr_t)Qc, ws.epilogue ? 1 : 0}), stream, segment_b);
+                                                           (int64_t)(intptr_t)Qc, ws.epilogue ? 1 : 0,
+                                                           ws.rr_force_jacobi ? 1 : 0}), stream, segment_b);
         if (rcb != GS_OK) return rcb;
         GS_HIP_CHECK(hipMemcpyAsync(host.data(), ws.theta + ws.pp, sizeof(double) * k, hipMemcpyDeviceToHost, stream));
         GS_HIP_CHECK(hipMemcpyAsync(host.data() + k, ws.theta, sizeof(double), hipMemcpyDeviceToHost, stream));
@@ -1295,6 +1301,7 @@ int eigh_topk_cheb(SubspaceWorkspace &ws, const double *A, int n, int64_t lda, i
         }
         const double th1 = host[k];
         ws.last_rr_sweeps = jhost[0];
+        if (jhost[1] & 6) ws.rr_force_jacobi = true;      // tridiag_eig: clustered / non-finite -> Jacobi for the retries
         const bool ok = finite && th1 > 0.0 && jhost[1] == 0 && worst <= tol2 * th1 * th1;
         if (ok) {
             *converged = 1;

@@ -163,3 +163,20 @@ def gemm_f64(A, B, alpha=1.0, beta=0.0, C=None, coef=None, E1=None, E2=None):
                                C.stride(0), float(alpha), float(beta), _p(coef), _p(E1), _p(E2),
                                _lib.current_stream_ptr()))
     return C
+
+
+def eig_tridiag(B):
+    """Eigen-decomposition of a symmetric ``p x p`` float64 matrix (p % 4 == 0, 8 <= p <= 128) by tridiagonalisation +
+    bisection + twisted factorisations: ``(theta [p] descending, U [p, p] eigenvectors as columns, status)`` with status
+    0 = fine, 2 = clustered eigenvalues (use ``jacobi_small``), 4 = non-finite."""
+    import torch
+    lib = _lib.load()
+    _need_cuda(B)
+    assert B.dtype == torch.float64 and B.dim() == 2 and B.shape[0] == B.shape[1]
+    B = B.contiguous()
+    p = B.shape[0]
+    U = torch.empty_like(B)
+    theta = torch.empty(p, dtype=torch.float64, device=B.device)
+    info = (C.c_int * 2)()
+    _lib.check(lib.gs_eig_tridiag(_p(B), p, _p(U), _p(theta), C.cast(info, C.c_void_p), _lib.current_stream_ptr()))
+    return theta, U, info[1]

@@ -219,6 +219,11 @@ int gs_eigh_topk(const double *A, int n, int k, const double *V0, int k0, double
  *                  info_host (2 ints) = {sweeps, 1 if the sweep limit was hit}.                                       */
 int gs_cholqr(const double *Y, int n, int p, double *Q, double *rdiag, void *stream);
 int gs_jacobi_small(const double *B, int p, double *U, double *theta, int *info_host, void *stream);
+/* gs_eig_tridiag:  the same problem as gs_jacobi_small (p % 4 == 0, 8 <= p <= 128) by Householder tridiagonalisation,
+ *                  bisection and twisted-factorisation eigenvectors (csrc/gs_tridiag.hip) - what the projection step of
+ *                  gs_eigh_topk runs; info_host = {1, status}: status 2 = eigenvalues closer than 1e-6 ||B|| (such problems
+ *                  go to gs_jacobi_small), 4 = non-finite input.                                                        */
+int gs_eig_tridiag(const double *B, int p, double *U, double *theta, int *info_host, void *stream);
 /* gs_gemm_f64:     the float64 product of those chains on the f64 matrix pipe (v_mfma_f64_16x16x4_f64; csrc/gs_dense64.hip):
  *                  C [M*N] (row-major, ldc) = alpha sum_t A(i,t) B(t,j) + beta C with A(i,t) = A[i*a_i + t*a_t],
  *                  B(t,j) = B[t*b_t + j*b_j] - any element strides, so transposed operands need no copy.  coef (3 doubles
