@@ -778,8 +778,8 @@ def test_plain_bf16_contraction_at_the_benchmarked_launch_size(dev, rows):
 
 def test_second_stream_fold_equals_in_launch_fold(tmp_path):
     """Wide launches (d = 512, >= 20 000 rows) fold their float32 slabs into the float64 accumulators on a second stream
-    while the next launch computes (``gram_fold_light_kernel``, ordered by events); ``GS_GRAM_NO_AUX_FOLD=1`` keeps the
-    folds on the spare workgroups of the next launch.  Same slabs, same float64 additions per element: faithful and
+    while the next launch computes (``gram_fold_light_kernel``, ordered by events); ``GS_GRAM_NO_AUX_FOLD=1`` (measurement build)
+    keeps the folds on the spare workgroups of the next launch.  Same slabs, same float64 additions per element: faithful and
     exact estimators on 30 000-row blocks agree to rounding (``tools/aux_fold_check.py``, one process per variant -
     the switch is read when the workspace is created)."""
     import os
@@ -787,9 +787,13 @@ def test_second_stream_fold_equals_in_launch_fold(tmp_path):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outs = []
-    for tag, extra in (("aux", {}), ("inline", {"GS_GRAM_NO_AUX_FOLD": "1"})):
+    # (round 4: the switch is compiled out of the production library - the in-launch variant runs on the measurement build,
+    #  ganspace_amd/lib_measure, same sources with -DGS_MEASURE_BUILD)
+    from ganspace_amd import _build
+    measure_lib = _build.build(measure=True, verbose=False)
+    for tag, extra in (("aux", {}), ("inline", {"GS_GRAM_NO_AUX_FOLD": "1", "GANSPACE_HIP_LIB": measure_lib})):
         path = str(tmp_path / f"{tag}.npy")
-        env = {k: v for k, v in os.environ.items() if k != "GS_GRAM_NO_AUX_FOLD"}
+        env = {k: v for k, v in os.environ.items() if k not in ("GS_GRAM_NO_AUX_FOLD", "GANSPACE_HIP_LIB")}
         env.update(extra)
         r = subprocess.run([sys.executable, os.path.join(root, "tools", "aux_fold_check.py"), path], cwd=root, env=env,
                            capture_output=True, text=True, timeout=300)
