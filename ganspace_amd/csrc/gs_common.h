@@ -164,6 +164,10 @@ struct GramWorkspace {
     // kernel on `aux` WHILE launch t + 1 computes (its waves fit next to the compute waves: no LDS, <= 48 VGPRs) -
     // spare workgroups of the compute kernel itself inherit its LDS / register footprint and only run once the
     // compute workgroups have retired (measured: +50-70 us per 131 072-row launch)
+    // The stream and its events are created at the first call that can use them (gram_update): a workspace that lives
+    // for one single-launch call (gs_gram_accumulate on a short matrix) never pays for them.
+    bool want_aux = false;                         // wide shape and not switched off: create `aux` on demand
+    bool persistent = false;                       // the workspace outlives a call (an IPCA handle): always worth it
     hipStream_t aux = nullptr;
     hipEvent_t ev_comp[2] = {nullptr, nullptr};    // slabs of set i are complete (recorded on the caller's stream)
     hipEvent_t ev_fold[2] = {nullptr, nullptr};    // slabs of set i are folded (recorded on aux)
@@ -179,7 +183,7 @@ struct GramWorkspace {
     mutable unsigned long long pace_epoch = 0;     // per workspace: its launches are ordered on its stream, its words are its own
 };
 
-int gram_workspace_alloc(GramWorkspace &ws, int64_t d);
+int gram_workspace_alloc(GramWorkspace &ws, int64_t d, bool persistent = false);
 void gram_workspace_free(GramWorkspace &ws);
 
 // Launch colsum+Gram partials for X[rows, ld] and fold them in float64 into

@@ -599,7 +599,16 @@ __global__ __launch_bounds__(256) void gram_fold_kernel(const float *__restrict_
     fold_elements(P, CS, G64, S1, dp, nchunks, T32, ntiles, accumulate, (int)blockIdx.x, (int)gridDim.x, 256);
 }
 
-int gram_workspace_alloc(GramWorkspace &ws, int64_t d) {
+static int aux_create(GramWorkspace &ws) {
+    GS_HIP_CHECK(hipStreamCreateWithFlags(&ws.aux, hipStreamNonBlocking));
+    for (int i = 0; i < 2; ++i) {
+        GS_HIP_CHECK(hipEventCreateWithFlags(&ws.ev_comp[i], hipEventDisableTiming));
+        GS_HIP_CHECK(hipEventCreateWithFlags(&ws.ev_fold[i], hipEventDisableTiming));
+    }
+    return GS_OK;
+}
+
+int gram_workspace_alloc(GramWorkspace &ws, int64_t d, bool persistent) {
     ws.dp = round_up(d, kMacroTile);
     const int64_t T = ws.dp / kMacroTile;
     const int64_t nmt = T * (T + 1) / 2;
@@ -613,12 +622,11 @@ int gram_workspace_alloc(GramWorkspace &ws, int64_t d) {
         GS_HIP_CHECK(hipMalloc(&ws.partial[i], sizeof(float) * ws.max_chunks * ws.dp * ws.dp));
         GS_HIP_CHECK(hipMalloc(&ws.colsum_partial[i], sizeof(float) * ws.max_chunks * ws.dp));
     }
-    if (ws.dp == 512 && gs_knob("GS_GRAM_NO_AUX_FOLD") == nullptr) {
-        GS_HIP_CHECK(hipStreamCreateWithFlags(&ws.aux, hipStreamNonBlocking));
-        for (int i = 0; i < 2; ++i) {
-            GS_HIP_CHECK(hipEventCreateWithFlags(&ws.ev_comp[i], hipEventDisableTiming));
-            GS_HIP_CHECK(hipEventCreateWithFlags(&ws.ev_fold[i], hipEventDisableTiming));
-        }
+    ws.want_aux = (ws.dp == 512 && gs_knob("GS_GRAM_NO_AUX_FOLD") == nullptr);
+    ws.persistent = persistent;
+    if (ws.want_aux && persistent) {               // (a handle: not inside its first update, which callers time)
+        const int rca = aux_create(ws);
+        if (rca != GS_OK) return rca;
     }
     GS_HIP_CHECK(hipMalloc(&ws.pace, sizeof(unsigned long long) * ws.max_chunks * nmt));
     GS_HIP_CHECK(hipMemset(ws.pace, 0, sizeof(unsigned long long) * ws.max_chunks * nmt));
@@ -912,6 +920,12 @@ int gram_update(GramWorkspace &ws, const float *X, int64_t rows, int64_t ld, int
     if (rows <= 0) return GS_OK;
     const bool al = (ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0);
     const int64_t rows_per_launch = gram_geometry(ws, rows, al).rows_per_launch;
+    // the second stream pays when a fold can hide behind a LATER compute launch: a handle (more calls follow: created
+    // with the workspace) or a one-shot call that splits into several launches (created here)
+    if (ws.want_aux && ws.aux == nullptr && rows > rows_per_launch) {
+        const int rca = aux_create(ws);
+        if (rca != GS_OK) return rca;
+    }
     bool acc = accumulate;
     for (int64_t base = 0; base < rows; base += rows_per_launch) {
         const int64_t n = (rows - base < rows_per_launch) ? rows - base : rows_per_launch;

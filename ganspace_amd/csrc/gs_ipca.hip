@@ -788,7 +788,7 @@ int gs_ipca_create(int64_t d, int k, int mode, int precision, int device, gs_ipc
         *out = h;
         return GS_OK;
     }
-    rc = gram_workspace_alloc(h->gws, d);
+    rc = gram_workspace_alloc(h->gws, d, /*persistent=*/true);
     h->gws.precision = precision;
     if (rc == GS_OK) rc = eigh_workspace_alloc(h->ews, (int)d + 2);
     if (rc == GS_OK && subspace_dim((int)d, k) > 0) rc = subspace_workspace_alloc(h->sws, (int)d, subspace_dim((int)d, k));

@@ -28,6 +28,8 @@
 // the identical test matrix.
 #include <vector>
 
+#include <utility>
+
 #include "gs_common.h"
 
 namespace gs {
@@ -343,15 +345,23 @@ extern "C" int gs_randomized_pca(const float *A, int64_t rows, int64_t d, int k,
         return rc;
     }
     const int64_t ld = ws.pp;
-    double *Z = ws.Y, *Q = ws.Q;                       // [d x ld] float64
+    double *Z = ws.Y, *Q = ws.Q;                       // [d x ld] float64 (orth_z swaps the two)
     const dim3 b256(256);
     auto a_times_q = [&]() -> int {                    // Y[rows x lp] = A Wt^T
         return gs_linear_forward(A, Wt, nullptr, Y, rows, (int)d, lp, stream);
     };
     auto at_times_y = [&]() -> int { return launch_tn_rows(A, d, d, Y, lp, l, rows, Z, ld, stream); };
-    auto orth_z = [&]() -> int {                       // Q = orth(Z), then its float32 transpose for the next product
+    // Q = orth(Z), then its float32 transpose for the next product.  CholeskyQR twice: one pass leaves
+    // ||Q^T Q - I|| ~ eps cond(Z)^2, and Z = A^T A Q has cond ~ (s_1 / s_l)^2 after a power step - a fast-decaying
+    // spectrum would lose the basis.  The second pass (on a basis whose conditioning is now ~1 + eps cond^2) restores
+    // orthogonality to rounding for cond(Z) up to ~1e8; beyond that, and for rank(A) < l, the pivots that die are zero
+    // columns of Q in both passes (chol_diag_kernel), i.e. the basis just has fewer vectors - what fbpca's pivoted LU /
+    // QR deliver there too.  Cost: one more l x l x d product and triangular solve, small beside a pass over A.
+    auto orth_z = [&]() -> int {
         int r2 = cholqr_blocked(ws, Z, Q, (int)d, l, stream);
+        if (r2 == GS_OK) r2 = cholqr_blocked(ws, Q, Z, (int)d, l, stream);
         if (r2 != GS_OK) return r2;
+        std::swap(Z, Q);
         hipLaunchKernelGGL(q_to_wt_kernel, dim3((unsigned)ceil_div(d, 256), (unsigned)lp), b256, 0, stream, Q, ld, d, l, lp, Wt);
         return GS_OK;
     };

@@ -58,6 +58,32 @@ def test_fbpca_estimator_matches_restatement_on_the_same_test_matrix(dev, n, d, 
     assert np.abs(gram - np.eye(k)).max() < 1e-5
 
 
+@pytest.mark.parametrize("n,d,k,latent,decay,noise", [
+    (5000, 400, 10, 15, 1.3, 0.0),        # rank(A) = 15 (+ float32 rounding) < l = 20: Cholesky pivots die
+    (6000, 200, 10, 40, 1.7, 0.02),       # s_1 / s_l ~ 2e3: cond(A^T A Q) ~ 4e6, one CholeskyQR pass loses ~1e-3
+    (300, 2000, 8, 10, 1.5, 0.0)])        # rows < feat_dim branch, rank 10 < l = 16
+def test_fbpca_low_rank_and_fast_decay(dev, n, d, k, latent, decay, noise):
+    """The float64 CholeskyQR of the range-finder bases (twice per orthonormalisation) against the restatement's
+    pivoted LU / QR where the iterate is rank deficient or badly conditioned."""
+    from ganspace_amd.estimators import get_estimator
+    X = _matrix(n, d, latent, seed=7 * n + d, decay=decay, noise=noise, offset=0.0)
+    X -= X.mean(axis=0, keepdims=True, dtype=np.float32)
+    est = get_estimator("fbpca", k, 1.0)
+    np.random.seed(11)
+    est.fit(torch.from_numpy(X).to(dev))
+    orc = fbpca_port.FacebookPCAEstimatorOracle(k)
+    np.random.seed(11)
+    orc.fit(X.astype(np.float64))
+    comp, stdev, _ = est.get_components()
+    ocomp, ostdev, _ = orc.get_components()
+    assert np.isfinite(comp).all() and np.isfinite(stdev).all()
+    acos = np.abs(np.sum(comp.astype(np.float64) * ocomp, axis=1))
+    assert acos.min() > 1 - 1e-5, acos
+    np.testing.assert_allclose(stdev, ostdev, rtol=5e-4)
+    gram = comp.astype(np.float64) @ comp.astype(np.float64).T
+    assert np.abs(gram - np.eye(k)).max() < 1e-5
+
+
 def test_fbpca_dense_fallback_for_small_matrices(dev):
     """fbpca hands matrices with l >= m / 1.25 or l >= n / 1.25 to a dense SVD (no randomness consumed)."""
     from ganspace_amd.estimators import get_estimator
