@@ -781,7 +781,8 @@ static void dump_trace(unsigned long long *trace_buf, int grid, hipStream_t stre
 }
 
 static void launch_partial(const GramWorkspace &ws, const GramGeom &g, int buf, const float *Xb, int64_t n,
-                           int64_t ld, int64_t d, const float *shift, const FoldJob &fold, hipStream_t stream) {
+                           int64_t ld, int64_t d, const float *shift, const FoldJob &fold, hipStream_t stream,
+                           hipEvent_t done = nullptr) {
     const bool vec = (ld % 4 == 0) && (d % 4 == 0) && ((reinterpret_cast<uintptr_t>(Xb) & 15) == 0);
     const int dp = (int)ws.dp;
     const int ablate = gram_ablate_mask();
@@ -817,7 +818,7 @@ static void launch_partial(const GramWorkspace &ws, const GramGeom &g, int buf, 
         //  those retire - a whole round of them, up to 128 slabs of 0.56 MB are waiting)
         if (ws.precision == GS_PREC_F32)
             (void)launch_gram_f32_wide(g.grid, fold.P != nullptr ? 256 : 0, Xb, n, ld, shift, ws.partial[buf],
-                                       ws.colsum_partial[buf], g.nchunks, g.plan, fj, stream);
+                                       ws.colsum_partial[buf], g.nchunks, g.plan, fj, stream, done);
         else
             (void)launch_gram_bf16_wide(ws.precision, g.grid, fold.P != nullptr ? 256 : 0, Xb, n, ld, shift, ws.partial[buf],
                                         ws.colsum_partial[buf], g.nchunks, g.plan, fj, stream);
@@ -944,11 +945,16 @@ int gram_update(GramWorkspace &ws, const float *X, int64_t rows, int64_t ld, int
                 GS_HIP_CHECK(hipStreamWaitEvent(stream, ws.ev_fold[buf], 0));
                 ws.aux_busy[buf] = false;
             }
+            // ev_comp rides on the kernel's own dispatch packet (hipExtLaunchKernel) instead of a marker packet behind it:
+            // one packet less between two compute launches (measured: -3 us per launch gap, profiles/r04_probes.md;
+            // measurement build: GS_GRAM_NO_EXT_EVENT restores the marker)
+            static const bool no_ext_event = gs_knob("GS_GRAM_NO_EXT_EVENT") != nullptr;
+            const bool ext = !no_ext_event && ws.precision == GS_PREC_F32 && !ws.profile;
             {
                 ProfScope prof(ws, stream, n);
-                launch_partial(ws, g, buf, X + base * ld, n, ld, d, shift, FoldJob{}, stream);
+                launch_partial(ws, g, buf, X + base * ld, n, ld, d, shift, FoldJob{}, stream, ext ? ws.ev_comp[buf] : nullptr);
             }
-            GS_HIP_CHECK(hipEventRecord(ws.ev_comp[buf], stream));
+            if (!ext) GS_HIP_CHECK(hipEventRecord(ws.ev_comp[buf], stream));
             GS_HIP_CHECK(hipStreamWaitEvent(ws.aux, ws.ev_comp[buf], 0));
             const int T32 = (int)ws.dp / kSubTile, ntiles = T32 * (T32 + 1) / 2;
             hipLaunchKernelGGL(gram_fold_light_kernel, dim3(256), dim3(256), 0, ws.aux, ws.partial[buf],

@@ -136,6 +136,6 @@ int launch_gram_bf16_wide(int precision, int grid, int nfold, const float *X, in
 
 // exact-f32 "wide" variant for d = 512 (gs_gram_wide.hip)
 int launch_gram_f32_wide(int grid, int nfold, const float *X, int64_t n, int64_t ld, const float *shift, float *P,
-                         float *CS, int nchunks, ChunkPlan plan, const FoldJob &fold, hipStream_t stream);
+                         float *CS, int nchunks, ChunkPlan plan, const FoldJob &fold, hipStream_t stream, hipEvent_t done = nullptr);
 
 }  // namespace gs

@@ -16,6 +16,8 @@
 #include <cstdlib>
 
 #include "gs_common.h"
+#include <hip/hip_ext.h>
+
 #include "gs_gram_internal.h"
 
 namespace gs {
@@ -253,7 +255,7 @@ __global__ __launch_bounds__(kFThreads, 1) void gram_f32_wide_kernel(
 }
 
 int launch_gram_f32_wide(int grid, int nfold, const float *X, int64_t n, int64_t ld, const float *shift, float *P,
-                         float *CS, int nchunks, ChunkPlan plan, const FoldJob &fold, hipStream_t stream) {
+                         float *CS, int nchunks, ChunkPlan plan, const FoldJob &fold, hipStream_t stream, hipEvent_t done) {
     const size_t lds_bytes = (size_t)2 * kFStageBytes;
     GS_REQUIRE(ld < ((int64_t)1 << 27) && ld % 4 == 0 && (reinterpret_cast<uintptr_t>(X) & 15) == 0, GS_EINVAL,
                "gram (wide): rows must be 16-byte aligned");
@@ -264,6 +266,12 @@ int launch_gram_f32_wide(int grid, int nfold, const float *X, int64_t n, int64_t
     }
     // measurement only (results wrong by design): GS_GRAM_ABLATE bit 0 no MFMA, bit 1 no LDS writes, bit 2 no loads
     const int ablate = gram_ablate_mask();
+    if (done != nullptr) {
+        // the completion signal of the dispatch packet itself is the event: no marker packet behind the kernel
+        hipExtLaunchKernelGGL(gram_f32_wide_kernel, dim3((unsigned)(grid + nfold)), dim3(kFThreads), (uint32_t)lds_bytes,
+                              stream, nullptr, done, 0u, X, n, ld, shift, P, CS, nchunks, plan, grid, fold, ablate);
+        return GS_OK;
+    }
     hipLaunchKernelGGL(gram_f32_wide_kernel, dim3((unsigned)(grid + nfold)), dim3(kFThreads), lds_bytes, stream, X, n, ld,
                        shift, P, CS, nchunks, plan, grid, fold, ablate);
     return GS_OK;

@@ -89,6 +89,8 @@ struct gs_ipca {
 
 namespace {
 
+constexpr int64_t kShiftRows = 8192;     // rows of the first block that seed the centring shift (EXACT)
+
 __device__ __forceinline__ double upper_get(const double *G, int dp, int i, int j) {
     // G holds the upper 32x32 sub-tiles (tile(i) <= tile(j)); inside a tile everything is valid
     return ((i >> 5) <= (j >> 5)) ? G[(int64_t)i * dp + j] : G[(int64_t)j * dp + i];
@@ -932,7 +934,10 @@ int gs_ipca_update(gs_ipca_t *h, const float *X, int64_t rows, int64_t ld, void 
         return GS_OK;
     }
     if (h->n_seen == 0) {
-        int rc = column_means_f32(X, rows, ld, d, dp, h->shift, h->vec, stream);
+        // EXACT: the shift only keeps the float32 products small (the mean is shift + S1 / n, exact for any shift) - the
+        // first kShiftRows rows estimate it as well as the whole block does, at a fraction of a pass over it
+        const int64_t srows = (h->mode == GS_MODE_EXACT && rows > kShiftRows) ? kShiftRows : rows;
+        int rc = column_means_f32(X, srows, ld, d, dp, h->shift, h->vec, stream);
         if (rc != GS_OK) return rc;
     }
     if (h->mode == GS_MODE_EXACT) {
@@ -1023,7 +1028,7 @@ int gs_ipca_update_resident(gs_ipca_t *h, const float *X, int64_t rows, int64_t 
         GS_REQUIRE(h->k <= rows, GS_EINVAL,
                    "n_components must be less or equal to the batch number of samples for the first "
                    "partial_fit call");
-        int rc = column_means_f32(X, rows, ld, d, dp, h->shift, h->vec, stream);
+        int rc = column_means_f32(X, rows > kShiftRows ? kShiftRows : rows, ld, d, dp, h->shift, h->vec, stream);
         if (rc != GS_OK) return rc;
     }
     if (h->res_rows > 0 && (ld != h->res_ld || X != h->res_ptr + h->res_rows * h->res_ld)) {

@@ -7,11 +7,11 @@
 // (sklearn/decomposition/_incremental_pca.py:362) via the projection step of eigh_topk_cheb; LAPACK itself solves this
 // problem the same way (dsytrd + dstebz / dstein-like vectors + dormtr).
 //
-//   tridiag_reduce_kernel   ONE workgroup, B in registers (row r in 4 lanes, 32 columns each): p - 2 Householder steps,
-//                           A <- H A H with H = I - tau v v^T, two barriers per step (row k and p = tau A v travel
-//                           through double-buffered LDS vectors, v^T p through an LDS float64 atomic).  The shrinking
-//                           trailing block is skipped in units of 4 columns.  Outputs: diagonal d, off-diagonal e, the
-//                           reflectors (rows of HV) and their tau.
+//   tridiag_reduce_kernel   ONE workgroup, B in registers (a 4 x 8 block per thread, interleaved rows and columns):
+//                           p - 2 Householder steps A <- H A H with H = I - tau v v^T, two barriers per step (v and
+//                           p = tau A v travel through LDS vectors, v^T p through an LDS float64 atomic).  The shrinking
+//                           trailing block is skipped in units of 16 columns / 32 rows.  Outputs: diagonal d,
+//                           off-diagonal e, the reflectors (rows of HV) and their tau.
 //   tridiag_eigvec_kernel   one WAVE per wanted eigenpair (p / 4 workgroups - the only part of a Rayleigh-Ritz step that
 //                           is not confined to one CU): (1) the eigenvalue by 65-section - 64 Sturm counts per iteration,
 //                           one per lane, 9 iterations to the last bit; (2) the eigenvector of T by a twisted
@@ -60,6 +60,18 @@ __device__ __forceinline__ double wave_sum(double v) {
     v = td_dpp_add<0x140>(v);  // row_mirror: every lane holds the sum of its 16-lane row
     return (td_readlane(v, 0) + td_readlane(v, 16)) + (td_readlane(v, 32) + td_readlane(v, 48));
 }
+// sum over the 64 lanes through the matrix core: D = A * ones sums A[i][k] over k - the four 16-lane groups - whatever the
+// row a lane's registers belong to; the four registers of a lane then cover a quarter of the rows, and a second product
+// sums the quarters.  Two dependent MFMAs and three adds (~120 clk) against four DPP stages and four readlanes (~280 clk,
+// tools/ubench/sclk_probe.hip): the back-transformation below is 126 of these in a row.
+typedef double td_f64x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ double wave_sum_mfma(double v) {
+    const td_f64x4 z = {0.0, 0.0, 0.0, 0.0};
+    const td_f64x4 c = __builtin_amdgcn_mfma_f64_16x16x4f64(v, 1.0, z, 0, 0, 0);
+    const double t = (c[0] + c[1]) + (c[2] + c[3]);
+    const td_f64x4 d = __builtin_amdgcn_mfma_f64_16x16x4f64(t, 1.0, z, 0, 0, 0);
+    return d[0];
+}
 // 1 / x to ~1e-16 relative: hardware seed + two Newton steps (no denormal / inf handling: callers keep |x| >= pivmin)
 __device__ __forceinline__ double td_rcp(double x) {
     double r = __builtin_amdgcn_rcp(x);
@@ -73,47 +85,77 @@ __device__ __forceinline__ double td_rcp(double x) {
 // ---------------------------------------------------------------------------------------------------------------
 // B (p x p symmetric, row-major, ld ldb) -> tridiagonal T = Q^T B Q:  dd[p], ee[p - 1] (ee[i] = T[i][i+1]), reflectors
 // HV[k][0..127] (v_k: zero up to column k, 1 at k + 1) and taus[k] for k < p - 2;  Q = H_0 H_1 ... H_{p-3}.
-// blockDim = 4 p (row r = tid / 4, lane q = tid % 4 holds columns q + 4 i, i < 32).
-__global__ __launch_bounds__(512) void tridiag_reduce_kernel(const double *__restrict__ B, int64_t ldb, int p,
-                                                              double *__restrict__ dd, double *__restrict__ ee,
-                                                              double *__restrict__ HV, double *__restrict__ taus) {
-    // Per step the whole workgroup does two things per matrix element - multiply-add into (A v)_r, and the rank-2 update -
-    // with v and q = p - K v read from LDS vectors that ONE wave prepares: no per-element selects, no redundant scalar
-    // arithmetic in 8 waves (a first version built v per thread from the published row: ~1000 instructions per thread
-    // and step, 9 000 clk per step).
-    __shared__ double xs[kTdMax];          // row k of the current matrix (published by its owners)
-    __shared__ double vv[kTdMax];          // Householder vector v (0 up to column k, 1 at k + 1)
-    __shared__ double ps[kTdMax];          // p = tau A v
-    __shared__ double sc[4];               // sigma | tau | (unused) | v^T p
-    const int tid = threadIdx.x, r = tid >> 2, q = tid & 3;
-    double a[32];
-#pragma unroll
-    for (int i = 0; i < 32; ++i) {
-        const int c = q + 4 * i;
-        a[i] = (r < p && c < p) ? B[(int64_t)r * ldb + c] : 0.0;
-    }
-    for (int e = tid; e < kTdMax; e += blockDim.x) {
-        ps[e] = 0.0;                       // (entries p .. 127 are read with the padded columns and never written)
-        vv[e] = 0.0;
-    }
-    __syncthreads();
-    for (int k = 0; k + 2 < p; ++k) {
-        const int i0 = (k + 1) >> 2;                 // first column group that reaches beyond column k
-        if (r == k) {
-            double s = 0.0;
-#pragma unroll
-            for (int i = 0; i < 32; ++i) {
-                const int c = q + 4 * i;
-                xs[c] = a[i];
-                if (c >= k + 2) s += a[i] * a[i];
-            }
-            s = sum4(s);
-            if (q == 0) sc[0] = s;
-        }
-        __syncthreads();                                          // (1) row k is published
-        if (tid < kTdMax) {
-            // two waves build v (and the scalars) from row k
-            const double alpha = xs[k + 1], sigma = sc[0];
+// blockDim = 512 whatever p is: group g = tid / 16 (32 groups, 4 per wave = one DPP row each) holds rows g + 32 t (t < 4),
+// lane j = tid % 16 of a group holds columns j + 16 i (i < 8): a 4 x 8 block of the (zero padded) 128 x 128 matrix per
+// thread, interleaved both ways so that every thread keeps work while the trailing block shrinks.
+//
+// Why blocks: per step every element takes one multiply-add into (A v)_r and two for the rank-2 update, and the vectors
+// they need (v, p) come from LDS.  With a thread holding 32 columns of ONE row (round 4's first version) that was 98 LDS
+// reads per thread and step - 3 000 clk of LDS bandwidth per step, 2.1 us per step measured; a 4 x 8 block needs 8 + 4
+// (v by column and by row) + 8 (p by column): 20 reads, and p_r comes out of a 16-lane DPP reduction in the registers
+// of the lanes that use it.  Two barriers per step instead of three: the wave that owns row k + 1 builds v for the next
+// step straight from its registers after its own update (no published row, no second pair of waves).
+namespace {
+
+// sum over the 16 lanes of a DPP row, result in all 16
+__device__ __forceinline__ double row16_sum(double v) {
+    v = sum4(v);
+    v = td_dpp_add<0x141>(v);  // row_half_mirror
+    v = td_dpp_add<0x140>(v);  // row_mirror
+    return v;
+}
+// the idx-th of eight values, idx uniform: conditional moves.  (Scalars, not an array: a select chain over the elements
+// of a local array is folded into an indexed access, and the array then lives in scratch or LDS.)
+__device__ __forceinline__ double pick8(double x0, double x1, double x2, double x3, double x4, double x5, double x6,
+                                        double x7, int idx) {
+    double v = x0;
+    v = (idx == 1) ? x1 : v;
+    v = (idx == 2) ? x2 : v;
+    v = (idx == 3) ? x3 : v;
+    v = (idx == 4) ? x4 : v;
+    v = (idx == 5) ? x5 : v;
+    v = (idx == 6) ? x6 : v;
+    v = (idx == 7) ? x7 : v;
+    return v;
+}
+
+}  // namespace
+
+namespace {
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() is a workgroup-scope release / acquire over ALL address
+// spaces: on gfx950 it waits for vmcnt(0), i.e. for the reflector / d / e stores the owner wave has just sent to global
+// memory - a round trip to L2 on the critical path of every step, for data nobody in this kernel reads back.
+__device__ __forceinline__ void td_lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+struct TdShared {
+    double vv[kTdMax];          // Householder vector v of the step (0 up to column k, 1 at k + 1)
+    double ps[kTdMax];          // p = tau A v
+    double tau[2];              // tau, by step parity
+    double vtp[2];              // v^T p (LDS float64 atomic, one add per wave), by step parity
+};
+
+// Steps k = 32 TK .. kend - 1: row k is rows[TK] of its owners - a compile-time position (a select over the four row
+// slots of `a` makes the compiler index the array, i.e. park it in scratch); row slots below TK are finished.
+template <int TK>
+__device__ __forceinline__ void td_steps(double (&a)[4][8], int kend, TdShared &sh, int wave, int gi, int j, int g, int lane,
+                                         double *__restrict__ dd, double *__restrict__ ee, double *__restrict__ HV,
+                                         double *__restrict__ taus) {
+    for (int k = 32 * TK; k < kend; ++k) {
+        const int par = k & 1;
+        // ---- (A) the wave that holds row k turns it into v (its update of the previous step is already in its registers)
+        if (wave == ((k & 31) >> 2)) {
+            const int og = k & 3;                          // row k = rows[TK] of group og of this wave
+            const double x0 = a[TK][0], x1 = a[TK][1], x2 = a[TK][2], x3 = a[TK][3], x4 = a[TK][4], x5 = a[TK][5],
+                         x6 = a[TK][6], x7 = a[TK][7];
+            auto sq = [&](double x, int i) { return (j + 16 * i >= k + 2) ? x * x : 0.0; };
+            double s = ((sq(x0, 0) + sq(x1, 1)) + (sq(x2, 2) + sq(x3, 3))) + ((sq(x4, 4) + sq(x5, 5)) + (sq(x6, 6) + sq(x7, 7)));
+            s = row16_sum(s);
+            const double sigma = td_readlane(s, 16 * og);
+            const double alpha = td_readlane(pick8(x0, x1, x2, x3, x4, x5, x6, x7, (k + 1) >> 4), 16 * og + ((k + 1) & 15));
+            const double dk = td_readlane(pick8(x0, x1, x2, x3, x4, x5, x6, x7, k >> 4), 16 * og + (k & 15));
             double tau = 0.0, beta = alpha, scal = 0.0;
             if (sigma > 0.0) {
                 const double n2 = alpha * alpha + sigma;
@@ -125,76 +167,109 @@ __global__ __launch_bounds__(512) void tridiag_reduce_kernel(const double *__res
                 tau = (beta - alpha) * td_rcp(beta);
                 scal = td_rcp(alpha - beta);
             }
-            const int c = tid;
-            const double vc = (c >= k + 2) ? xs[c] * scal : (c == k + 1 ? 1.0 : 0.0);
-            vv[c] = vc;
-            HV[(int64_t)k * kTdMax + c] = vc;
-            if (tid == 0) {
-                sc[1] = tau;
-                sc[3] = 0.0;
-                dd[k] = xs[k];
-                ee[k] = beta;
-                taus[k] = tau;
-            }
-        }
-        __syncthreads();                                          // (2) v is ready
-        const double tau = sc[1];
-        // (v and q are zero on the columns up to k, so finished columns need no test - a branch per column group would
-        //  serialise the LDS reads behind it: 7 700 clk per step; finished groups are skipped eight at a time)
-        double w0 = 0.0, w1 = 0.0;
-#pragma unroll
-        for (int ch = 0; ch < 4; ++ch) {
-            if (8 * ch + 7 >= i0) {
-#pragma unroll
-                for (int ii = 0; ii < 8; ii += 2) {
-                    w0 += a[8 * ch + ii] * vv[q + 4 * (8 * ch + ii)];
-                    w1 += a[8 * ch + ii + 1] * vv[q + 4 * (8 * ch + ii + 1)];
+            if (gi == og) {
+                auto put = [&](double x, int i) {
+                    const int c = j + 16 * i;
+                    const double vc = (c >= k + 2) ? x * scal : (c == k + 1 ? 1.0 : 0.0);
+                    sh.vv[c] = vc;
+                    HV[(int64_t)k * kTdMax + c] = vc;
+                };
+                put(x0, 0), put(x1, 1), put(x2, 2), put(x3, 3), put(x4, 4), put(x5, 5), put(x6, 6), put(x7, 7);
+                if (j == 0) {
+                    sh.tau[par] = tau;
+                    sh.vtp[par] = 0.0;     // (last read in the update of step k - 2: two barriers ago)
+                    dd[k] = dk;
+                    ee[k] = beta;
+                    taus[k] = tau;
                 }
             }
         }
-        double w = sum4(w0 + w1);
-        const double v_r = vv[r];
-        const double p_r = (r >= k + 1) ? tau * w : 0.0;
-        if (q == 0) ps[r] = p_r;
+        td_lds_barrier();                                          // (1) v, tau are published
+        // ---- (B) p = tau A v over the trailing block.  Row slots below TK and column groups below 2 TK are finished for
+        //      the whole slot and skipped at compile time; inside the slot nothing is skipped (v, and p, are zero on the
+        //      finished rows / columns in between, and a uniform branch per group costs ~30 clk taken or not -
+        //      tools/ubench/sclk_probe.hip - which is more than the multiply-adds it would save)
+        constexpr int I0 = 2 * TK;
+        const double tau = sh.tau[par];
+        double vc[8], vr[4];
+#pragma unroll
+        for (int i = I0; i < 8; ++i) vc[i] = sh.vv[j + 16 * i];
+#pragma unroll
+        for (int t = TK; t < 4; ++t) vr[t] = sh.vv[g + 32 * t];
+        double pr[4];
+#pragma unroll
+        for (int t = TK; t < 4; ++t) {
+            double w0 = 0.0, w1 = 0.0;
+#pragma unroll
+            for (int i = I0; i < 8; i += 2) {
+                w0 += a[t][i] * vc[i];
+                w1 += a[t][i + 1] * vc[i + 1];
+            }
+            w0 = row16_sum(w0 + w1);
+            pr[t] = (g + 32 * t >= k + 1) ? tau * w0 : 0.0;
+        }
+        if (j == 0) {
+#pragma unroll
+            for (int t = TK; t < 4; ++t) sh.ps[g + 32 * t] = pr[t];
+        }
         {
-            // v^T p: one LDS atomic per wave (16 rows)
-            const double t = wave_sum(q == 0 ? p_r * v_r : 0.0);
-            if ((tid & 63) == 0) atomicAdd(&sc[3], t);
+            // v^T p: the 16 lanes of a group hold the same p_r, v_r - one lane per group counts
+            double dot = 0.0;
+#pragma unroll
+            for (int t = TK; t < 4; ++t) dot += pr[t] * vr[t];
+            const double tsum = (td_readlane(dot, 0) + td_readlane(dot, 16)) + (td_readlane(dot, 32) + td_readlane(dot, 48));
+            if (lane == 0) atomicAdd(&sh.vtp[par], tsum);
         }
-        __syncthreads();                                          // (3) p and v^T p are complete
-        // A -= v q^T + q v^T with q = p - K v, written with the raw p:  a_rc -= v_r p_c + (p_r - 2 K v_r) v_c
-        // (no pass that turns p into q, no fourth barrier)
-        const double K = 0.5 * tau * sc[3];
-        const double g_r = p_r - 2.0 * K * v_r;
+        td_lds_barrier();                                          // (2) p and v^T p are complete
+        // ---- (C) A -= v q^T + q v^T with q = p - K v, written with the raw p:  a_rc -= v_r p_c + (p_r - 2 K v_r) v_c
+        const double K = 0.5 * tau * sh.vtp[par];
+        double pc[8], gr[4];
 #pragma unroll
-        for (int ch = 0; ch < 4; ++ch) {
-            if (8 * ch + 7 >= i0) {
+        for (int i = I0; i < 8; ++i) pc[i] = sh.ps[j + 16 * i];
 #pragma unroll
-                for (int ii = 0; ii < 8; ++ii) {
-                    const int c = q + 4 * (8 * ch + ii);
-                    a[8 * ch + ii] -= v_r * ps[c] + g_r * vv[c];
-                }
-            }
+        for (int t = TK; t < 4; ++t) gr[t] = pr[t] - 2.0 * K * vr[t];
+#pragma unroll
+        for (int t = TK; t < 4; ++t)
+#pragma unroll
+            for (int i = I0; i < 8; ++i) a[t][i] = fma(-gr[t], vc[i], fma(-vr[t], pc[i], a[t][i]));
+        // (columns 32 TK .. are rows of the slots TK .. as well: every ps entry read above was written in this step; the
+        //  next step's vv / sc writes come after barrier (2), its ps writes after its barrier (1))
+    }
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(512) void tridiag_reduce_kernel(const double *__restrict__ B, int64_t ldb, int p,
+                                                              double *__restrict__ dd, double *__restrict__ ee,
+                                                              double *__restrict__ HV, double *__restrict__ taus) {
+    __shared__ TdShared sh;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int gi = lane >> 4, j = lane & 15, g = 4 * wave + gi;
+    double a[4][8];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int r = g + 32 * t, c = j + 16 * i;
+            a[t][i] = (r < p && c < p) ? B[(int64_t)r * ldb + c] : 0.0;
         }
-        // (the next step's owners publish into xs / sc[0] only after this update, and barrier (1) orders it against
-        //  every read of this step)
-    }
-    // the trailing 2 x 2 block
-    __syncthreads();
-    if (r == p - 2) {
+    const int kstop = p - 2;                                      // steps k = 0 .. p - 3
+    td_steps<0>(a, kstop < 32 ? kstop : 32, sh, wave, gi, j, g, lane, dd, ee, HV, taus);
+    td_steps<1>(a, kstop < 64 ? kstop : 64, sh, wave, gi, j, g, lane, dd, ee, HV, taus);
+    td_steps<2>(a, kstop < 96 ? kstop : 96, sh, wave, gi, j, g, lane, dd, ee, HV, taus);
+    td_steps<3>(a, kstop, sh, wave, gi, j, g, lane, dd, ee, HV, taus);
+    // the trailing 2 x 2 block, from the registers of its owners (predicated stores: no select over the row slots)
+    const int r2 = p - 2, r1 = p - 1;
 #pragma unroll
-        for (int i = 0; i < 32; ++i) xs[q + 4 * i] = a[i];
-    }
-    if (r == p - 1) {
+    for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int i = 0; i < 32; ++i) vv[q + 4 * i] = a[i];
-    }
-    __syncthreads();
-    if (tid == 0) {
-        dd[p - 2] = xs[p - 2];
-        ee[p - 2] = xs[p - 1];
-        dd[p - 1] = vv[p - 1];
-    }
+        for (int i = 0; i < 8; ++i) {
+            const int r = g + 32 * t, c = j + 16 * i;
+            if (r == r2 && c == r2) dd[r2] = a[t][i];
+            if (r == r2 && c == r1) ee[r2] = a[t][i];
+            if (r == r1 && c == r1) dd[r1] = a[t][i];
+        }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -223,9 +298,13 @@ __global__ __launch_bounds__(256) void tridiag_eigvec_kernel(const double *__res
         e2[i] = e * e;
         ts[i] = (i < p - 2) ? taus[i] : 0.0;
     }
-    for (int e = tid; e < (p - 2) * p; e += 256) {
-        const int k = e / p, c = e - k * p;
-        hv[k * ldh + c] = HV[(int64_t)k * kTdMax + c];
+    {
+        // (column per thread, two rows per pass: no division, and the loads of a pass do not depend on each other)
+        const int c = tid & (kTdMax - 1);
+        if (c < p) {
+#pragma unroll 8
+            for (int k = tid >> 7; k < p - 2; k += 2) hv[k * ldh + c] = HV[(int64_t)k * kTdMax + c];
+        }
     }
     __syncthreads();
     if (m >= p) return;                                // (no barrier below)
@@ -347,7 +426,7 @@ __global__ __launch_bounds__(256) void tridiag_eigvec_kernel(const double *__res
     for (int k = p - 3; k >= 0; --k) {
         const double v0 = (lane < p) ? hv[k * ldh + lane] : 0.0;
         const double v1 = (lane + 64 < p) ? hv[k * ldh + lane + 64] : 0.0;
-        const double s = ts[k] * wave_sum(v0 * z0 + v1 * z1);
+        const double s = ts[k] * wave_sum_mfma(v0 * z0 + v1 * z1);
         z0 -= s * v0;
         z1 -= s * v1;
     }
@@ -376,7 +455,7 @@ int tridiag_eig_launch(const double *B, int64_t ldb, int p, double *U, int64_t l
         if (rco != GS_OK) return rco;
     }
     if (!gs_dry_run()) GS_HIP_CHECK(hipMemsetAsync(info, 0, sizeof(int) * 2, stream));
-    GS_LAUNCH(tridiag_reduce_kernel, dim3(1), dim3((unsigned)(4 * p)), 0, stream, B, ldb, p, dd, ee, HV, taus);
+    GS_LAUNCH(tridiag_reduce_kernel, dim3(1), dim3(512), 0, stream, B, ldb, p, dd, ee, HV, taus);
     GS_LAUNCH(tridiag_eigvec_kernel, dim3((unsigned)ceil_div(p, 4)), dim3(256), tridiag_eigvec_lds(p), stream, dd, ee, HV, taus,
               p, U, ldu, theta, info);
     GS_HIP_CHECK(hipGetLastError());
