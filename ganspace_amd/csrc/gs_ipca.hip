@@ -83,6 +83,11 @@ struct gs_ipca {
     // ev_asm: the block is assembled and the next shift is in place (aux -> caller's stream: the next Gram launch may
     // overwrite G64 / S1); ev_chain: end of what has been enqueued on aux (readers join through it).
     hipEvent_t ev_gram = nullptr, ev_asm = nullptr, ev_chain = nullptr;
+    // gs_ipca_finalize hands six arrays to the host.  Six copies into pageable memory are six staged transfers with a
+    // host wait each; for the Gram-side sizes the results are packed into `res_dev` by one kernel and travel as ONE
+    // transfer into the handle's own pinned buffer (layout: outs[3k] | mean[d] | var[d] (float64), components[k*d] (float32))
+    void *res_dev = nullptr, *res_host = nullptr;
+    size_t res_bytes = 0;
     bool chain_live = false;     // aux holds work the caller's stream has not joined yet
     bool asm_live = false;       // ev_asm has been recorded and not yet waited for
 };
@@ -297,6 +302,24 @@ __global__ void pad_copy_kernel(const double *__restrict__ Bk, int k, double *__
 }
 
 // sv = sqrt(lambda), ev = lambda/(n-1), evr = lambda/total
+// results of a fit, packed for one device-to-host transfer (see gs_ipca::res_dev)
+__global__ void pack_results_kernel(const double *__restrict__ outs, const double *__restrict__ mean,
+                                    const double *__restrict__ m2, const float *__restrict__ comp, double n, int k,
+                                    int d, double *__restrict__ stage) {
+    const int64_t nd = 3 * (int64_t)k + 2 * (int64_t)d, nf = (int64_t)k * d;
+    float *cf = reinterpret_cast<float *>(stage + nd);
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < nd + nf; e += (int64_t)gridDim.x * blockDim.x) {
+        if (e < 3 * k)
+            stage[e] = outs[e];
+        else if (e < 3 * k + d)
+            stage[e] = mean[e - 3 * k];
+        else if (e < nd)
+            stage[e] = m2[e - 3 * k - d] / n;
+        else
+            cf[e - nd] = comp[e - nd];
+    }
+}
+
 __global__ void derive_outputs_kernel(const double *__restrict__ lam, const double *__restrict__ total_src,
                                       int total_len, double *__restrict__ outs, int k, double n) {
     __shared__ double part[256];
@@ -762,6 +785,19 @@ int gs_ipca_create(int64_t d, int k, int mode, int precision, int device, gs_ipc
         if (h->aux) (void)hipStreamDestroy(h->aux);
         h->aux = nullptr;
     }
+    {
+        const size_t rb = sizeof(double) * (3 * (size_t)k + 2 * (size_t)d) + sizeof(float) * (size_t)k * d;
+        if (rb <= ((size_t)4 << 20)) {     // (wide layers keep the separate copies: pinning tens of MB per handle costs more)
+            if (hipMalloc(&h->res_dev, rb) == hipSuccess && hipHostMalloc(&h->res_host, rb, hipHostMallocDefault) == hipSuccess) {
+                h->res_bytes = rb;
+            } else {
+                (void)hipGetLastError();
+                if (h->res_dev) (void)hipFree(h->res_dev);
+                h->res_dev = nullptr;
+                h->res_host = nullptr;
+            }
+        }
+    }
     int rc = GS_OK;
     auto alloc = [&](void **p, size_t bytes) {
         if (rc != GS_OK) return;
@@ -847,6 +883,8 @@ int gs_ipca_destroy(gs_ipca_t *h) {
                     h->Vk,    h->lam, h->scal, h->outs, h->comp32, h->mean32, h->Bk, h->T};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
+    if (h->res_dev) (void)hipFree(h->res_dev);
+    if (h->res_host) (void)hipHostFree(h->res_host);
     if (h->aux) {
         (void)hipStreamSynchronize(h->aux);
         (void)hipStreamDestroy(h->aux);
@@ -1131,6 +1169,23 @@ int gs_ipca_finalize(gs_ipca_t *h, float *components_host, double *singular_valu
     } else if (h->pending_diag) {
         int rc = faithful_materialize(h, stream);
         if (rc != GS_OK) return rc;
+    }
+    if (h->res_bytes > 0) {
+        const int64_t total = 3 * (int64_t)k + 2 * (int64_t)d + (int64_t)k * d;
+        hipLaunchKernelGGL(pack_results_kernel, dim3((unsigned)ceil_div(total, 256 * 4)), dim3(256), 0, stream, h->outs,
+                           h->mean, h->m2, h->comp32, (double)h->n_seen, k, d, (double *)h->res_dev);
+        GS_HIP_CHECK(hipGetLastError());
+        GS_HIP_CHECK(hipMemcpyAsync(h->res_host, h->res_dev, h->res_bytes, hipMemcpyDeviceToHost, stream));
+        GS_HIP_CHECK(hipStreamSynchronize(stream));
+        const double *rd = (const double *)h->res_host;
+        if (singular_values_host) std::memcpy(singular_values_host, rd, sizeof(double) * k);
+        if (explained_variance_host) std::memcpy(explained_variance_host, rd + k, sizeof(double) * k);
+        if (explained_variance_ratio_host) std::memcpy(explained_variance_ratio_host, rd + 2 * k, sizeof(double) * k);
+        if (mean_host) std::memcpy(mean_host, rd + 3 * k, sizeof(double) * d);
+        if (var_host) std::memcpy(var_host, rd + 3 * k + d, sizeof(double) * d);
+        if (components_host) std::memcpy(components_host, rd + 3 * k + 2 * d, sizeof(float) * (size_t)k * d);
+        if (n_seen_host) *n_seen_host = h->n_seen;
+        return GS_OK;
     }
     std::vector<double> outs(3 * (size_t)k);
     GS_HIP_CHECK(hipMemcpyAsync(outs.data(), h->outs, sizeof(double) * 3 * k, hipMemcpyDeviceToHost, stream));
