@@ -274,6 +274,8 @@ struct SubspaceWorkspace {
     // projection step of eigh_topk_cheb: tridiagonalisation + bisection (gs_tridiag.hip) unless that solver reported
     // clustered Ritz values on this workspace - then one-sided Jacobi from there on
     double *td_scratch = nullptr;  // [(128 + 3) * 128] reflectors, diagonal, off-diagonal, taus
+    double *pin = nullptr;         // [p_cap + 32] PINNED host scratch: what the solver reads back between its segments
+                                   // (a copy into pageable memory is a staged, synchronous transfer: ~40 us each)
     bool rr_force_jacobi = false;
     int warm_mults = 0;            // products the last converged warm-started solve used (schedule hint)
     // gs_topk.hip: filter schedule of the last converged warm-started solve (reused without a host round trip)

@@ -501,6 +501,10 @@ int subspace_workspace_alloc(SubspaceWorkspace &ws, int n, int p) {
     if (rc == GS_OK) rc = alloc(&ws.Rm, ppp);
     if (rc == GS_OK) rc = alloc(&ws.Dinv, (size_t)(ws.pp / 16 + 1) * kCB * kCB);
     if (rc == GS_OK) rc = alloc(&ws.td_scratch, (size_t)(128 + 3) * 128);
+    if (rc == GS_OK && hipHostMalloc((void **)&ws.pin, sizeof(double) * ((size_t)ws.p_cap + 32), hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        ws.pin = nullptr;              // (the readers fall back to pageable buffers)
+    }
     if (rc == GS_OK && hipMemset(ws.Rm, 0, sizeof(double) * ppp) != hipSuccess) rc = GS_EHIP;
     if (rc == GS_OK) rc = eigh_workspace_alloc(ws.ews, ws.pp + 2);
     if (rc == GS_OK) rc = topk_prepare_kernels();
@@ -516,6 +520,8 @@ void graph_cache_free(GraphCache &gc) {
 void subspace_workspace_free(SubspaceWorkspace &ws) {
     graph_cache_free(ws.graphs);
     if (ws.inv_host) (void)hipHostFree(ws.inv_host);
+    if (ws.pin) (void)hipHostFree(ws.pin);
+    ws.pin = nullptr;
     if (ws.inv_event) (void)hipEventDestroy(ws.inv_event);
     double *ptrs[] = {ws.pool, ws.G, ws.H, ws.B, ws.U, ws.theta, ws.Rm, ws.Dinv, ws.td_scratch};
     for (double *p : ptrs)
@@ -612,7 +618,8 @@ int eigh_topk_subspace(SubspaceWorkspace &ws, const double *A, int n, int64_t ld
     int mults = 0, interval = 2, orths = 0, next_rr = warm ? (ws.warm_mults > 4 ? ws.warm_mults : 4) : max_mults;
     double rho = 0.0, prev_worst = 0.0;
     *converged = 0;
-    std::vector<double> host(k + 8);
+    std::vector<double> host_pageable(k + 8);
+    double *host = ws.pin ? ws.pin : host_pageable.data();
     double *stats = ws.theta + 3 * ws.pp + 8;     // 6 doubles behind the pivot floors
     while (true) {
         // ---- power phase ---------------------------------------------------------------------------------
@@ -639,7 +646,7 @@ int eigh_topk_subspace(SubspaceWorkspace &ws, const double *A, int n, int64_t ld
                 continue;
             }
             GS_LAUNCH(rdiag_stats_kernel, dim3(1), dim3(64), 0, stream, ws.Rm, ld, p, k, stats);
-            GS_HIP_CHECK(hipMemcpyAsync(host.data(), stats, sizeof(double) * 6, hipMemcpyDeviceToHost, stream));
+            GS_HIP_CHECK(hipMemcpyAsync(host, stats, sizeof(double) * 6, hipMemcpyDeviceToHost, stream));
             GS_HIP_CHECK(hipStreamSynchronize(stream));
             const double r1 = host[0], rk = host[1], rp = host[2], dmax = host[3], dmin = host[4];
             const int ndead = (int)host[5];
@@ -683,8 +690,8 @@ int eigh_topk_subspace(SubspaceWorkspace &ws, const double *A, int n, int64_t ld
         gemm_f64(n, k, p, Y, ld, 1, ws.U, ld, 1, ws.R, ld, stream);  // R = (A Q) U_k
         GS_LAUNCH(resid_kernel, dim3((unsigned)k), dim3(256), 0, stream, ws.R, Z, ld, ws.theta, n, k,
                            ws.theta + ws.pp);
-        GS_HIP_CHECK(hipMemcpyAsync(host.data(), ws.theta + ws.pp, sizeof(double) * k, hipMemcpyDeviceToHost, stream));
-        GS_HIP_CHECK(hipMemcpyAsync(host.data() + k, ws.theta, sizeof(double), hipMemcpyDeviceToHost, stream));
+        GS_HIP_CHECK(hipMemcpyAsync(host, ws.theta + ws.pp, sizeof(double) * k, hipMemcpyDeviceToHost, stream));
+        GS_HIP_CHECK(hipMemcpyAsync(host + k, ws.theta, sizeof(double), hipMemcpyDeviceToHost, stream));
         GS_HIP_CHECK(hipStreamSynchronize(stream));
         double worst = 0;
         for (int i = 0; i < k; ++i) worst = worst > host[i] ? worst : host[i];

@@ -1160,14 +1160,15 @@ int eigh_topk_cheb(SubspaceWorkspace &ws, const double *A, int n, int64_t lda, i
     // ---- plan ---------------------------------------------------------------------------------------------
     int deg = 1, ncyc = 1;
     double gain = 0.0;
-    std::vector<double> host(k + 16);
+    std::vector<double> host_pageable(k + 16);
+    double *host = ws.pin ? ws.pin : host_pageable.data();     // (pinned: the read-backs below are plain DMA)
     const bool reuse_plan = warm && ws.plan_valid && ws.plan_p == p;
     // a cold solve right after a converged cold solve of a same-sized matrix (one fit after another): try that solve's
     // schedule first - the coefficients still come from THIS matrix's estimates, the residual test still decides
     const bool reuse_cold = !warm && ws.cold_plan_valid && ws.cold_plan_p == p;
     auto plan_from_stats = [&](bool *no_gap) -> int {
         *no_gap = false;
-        GS_HIP_CHECK(hipMemcpyAsync(host.data(), stats, sizeof(double) * 8, hipMemcpyDeviceToHost, stream));
+        GS_HIP_CHECK(hipMemcpyAsync(host, stats, sizeof(double) * 8, hipMemcpyDeviceToHost, stream));
         GS_HIP_CHECK(hipStreamSynchronize(stream));
         const double rk = host[1], ndead = host[5], lam1 = host[6], b = host[7];
         if (ndead > 0.0 || !(b > 1e-12 * lam1)) {
@@ -1288,9 +1289,9 @@ int eigh_topk_cheb(SubspaceWorkspace &ws, const double *A, int n, int64_t lda, i
                                                            (int64_t)(intptr_t)Qc, ws.epilogue ? 1 : 0,
                                                            ws.rr_force_jacobi ? 1 : 0}), stream, segment_b);
         if (rcb != GS_OK) return rcb;
-        GS_HIP_CHECK(hipMemcpyAsync(host.data(), ws.theta + ws.pp, sizeof(double) * k, hipMemcpyDeviceToHost, stream));
-        GS_HIP_CHECK(hipMemcpyAsync(host.data() + k, ws.theta, sizeof(double), hipMemcpyDeviceToHost, stream));
-        int jhost[2] = {0, 0};
+        GS_HIP_CHECK(hipMemcpyAsync(host, ws.theta + ws.pp, sizeof(double) * k, hipMemcpyDeviceToHost, stream));
+        GS_HIP_CHECK(hipMemcpyAsync(host + k, ws.theta, sizeof(double), hipMemcpyDeviceToHost, stream));
+        int *jhost = reinterpret_cast<int *>(host + k + 2);
         GS_HIP_CHECK(hipMemcpyAsync(jhost, jinfo, sizeof(int) * 2, hipMemcpyDeviceToHost, stream));
         GS_HIP_CHECK(hipStreamSynchronize(stream));
         double worst = 0;
