@@ -253,3 +253,16 @@ def test_two_live_native_streams_do_not_share_a_ring():
     assert s3._ring[2] is True
     s3.close()
     assert all(e[2] is False for e in _zgen._RING_CACHE.values())
+
+
+def test_regression_staging_is_bounded_in_rows_and_bytes():
+    """``linreg_lstsq`` stages mini-batches of [A|Z] rows per Gram call: as many as fit 65 536 rows / 256 MB, at least one
+    mini-batch, never a partial one."""
+    from ganspace_amd.decomposition import _regression_stage_batches as stage
+    assert stage(2000, 208) == 32                      # cfg3: 500 mini-batches -> 16 Gram calls (was 250)
+    assert stage(10000, 592) == 6                      # cfg4: 100 -> 17
+    assert stage(10000, 8192) == 1                     # a mini-batch wider than the byte budget still goes through whole
+    assert stage(70000, 208) == 1
+    for B, wp in [(1, 8), (250, 208), (4096, 4096), (3, 7)]:
+        n = stage(B, wp)
+        assert n >= 1 and (n == 1 or (n * B <= 65536 and n * B * wp * 4 <= 256 << 20))
