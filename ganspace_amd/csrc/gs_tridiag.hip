@@ -9,9 +9,10 @@
 //
 //   tridiag_reduce_kernel   ONE workgroup, B in registers (a 4 x 8 block per thread, interleaved rows and columns):
 //                           p - 2 Householder steps A <- H A H with H = I - tau v v^T, two barriers per step (v and
-//                           p = tau A v travel through LDS vectors, v^T p through an LDS float64 atomic).  The shrinking
-//                           trailing block is skipped in units of 16 columns / 32 rows.  Outputs: diagonal d,
-//                           off-diagonal e, the reflectors (rows of HV) and their tau.
+//                           p = tau A v travel through LDS vectors, v^T p through an LDS float64 atomic).  Finished row
+//                           slots (32 rows) and column groups (32 columns) are skipped at compile time: the step loop
+//                           is instantiated once per row slot.  Outputs: diagonal d, off-diagonal e, the reflectors
+//                           (rows of HV) and their tau.
 //   tridiag_eigvec_kernel   one WAVE per wanted eigenpair (p / 4 workgroups - the only part of a Rayleigh-Ritz step that
 //                           is not confined to one CU): (1) the eigenvalue by 65-section - 64 Sturm counts per iteration,
 //                           one per lane, 9 iterations to the last bit; (2) the eigenvector of T by a twisted

@@ -147,7 +147,9 @@ int gs_ipca_allreduce(gs_ipca_t *h, void *rccl_comm, void *stream);
  *     convention of sklearn svd_flip(u_based_decision=False) (extmath.py:943-951);
  *   singular_values/explained_variance/explained_variance_ratio [k] float64;
  *   mean/var [d] float64 (var = biased per-feature variance, sklearn var_);
- *   n_seen int64.  Synchronises `stream`.  EXACT mode runs the eigensolve here; FAITHFUL /
+ *   n_seen int64.  Synchronises `stream`.  For the Gram-side sizes the results travel as ONE transfer through a pinned
+ *   buffer that belongs to the handle (a handle is not re-entrant: one finalize at a time).
+ *   EXACT mode runs the eigensolve here; FAITHFUL /
  *   SMALLSIDE carry an undiagonalised basis of the k leading directions from block to block
  *   once five blocks have been absorbed and run the (k x k) diagonalisation here - the
  *   update may be continued afterwards (the recurrence does not depend on when it is read). */
