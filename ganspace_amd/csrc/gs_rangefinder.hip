@@ -100,6 +100,7 @@ __global__ __launch_bounds__(256, 2) void tn_rows_kernel(const float *__restrict
     for (int s = 0; s < nst; ++s) {
         const int buf = s & 1;
         fetch(r0 + (int64_t)(s + 1 < nst ? s + 1 : s) * kTS);
+        __builtin_amdgcn_sched_barrier(0);      // (the loads go out before the stage's MFMAs: see rowgram_kernel)
         const float *Ap = &lds[buf][0][arow][acol];
         const float *Bp = &lds[buf][1][arow][bcol];
 #pragma unroll

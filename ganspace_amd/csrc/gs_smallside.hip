@@ -133,6 +133,9 @@ __global__ __launch_bounds__(256, 1) void rowgram_kernel(const float *__restrict
     for (int s = 0; s < nst; ++s) {
         const int buf = s & 1;
         fetch(k_begin + (int64_t)(s + 1 < nst ? s + 1 : s) * kRK);      // unconditional (clamped): no branch around loads
+        // the loads go out BEFORE the stage's MFMAs: left to itself the scheduler sinks them behind 56 of the 64 MFMAs
+        // (ISA, round 4), and stash() then waits for memory with the matrix pipe idle
+        __builtin_amdgcn_sched_barrier(0);
         const float *A = &lds[buf][0][arow][acol];
         const float *B = &lds[buf][diag ? 0 : 1][arow][bcol];
 #pragma unroll
@@ -422,6 +425,7 @@ __global__ __launch_bounds__(256, 2) void tn_gemm_kernel(const float *__restrict
         // (unconditional: past the last stage the clamped rows are fetched again and stashed into the buffer nobody reads
         //  any more)
         GS_TN_FETCH((s + 1) * 32)
+        __builtin_amdgcn_sched_barrier(0);      // (loads before the MFMAs, as in rowgram_kernel)
         const float *A = &lds[buf][0][arow][acol];
         const float *B = &lds[buf][1][arow][bcol];
 #pragma unroll
