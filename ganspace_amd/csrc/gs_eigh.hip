@@ -210,11 +210,29 @@ __global__ __launch_bounds__(BS * 64) void jacobi_block_kernel(double *__restric
     // stage: wave w owns column w of block p (slot w) and of block q (slot BS + w)
     const int colp = p * BS + w, colq = q * BS + w;
     double *sp = panel + w * NP, *sq = panel + (BS + w) * NP;
+    {
+        // loads at clamped addresses, eight per column in flight, the padding selected afterwards: with the test around the
+        // load the compiler emits load - s_waitcnt vmcnt(0) - LDS store per element, one round trip to L2 each (found in
+        // the ISA, round 4: all 2 NPL loads of this kernel were serialised)
+        constexpr int CH = NPL < 8 ? NPL : 8;
+        const int64_t cp = colp < n ? colp : n - 1, cq = colq < n ? colq : n - 1;
 #pragma unroll
-    for (int t = 0; t < NPL; ++t) {
-        const int e = t * 64 + lane;
-        sp[e] = (colp < n && e < n) ? W[(int64_t)colp * ldw + e] : 0.0;
-        sq[e] = (colq < n && e < n) ? W[(int64_t)colq * ldw + e] : 0.0;
+        for (int t0 = 0; t0 < NPL; t0 += CH) {
+            double vp[CH], vq[CH];
+#pragma unroll
+            for (int t = 0; t < CH; ++t) {
+                const int e = (t0 + t) * 64 + lane;
+                const int ec = e < n ? e : n - 1;
+                vp[t] = W[cp * ldw + ec];
+                vq[t] = W[cq * ldw + ec];
+            }
+#pragma unroll
+            for (int t = 0; t < CH; ++t) {
+                const int e = (t0 + t) * 64 + lane;
+                sp[e] = (colp < n && e < n) ? vp[t] : 0.0;
+                sq[e] = (colq < n && e < n) ? vq[t] : 0.0;
+            }
+        }
     }
     const double tiny = (double)n * 2.220446049250313e-16;
     const double floor2 = maxnorm[0] * tiny * tiny;
