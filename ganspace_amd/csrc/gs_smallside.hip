@@ -174,6 +174,132 @@ __global__ __launch_bounds__(256, 1) void rowgram_kernel(const float *__restrict
     }
 }
 
+// ---- candidate for round 5 (measurement build only: GS_ROWGRAM_RK=1): the same kernel with the LDS image in the layout
+// the K-blocked M already has - [row][32 k, padded to 36 floats] instead of the transposed [k][row].  A stage is then
+// staged by eight 16-byte LDS writes per thread (32 scalar ones now) and the MFMA operands are read as four
+// ds_read_b128 per group of 8 k values (sixteen ds_read_b32 pairs now): lanes 0-31 take k = 8 g + e, lanes 32-63
+// k = 8 g + 4 + e for the e-th of the group's four MFMAs - any assignment of k values to the two halves works as long as
+// both operands use the same one.  Row stride 144 B: sixteen consecutive rows of a b128 access cover the 64 banks
+// exactly once.  Same decomposition, same float64 carry, same output as rowgram_kernel; written after round 4's GPU
+// budget was spent - NOT run yet.
+constexpr int kRKP = kRK + 4;
+
+__global__ __launch_bounds__(256, 1) void rowgram_rk_kernel(const float *__restrict__ M, int64_t d, int64_t ldm,
+                                                            double *__restrict__ slab, int rp, int nmt, int T,
+                                                            int64_t kchunk, const int2 *__restrict__ order, int total) {
+    __shared__ __attribute__((aligned(16))) float lds[2][2][kRT][kRKP];
+    int split, I, J;
+    if (!rowgram_assign(order, nmt, total, split, I, J)) return;
+    const bool diag = (I == J);
+    const int64_t k_begin = (int64_t)split * kchunk;
+    const int64_t k_end = (k_begin + kchunk < d) ? k_begin + kchunk : d;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wi = wave >> 1, wj = wave & 1;
+    const int k4 = tid & 7, r8 = tid >> 3;
+    const int64_t rowA = (int64_t)I * kRT, rowB = (int64_t)J * kRT;
+
+    // (named registers and macros, not arrays captured by lambdas: those were materialised in 160 B of scratch here)
+    float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
+#define GS_RK_FETCH1(i, kc)                                                                        \
+    ra##i = *reinterpret_cast<const float4 *>(M + mblk(rowA + r8 + 32 * (i), (kc), ldm));          \
+    rb##i = *reinterpret_cast<const float4 *>(M + mblk(rowB + r8 + 32 * (i), (kc), ldm));
+#define GS_RK_FETCH(k0)                                                                            \
+    {                                                                                              \
+        const int64_t kk_ = (k0) + k4 * 4;                                                         \
+        const int64_t kc_ = kk_ < k_end ? kk_ : k_begin; /* d % 4 == 0 is required by the caller */ \
+        GS_RK_FETCH1(0, kc_) GS_RK_FETCH1(1, kc_) GS_RK_FETCH1(2, kc_) GS_RK_FETCH1(3, kc_)        \
+    }
+#define GS_RK_STASH1(i, buf, mk)                                                                   \
+    {                                                                                              \
+        float4 va_ = ra##i, vb_ = rb##i;                                                           \
+        va_.x *= (mk), va_.y *= (mk), va_.z *= (mk), va_.w *= (mk);                                \
+        vb_.x *= (mk), vb_.y *= (mk), vb_.z *= (mk), vb_.w *= (mk);                                \
+        *reinterpret_cast<float4 *>(&lds[buf][0][r8 + 32 * (i)][k4 * 4]) = va_;                    \
+        *reinterpret_cast<float4 *>(&lds[buf][1][r8 + 32 * (i)][k4 * 4]) = vb_;                    \
+    }
+#define GS_RK_STASH(buf, k0)                                                                       \
+    {                                                                                              \
+        float mk_ = ((k0) + k4 * 4 < k_end) ? 1.f : 0.f;                                           \
+        /* opaque and ordered behind the scheduling barrier: a plain multiply by the mask is placed right behind the \
+           loads (it is pure arithmetic: nothing orders it against the MFMAs), and the wait for memory with it */     \
+        asm volatile("" : "+v"(mk_));                                                              \
+        GS_RK_STASH1(0, buf, mk_) GS_RK_STASH1(1, buf, mk_) GS_RK_STASH1(2, buf, mk_) GS_RK_STASH1(3, buf, mk_) \
+    }
+
+    f32x16 acc[4] = {{0}, {0}, {0}, {0}};
+    double acc64[4][16];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc64[a][r] = 0.0;
+
+    const int nst = (int)((k_end - k_begin + kRK - 1) / kRK);
+    const int half = lane >> 5;
+    const int arow = wi * 64 + (lane & 31), brow = wj * 64 + (lane & 31);
+    if (nst > 0) {
+        GS_RK_FETCH(k_begin)
+        GS_RK_STASH(0, k_begin)
+    }
+    __syncthreads();
+    for (int s = 0; s < nst; ++s) {
+        const int buf = s & 1;
+        GS_RK_FETCH(k_begin + (int64_t)(s + 1 < nst ? s + 1 : s) * kRK)
+        __builtin_amdgcn_sched_barrier(0);
+        const float *Ap = &lds[buf][0][arow][4 * half];
+        const float *Bp = &lds[buf][diag ? 0 : 1][brow][4 * half];
+#pragma unroll
+        for (int g = 0; g < kRK / 8; ++g) {
+            const float4 a0 = *reinterpret_cast<const float4 *>(Ap + 8 * g);
+            const float4 a1 = *reinterpret_cast<const float4 *>(Ap + 32 * kRKP + 8 * g);
+            const float4 b0 = *reinterpret_cast<const float4 *>(Bp + 8 * g);
+            const float4 b1 = *reinterpret_cast<const float4 *>(Bp + 32 * kRKP + 8 * g);
+#define GS_RK_STEP(e)                                                               \
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.e, b0.e, acc[0], 0, 0, 0);     \
+    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.e, b1.e, acc[1], 0, 0, 0);     \
+    acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.e, b0.e, acc[2], 0, 0, 0);     \
+    acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.e, b1.e, acc[3], 0, 0, 0);
+            GS_RK_STEP(x)
+            GS_RK_STEP(y)
+            GS_RK_STEP(z)
+            GS_RK_STEP(w)
+#undef GS_RK_STEP
+        }
+        // The stash follows the MFMAs in the SAME basic block, for both panels and every stage: with a branch between
+        // them (the float64 carry below, `s + 1 < nst`, `!diag`) the compiler sinks the LOADS into the block of their
+        // only use - behind the MFMAs, scheduling barrier or not.  Past the last stage the clamped stage is written once
+        // more into the buffer nobody reads any more; a diagonal tile writes a second panel it never reads.
+        __builtin_amdgcn_sched_barrier(0);
+        GS_RK_STASH(buf ^ 1, k_begin + (int64_t)(s + 1 < nst ? s + 1 : s) * kRK)
+        if ((s + 1) % kFlushStages == 0 || s + 1 == nst) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    acc64[a][r] += (double)acc[a][r];
+                    acc[a][r] = 0.f;
+                }
+            }
+        }
+        __syncthreads();
+    }
+#undef GS_RK_FETCH
+#undef GS_RK_FETCH1
+#undef GS_RK_STASH
+#undef GS_RK_STASH1
+    double *out = slab + (int64_t)split * rp * rp;
+    const int row_base = I * kRT + wi * 64 + 4 * (lane >> 5);
+    const int col_base = J * kRT + wj * 64 + (lane & 31);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = row_base + (r & 3) + 8 * (r >> 2);
+        out[(int64_t)row * rp + col_base] = acc64[0][r];
+        out[(int64_t)row * rp + col_base + 32] = acc64[1][r];
+        out[(int64_t)(row + 32) * rp + col_base] = acc64[2][r];
+        out[(int64_t)(row + 32) * rp + col_base + 32] = acc64[3][r];
+    }
+}
+
 // ---- the same partial products on the bf16 matrix cores (opt-in: GS_PREC_BF16X6 / GS_PREC_BF16X3) -----------------
 // v_mfma_f32_32x32x16_bf16 wants 8 CONSECUTIVE k per lane for a fixed row of either operand - and both operands of
 // M M^T are rows of the row-major M, K-contiguous: no transpose anywhere (unlike X^T X, gs_gram_bf16.hip).  A thread
@@ -756,7 +882,11 @@ int smallside_update(SmallSide &ss, const float *X, int64_t rows, int64_t ldx, d
     const int total = nmt * ss.nsplit;
     const unsigned rgrid = (unsigned)(((total + 7) / 8) * 8);
     const int2 *order = reinterpret_cast<const int2 *>(ss.tile_order);
-    if (ss.precision == GS_PREC_F32) {
+    static const bool rk_layout = gs_knob("GS_ROWGRAM_RK") != nullptr;      // (measurement build: the round-5 candidate)
+    if (ss.precision == GS_PREC_F32 && rk_layout) {
+        hipLaunchKernelGGL(rowgram_rk_kernel, dim3(rgrid), dim3(256), 0, stream, ss.M, d, (int64_t)rp, ss.slab, rp, nmt, Tt,
+                           kchunk, order, total);
+    } else if (ss.precision == GS_PREC_F32) {
         hipLaunchKernelGGL(rowgram_kernel, dim3(rgrid), dim3(256), 0, stream, ss.M, d, (int64_t)rp, ss.slab, rp, nmt, Tt,
                            kchunk, order, total);
     } else {
