@@ -1,8 +1,13 @@
-// What clock does a ONE-workgroup kernel run at, and what do its dependent operations cost?  The float64 solver chains
-// (chol_inv_kernel, tridiag_reduce_kernel, ...) are single-workgroup, latency-bound kernels: every estimate of theirs
-// in cycles came out ~2x below the measured time.  This probe reads the shader clock (s_memtime) against the 100 MHz
-// real-time counter (s_memrealtime) around loops of dependent operations, for a lone kernel after idle, for the same
-// kernel after 30 ms of back-to-back launches, and for the same kernel while a chip-filling kernel runs on another stream.
+// What do the dependent operations of a ONE-workgroup kernel cost?  The float64 solver chains (chol_inv_kernel,
+// tridiag_reduce_kernel, ...) are single-workgroup, latency-bound kernels, and every estimate of theirs in cycles had come
+// out ~2x below the measured time.  This probe brackets loops of dependent operations (unrolled 16x: a loop-closing
+// taken branch alone is ~33 clk) with the shader clock (s_memtime) and the 100 MHz real-time counter (s_memrealtime):
+// dependent v_fma_f64, v_rsq_f64 / v_rcp_f64 + fma, a DPP row step + add + mul, an LDS write -> read round trip,
+// __syncthreads with 2 / 8 / 16 waves, two v_readlane + add, blocks guarded by uniform branches (taken / not taken /
+// alternating), and two calibrations: 16 x s_nop 15 (= 16 x 16 x 4 cycles: s_memtime IS the shader clock, 2.4 GHz for a
+// lone kernel) and a chain of v_add_f32.  An earlier version also ran the loops after idle, back to back and beside a
+// chip-filling kernel: the clock read 2.39-2.42 GHz in all of them (profiles/r04_probes.md).  Results:
+// profiles/r04_sclk_probe.log.
 //   hipcc --offload-arch=gfx950 -O3 -w tools/ubench/sclk_probe.hip -o tools/ubench/sclk_probe && tools/ubench/sclk_probe
 #include <hip/hip_runtime.h>
 #include <chrono>
