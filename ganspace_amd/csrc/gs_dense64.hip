@@ -61,7 +61,12 @@ __global__ void mm64_zero_kernel(double *__restrict__ C, int N, int64_t ldc) {
 // KSPLIT = true : grid (N/16, M/16, zsplit); the 4 waves of a workgroup take quarters of the K range of ONE tile.
 // KSPLIT = false: grid (N/32, M/32, zsplit); wave w owns tile (w >> 1, w & 1) of a 32 x 32 block, full K range.
 // CH: k values a wave loads ahead of its MFMAs (32 or 128).
-template <bool KSPLIT, int CH>
+// LEAN (measurement build only, GS_MM64_LEAN=1; written after round 4's GPU budget was spent, not run yet): the ISA of the
+// plain variant guards each of the 2 x CH / 4 operand loads of a chunk with its own branch (`br G br G ...`, ~30 clk
+// each: ~0.8 us of a 7.5 us product) and reads the two epilogue operands with a round trip each.  LEAN takes whole
+// chunks of whole tiles - the only case the solver chains produce - without any predicate, and issues both epilogue
+// loads before it uses either (from C itself where an operand is absent: a valid address whose value is discarded).
+template <bool KSPLIT, int CH, bool LEAN = false>
 __global__ __launch_bounds__(256) void mm64_kernel(int M, int N, int K, const double *__restrict__ A, int64_t a_i,
                                                    int64_t a_t, const double *__restrict__ B, int64_t b_t, int64_t b_j,
                                                    double *__restrict__ C, int64_t ldc, double alpha, double beta,
@@ -100,8 +105,29 @@ __global__ __launch_bounds__(256) void mm64_kernel(int M, int N, int K, const do
     const double *Bp = B + (int64_t)(jok ? gj : 0) * b_j;
     d4_t acc = {0.0, 0.0, 0.0, 0.0};
     constexpr int NB = CH / 16;                    // batches of 16 k values = 4 MFMAs each
+    const bool tile_full = (i0 + 16 <= M) && (j0 + 16 <= N);       // (workgroup-uniform for KSPLIT, wave-uniform otherwise)
     for (int k0 = kb; k0 < ke; k0 += CH) {
         double a[NB][4], b[NB][4];
+        if (LEAN && tile_full && k0 + CH <= ke) {
+#pragma unroll
+            for (int q = 0; q < NB; ++q) {
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const int kk = k0 + 16 * q + 4 * g + m;
+                    a[q][m] = Ap[(int64_t)kk * a_t];
+                    b[q][m] = Bp[(int64_t)kk * b_t];
+                }
+            }
+            // (all loads of the chunk in flight before the first MFMA waits for its pair: left alone the scheduler keeps a
+            //  window of ~10 loads, i.e. ~5 MFMAs of 32 clk against a ~700 clk round trip)
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < NB; ++q) {
+#pragma unroll
+                for (int m = 0; m < 4; ++m) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q][m], b[q][m], acc, 0, 0, 0);
+            }
+            continue;
+        }
 #pragma unroll
         for (int q = 0; q < NB; ++q) {
 #pragma unroll
@@ -126,7 +152,14 @@ __global__ __launch_bounds__(256) void mm64_kernel(int M, int N, int K, const do
         double *dst = C + (int64_t)r * ldc + c;
         if (epi.coef != nullptr) {
             double o = epi.coef[0] * v;
-            if (!split || zi == 0) {
+            if (LEAN) {
+                const double *q1 = epi.E1 ? epi.E1 : C, *q2 = epi.E2 ? epi.E2 : C;
+                const double x1 = q1[(int64_t)r * ldc + c], x2 = q2[(int64_t)r * ldc + c];
+                if (!split || zi == 0) {
+                    if (epi.E1) o += epi.coef[1] * x1;
+                    if (epi.E2) o += epi.coef[2] * x2;
+                }
+            } else if (!split || zi == 0) {
                 if (epi.E1) o += epi.coef[1] * epi.E1[(int64_t)r * ldc + c];
                 if (epi.E2) o += epi.coef[2] * epi.E2[(int64_t)r * ldc + c];
             }
@@ -174,6 +207,25 @@ void mm64(int M, int N, int K, const double *A, int64_t a_i, int64_t a_t, const 
     const int ts = ksplit ? 16 : 32;
     const int ntc = (int)ceil_div(N, ts), nrl = (int)ceil_div(ceil_div(M, ts), 8);
     const dim3 grid((unsigned)(8 * nrl * ntc * zs));
+    static const bool lean = gs_knob("GS_MM64_LEAN") != nullptr;          // (measurement build: the round-5 candidate)
+    if (lean) {
+#define GS_MM64_GO(KS, CHV)                                                                                           \
+    GS_LAUNCH((mm64_kernel<KS, CHV, true>), grid, dim3(256), 0, stream, M, N, K, A, a_i, a_t, B, b_t, b_j, C, ldc, alpha, \
+              beta, kchunk, ntc, nrl, epi)
+        if (ksplit) {
+            if (kchunk <= 128)
+                GS_MM64_GO(true, 32);
+            else
+                GS_MM64_GO(true, 128);
+        } else {
+            if (kchunk <= 32)
+                GS_MM64_GO(false, 32);
+            else
+                GS_MM64_GO(false, 128);
+        }
+#undef GS_MM64_GO
+        return;
+    }
     if (ksplit) {
         if (kchunk <= 128)
             GS_LAUNCH((mm64_kernel<true, 32>), grid, dim3(256), 0, stream, M, N, K, A, a_i, a_t, B, b_t, b_j, C, ldc, alpha,
