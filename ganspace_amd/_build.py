@@ -25,7 +25,7 @@ MEASURE_LIBDIR = os.path.join(PKG, "lib_measure")    # -DGS_MEASURE_BUILD: the A
 
 
 # kernels whose build fails if the register allocator gives them scratch (mangled-name substrings)
-NO_SCRATCH = re.compile(r"gram_|rowgram|tn_gemm|tn_rows|linear_act|mm64_|chol_inv|jacobi_lds|tridiag")
+NO_SCRATCH = re.compile(r"gram_|rowgram|tn_gemm|tn_rows|linear_act|project_rows|ss_build|mm64_|chol_inv|jacobi_lds|tridiag")
 
 
 def _kernel_usage(remarks: str) -> dict:

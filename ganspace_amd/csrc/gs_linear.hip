@@ -124,6 +124,133 @@ __global__ __launch_bounds__(256, 2) void linear_act_kernel(
     }
 }
 
+// ---- projection of centred rows onto a few directions: out = ((X - shift) C^T) * colscale -----------------------
+// The regression back to latent space (reference decomposition.py:110-118: `(act - mean) @ comp.T / stdev`) multiplies a
+// [B, d] activation batch by k <= 128 directions: ONE column tile, so the 128 x 128 tiling above gives ceil(B / 128)
+// workgroups (16 at B = 2000) that each walk all d columns - 3.4 ms per cfg3 mini-batch, on 6 % of the chip.  Here the
+// feature range is cut into slices (blockIdx.y), every workgroup multiplies one 128-row tile by one slice and leaves
+// its float32 partial tile in scratch; project_reduce_kernel adds the slices in float64, scales the columns and writes
+// straight into the caller's [A|Z] staging rows (leading dimension ldo).  The centring happens while a tile is
+// staged (the reference's order: centre first, then multiply - no second copy of the batch), same k-ordered fma
+// chains within a slice as linear_act_kernel.
+__global__ __launch_bounds__(256, 2) void project_rows_kernel(const float *__restrict__ X, int64_t ldx, int64_t M,
+                                                              const float *__restrict__ C, int N, int K,
+                                                              const float *__restrict__ shift, float *__restrict__ part,
+                                                              int kchunk, int64_t Mp, int Np) {
+    __shared__ float lds[2][2][kLK][kLP];
+    const int ntn = Np / kLT;
+    const int64_t tm = blockIdx.x / ntn;
+    const int tn = blockIdx.x % ntn;
+    const int64_t m0 = tm * kLT;
+    const int n0 = tn * kLT;
+    const int k_begin = blockIdx.y * kchunk;
+    const int k_end = k_begin + kchunk < K ? k_begin + kchunk : K;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wi = wave >> 1, wj = wave & 1;
+    const int k4 = tid & 7, r8 = tid >> 3;
+
+    float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3, sh;
+    // rows past M / N and columns past the slice are read at clamped addresses (no select on a loaded value: it would
+    // serialise the loads) and multiplied by zero: a column past k_end gets a zero C entry, a row past M is never stored
+#define GS_PR_FETCH1(i, kc)                                                                                     \
+    {                                                                                                           \
+        const int64_t rx_ = m0 + r8 + 32 * (i);                                                                 \
+        const int rc_ = n0 + r8 + 32 * (i);                                                                     \
+        ra##i = *reinterpret_cast<const float4 *>(X + (rx_ < M ? rx_ : M - 1) * ldx + (kc));                    \
+        rb##i = *reinterpret_cast<const float4 *>(C + (int64_t)(rc_ < N ? rc_ : N - 1) * K + (kc));             \
+    }
+#define GS_PR_FETCH(k0)                                                                                         \
+    {                                                                                                           \
+        const int kk_ = (k0) + k4 * 4;                                                                          \
+        const int kc_ = kk_ < k_end ? kk_ : k_begin;                                                            \
+        GS_PR_FETCH1(0, kc_) GS_PR_FETCH1(1, kc_) GS_PR_FETCH1(2, kc_) GS_PR_FETCH1(3, kc_)                     \
+        sh = shift ? *reinterpret_cast<const float4 *>(shift + kc_) : make_float4(0.f, 0.f, 0.f, 0.f);          \
+    }
+#define GS_PR_STASH1(i, buf, mk, mb)                                                    \
+    {                                                                                   \
+        const int r_ = r8 + 32 * (i);                                                   \
+        lds[buf][0][k4 * 4 + 0][r_] = ra##i.x - sh.x;                                   \
+        lds[buf][0][k4 * 4 + 1][r_] = ra##i.y - sh.y;                                   \
+        lds[buf][0][k4 * 4 + 2][r_] = ra##i.z - sh.z;                                   \
+        lds[buf][0][k4 * 4 + 3][r_] = ra##i.w - sh.w;                                   \
+        const float m_ = (mk) * (mb)[i];                                                \
+        lds[buf][1][k4 * 4 + 0][r_] = rb##i.x * m_;                                     \
+        lds[buf][1][k4 * 4 + 1][r_] = rb##i.y * m_;                                     \
+        lds[buf][1][k4 * 4 + 2][r_] = rb##i.z * m_;                                     \
+        lds[buf][1][k4 * 4 + 3][r_] = rb##i.w * m_;                                     \
+    }
+#define GS_PR_STASH(buf, k0)                                                            \
+    {                                                                                   \
+        const float mk_ = ((k0) + k4 * 4 < k_end) ? 1.f : 0.f;                          \
+        GS_PR_STASH1(0, buf, mk_, rowok) GS_PR_STASH1(1, buf, mk_, rowok)               \
+        GS_PR_STASH1(2, buf, mk_, rowok) GS_PR_STASH1(3, buf, mk_, rowok)               \
+    }
+    float rowok[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) rowok[i] = (n0 + r8 + 32 * i < N) ? 1.f : 0.f;
+
+    f32x16 acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};
+    const int nst = k_end > k_begin ? (k_end - k_begin + kLK - 1) / kLK : 0;
+    const int arow = lane >> 5;
+    const int acol = wi * 64 + (lane & 31), bcol = wj * 64 + (lane & 31);
+    if (nst > 0) {
+        GS_PR_FETCH(k_begin)
+        GS_PR_STASH(0, k_begin)
+    }
+    __syncthreads();
+    for (int s = 0; s < nst; ++s) {
+        const int buf = s & 1;
+        const int knext = k_begin + (s + 1 < nst ? s + 1 : s) * kLK;
+        GS_PR_FETCH(knext)
+        __builtin_amdgcn_sched_barrier(0);          // (loads before the stage's MFMAs)
+        const float *A = &lds[buf][0][0][0];
+        const float *B = &lds[buf][1][0][0];
+#pragma unroll
+        for (int k = 0; k < kLK; k += 2) {
+            const float a0 = A[(k + arow) * kLP + acol];
+            const float a1 = A[(k + arow) * kLP + acol + 32];
+            const float b0 = B[(k + arow) * kLP + bcol];
+            const float b1 = B[(k + arow) * kLP + bcol + 32];
+            acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc00, 0, 0, 0);
+            acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc01, 0, 0, 0);
+            acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc10, 0, 0, 0);
+            acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc11, 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // (past the last stage the last stage is stashed once more into the buffer nobody reads any more)
+        GS_PR_STASH(buf ^ 1, knext)
+        __syncthreads();
+    }
+#undef GS_PR_FETCH
+#undef GS_PR_FETCH1
+#undef GS_PR_STASH
+#undef GS_PR_STASH1
+    float *out = part + (int64_t)blockIdx.y * Mp * Np;
+    const int col0 = n0 + wj * 64 + (lane & 31);
+    const int64_t row_base = m0 + wi * 64 + 4 * (lane >> 5);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int64_t row = row_base + (r & 3) + 8 * (r >> 2);
+        out[row * Np + col0] = acc00[r];
+        out[row * Np + col0 + 32] = acc01[r];
+        out[(row + 32) * Np + col0] = acc10[r];
+        out[(row + 32) * Np + col0 + 32] = acc11[r];
+    }
+}
+
+__global__ __launch_bounds__(256) void project_reduce_kernel(const float *__restrict__ part, int splits, int64_t Mp, int Np,
+                                                             int64_t M, int N, const float *__restrict__ colscale,
+                                                             float *__restrict__ out, int64_t ldo) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int col = (int)(e % Np);
+    const int64_t row = e / Np;
+    if (row >= M || col >= N) return;
+    double s = 0.0;
+    for (int c = 0; c < splits; ++c) s += (double)part[((int64_t)c * Mp + row) * Np + col];
+    out[row * ldo + col] = (float)(colscale ? s * (double)colscale[col] : s);
+}
+
 // ---- fast path: whole K steps, whole N tiles, 16-byte aligned rows ---------------------------------------------
 // Same arithmetic order per output element as linear_act_kernel (a k-ordered fma chain), restructured the way the
 // Gram kernel was (gs_gram.hip):
@@ -372,6 +499,16 @@ static int launch_linear(const float *x, const float *W, const float *b, float *
     return GS_OK;
 }
 
+// slices of the feature range for project_rows_kernel: enough workgroups for two per CU, at least 1024 columns each
+static int project_splits(int64_t rows, int directions, int features) {
+    const int64_t tiles = ceil_div(rows > 0 ? rows : 1, kLT) * ceil_div(directions, kLT);
+    int64_t s = ceil_div(512, tiles);
+    const int64_t cap = features / 1024 > 0 ? features / 1024 : 1;
+    if (s > cap) s = cap;
+    if (s > 64) s = 64;
+    return (int)(s < 1 ? 1 : s);
+}
+
 }  // namespace gs
 
 using namespace gs;
@@ -388,6 +525,44 @@ int gs_linear_forward(const float *x, const float *W, const float *b, float *y, 
     if (rows == 0) return GS_OK;
     return launch_linear(x, W, b, y, rows, out_features, in_features, 1.f, 1.f, 0.f, 1.f, 0,
                          (hipStream_t)stream);
+}
+
+int gs_project_rows_nbytes(int64_t rows, int directions, int features, int64_t *nbytes) {
+    GS_REQUIRE(nbytes && rows >= 0 && directions >= 1 && features >= 4, GS_EINVAL, "gs_project_rows_nbytes: bad argument");
+    const int64_t Mp = round_up(rows > 0 ? rows : 1, kLT);
+    const int Np = (int)round_up(directions, kLT);
+    *nbytes = (int64_t)sizeof(float) * project_splits(rows, directions, features) * Mp * Np;
+    return GS_OK;
+}
+
+int gs_project_rows(const float *x, int64_t ldx, int64_t rows, int features, const float *shift, const float *dirs,
+                    int directions, const float *colscale, float *out, int64_t ldo, void *scratch, int64_t scratch_bytes,
+                    void *stream_) {
+    GS_REQUIRE(x && dirs && out && scratch, GS_EINVAL, "gs_project_rows: NULL argument");
+    GS_REQUIRE(rows >= 0 && directions >= 1 && features >= 4 && features % 4 == 0 && ldx % 4 == 0 && ldx >= features &&
+                   ldo >= directions,
+               GS_EINVAL, "gs_project_rows: features and ldx must be positive multiples of 4, ldo >= directions");
+    GS_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dirs) | reinterpret_cast<uintptr_t>(shift)) &
+                15) == 0,
+               GS_EINVAL, "gs_project_rows: x, shift and dirs must be 16-byte aligned");
+    if (rows == 0) return GS_OK;
+    hipStream_t stream = (hipStream_t)stream_;
+    const int splits = project_splits(rows, directions, features);
+    const int64_t Mp = round_up(rows, kLT);
+    const int Np = (int)round_up(directions, kLT);
+    GS_REQUIRE(scratch_bytes >= (int64_t)sizeof(float) * splits * Mp * Np, GS_EINVAL,
+               "gs_project_rows: scratch smaller than gs_project_rows_nbytes");
+    const int kchunk = (int)round_up(ceil_div(features, splits), kLK);
+    const int64_t tiles = (Mp / kLT) * (Np / kLT);
+    GS_REQUIRE(tiles < 2147483647, GS_EINVAL, "gs_project_rows: grid too large");
+    float *part = static_cast<float *>(scratch);
+    hipLaunchKernelGGL(project_rows_kernel, dim3((unsigned)tiles, (unsigned)splits), dim3(256), 0, stream, x, ldx, rows, dirs,
+                       directions, features, shift, part, kchunk, Mp, Np);
+    const int64_t elems = rows * Np;
+    hipLaunchKernelGGL(project_reduce_kernel, dim3((unsigned)ceil_div(elems, 256)), dim3(256), 0, stream, part, splits, Mp,
+                       Np, rows, directions, colscale, out, ldo);
+    GS_HIP_CHECK(hipGetLastError());
+    return GS_OK;
 }
 
 int gs_mapping_forward(const float *z, float *w, float *scratch, const float *weights, const float *bias,

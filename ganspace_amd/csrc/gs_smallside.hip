@@ -13,8 +13,8 @@
 //     S' = sqrt(w_k),  rows sign-fixed (svd_flip, extmath.py:943-951)
 //
 // M is materialised once per block in HBM (1.09 GB at r = 2081, d = 131 072: 288 GB of HBM make
-// that the simple choice), K-blocked ([d / 32][rp][32], see mblk()), and streamed: once for T (row
-// panels re-read through L2/MALL), once for V'.
+// that the simple choice), panel-blocked ([d / 32][rp / 128][8][128][4], see mpan()), and streamed: once for T (LDS-DMA,
+// row panels re-read through L2/MALL), once for V'.
 #include <cstdlib>
 #include <vector>
 
@@ -26,17 +26,21 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 
 constexpr int kRT = 128;  // output tile
 constexpr int kRK = 32;   // K step (columns of M)
-constexpr int kRP = kRT + 1;
 constexpr int kFlushStages = 32;  // float64 carry every 32 * 32 = 1024 columns
 
-// M is stored K-BLOCKED: [d / 32][rp][32] - the 32 columns of a block for all rp rows are contiguous (128 B per row,
-// rows 128 B apart).  A stage of the T = M M^T kernels (128 rows x 32 columns of a panel) is then ONE contiguous
-// 16 KB run instead of 128 lines that lie a whole row (up to 512 KB) apart: with the row-major layout every 128-byte
-// line came from a different DRAM page and TLB entry, and the kernels ran at ~2.7 TB/s of L2 -> CU traffic whatever
-// the matrix-pipe work (the split-bf16 contraction measured no faster than the f32 one).  `ldm` below is rp.
-__device__ __forceinline__ int64_t mblk(int64_t row, int64_t col, int64_t rp) {
-    return ((col >> 5) * rp + row) * 32 + (col & 31);
+// M is stored PANEL-BLOCKED: [d / 32 K-blocks][rp / 128 panels][8 k-quads][128 rows][4 floats].  One (K-block, panel)
+// unit - 128 rows x 32 columns, 16 KB - is contiguous and already IS the LDS image the T = M M^T kernel multiplies
+// from: a stage of that kernel is two straight 16 KB copies done by the LDS-DMA path (global_load_lds_dwordx4: no
+// staging registers, no ds_write), and a lane's MFMA operands for four consecutive k come back as one ds_read_b128
+// (sixteen consecutive rows of one k-quad cover the 64 banks exactly once).  History: row-major M made every 128-byte
+// line of a stage come from a different DRAM page (~2.7 TB/s of L2 -> CU traffic whatever the matrix-pipe work); the
+// K-blocked [d / 32][rp][32] layout of rounds 3-4 fixed that but needed 32 scalar ds_write per thread and stage for the
+// transposed image - with one wave per SIMD the matrix pipe idled through all of it (0.535 of the f32 peak).
+__device__ __forceinline__ int64_t mpan(int64_t row, int64_t col, int64_t npan) {
+    return ((((col >> 5) * npan + (row >> 7)) * 8 + ((col >> 2) & 7)) * 128 + (row & 127)) * 4 + (col & 3);
 }
+constexpr int kUnitBytes = kRT * kRK * 4;       // 16 KB
+constexpr int kStageBytes = 2 * kUnitBytes;     // panel A | panel B
 
 __device__ __forceinline__ void decode_upper2(int idx, int T, int &I, int &J) {
     int i = 0, len = T;
@@ -51,10 +55,9 @@ __device__ __forceinline__ void decode_upper2(int idx, int T, int &I, int &J) {
 
 // ---- T partials: slab[s][rp][rp] (float64, upper macro tiles) = M[:, Ks] M[:, Ks]^T ----------------
 // Workgroup -> (split, tile): block b runs on XCD b % 8 (observed placement, used for speed only), so the blocks of
-// one XCD are given CONSECUTIVE entries of `order`, which lists the upper-triangle tiles in 4 x 4 blocks: the ~32
-// workgroups resident on an XCD then work on 2 such blocks = 16 panels instead of 64, and walk the same columns
-// of them at the same time - their panel stages hit in that XCD's L2 (measured before: 26 % L2 hit rate, 7.2 GB of
-// fabric traffic per launch for a 1.09 GB matrix).
+// one XCD are given CONSECUTIVE entries of `order`, which lists the upper-triangle tiles in 4 x 4 blocks: the
+// workgroups resident on an XCD then work on a few such blocks and walk the same columns of them at the same time -
+// their panel stages hit in that XCD's L2.
 __device__ __forceinline__ bool rowgram_assign(const int2 *__restrict__ order, int nmt, int total, int &split, int &I,
                                                int &J) {
     const int per = (total + 7) >> 3;
@@ -67,226 +70,139 @@ __device__ __forceinline__ bool rowgram_assign(const int2 *__restrict__ order, i
     return true;
 }
 
-__global__ __launch_bounds__(256, 1) void rowgram_kernel(const float *__restrict__ M, int64_t d, int64_t ldm,
-                                                         double *__restrict__ slab, int rp, int nmt, int T,
-                                                         int64_t kchunk, const int2 *__restrict__ order, int total) {
-    __shared__ float lds[2][2][kRK][kRP];
+typedef __attribute__((address_space(3))) void ss_lds_void;
+typedef __attribute__((address_space(1))) void ss_glb_void;
+using f32x4v = __attribute__((ext_vector_type(4))) float;
+
+// The fragment reads are inline assembly on purpose: the compiler orders every ds_read it knows about behind ALL
+// outstanding LDS-DMA of the same array (s_waitcnt vmcnt(0)) - i.e. behind the stage that was requested a moment ago for
+// the NEXT iteration - while the only ordering this pipeline needs is the explicit `s_waitcnt vmcnt(0); s_barrier` at the
+// top of a stage.  GS_DSR128 issues a read, GS_DSWAIT4 waits for the LDS queue and ties the four registers to the wait.
+#define GS_DSR128(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+#define GS_DSWAIT4(a, b, c, e) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(e))
+
+// PROBE (measurement build only): 0 = the kernel; 1 = no DMA after the first stage (matrix pipe + LDS reads alone);
+// 2 = no MFMA (DMA + barriers alone)
+template <int PROBE>
+__global__ __launch_bounds__(256, 2) void rowgram_dma_kernel(const float *__restrict__ M, int64_t d, int npan,
+                                                             double *__restrict__ slab, int rp, int nmt,
+                                                             int64_t kchunk, const int2 *__restrict__ order, int total) {
+    // ring of two stages; stage = [panel A | panel B][8 k-quads][128 rows][16 B]
+    __shared__ __attribute__((aligned(1024))) unsigned char ring[2 * kStageBytes];
     int split, I, J;
     if (!rowgram_assign(order, nmt, total, split, I, J)) return;
     const bool diag = (I == J);
     const int64_t k_begin = (int64_t)split * kchunk;
     const int64_t k_end = (k_begin + kchunk < d) ? k_begin + kchunk : d;
+    // (columns d .. round_up(d, 32) of M are zero: allocated zeroed, never written - a partial last K-block needs no mask)
+    const int nst = k_end > k_begin ? (int)((k_end - k_begin + kRK - 1) / kRK) : 0;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wi = wave >> 1, wj = wave & 1;
-    const int k4 = tid & 7, r8 = tid >> 3;
-    const int64_t rowA = (int64_t)I * kRT, rowB = (int64_t)J * kRT;
+    const int half = lane >> 5, l31 = lane & 31;
 
-    // Loads are issued at CLAMPED addresses and nothing looks at the loaded values until stash(): a select on a
-    // value just loaded (masking the tail here) makes the compiler wait for every single load (s_waitcnt vmcnt(0)
-    // after each one - the kernel then runs at one L2/HBM round trip per 16 bytes per thread).
-    float4 ra[4], rb[4];
-    auto fetch = [&](int64_t k0) {
-        const int64_t kk = k0 + k4 * 4;
-        const int64_t kc = kk < k_end ? kk : k_begin;   // d % 4 == 0 is required by the caller
+    // DMA: a unit is sixteen 1 KB pieces; wave w moves pieces 4 w .. 4 w + 3 of each panel.  Source = unit base (uniform,
+    // advances by npan units per stage) + this lane's 16 bytes; destination = M0 base (uniform) + lane * 16 (implicit).
+    const int64_t kb0 = k_begin >> 5;
+    const char *srcA = reinterpret_cast<const char *>(M) + ((kb0 * npan + I) * (int64_t)kUnitBytes) + wave * 4096 + lane * 16;
+    const char *srcB = reinterpret_cast<const char *>(M) + ((kb0 * npan + J) * (int64_t)kUnitBytes) + wave * 4096 + lane * 16;
+    const int64_t kbstride = (int64_t)npan * kUnitBytes;
+    auto issue = [&](int s) {
+        unsigned char *dst = ring + (s & 1) * kStageBytes + wave * 4096;
+        const char *a = srcA + (int64_t)s * kbstride;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            // both panels unconditionally (a diagonal tile reads its panel twice - L1 hits): a branch around a load
-            // makes the compiler's s_waitcnt placement pessimistic for every load after the join
-            ra[i] = *reinterpret_cast<const float4 *>(M + mblk(rowA + r8 + 32 * i, kc, ldm));
-            rb[i] = *reinterpret_cast<const float4 *>(M + mblk(rowB + r8 + 32 * i, kc, ldm));
-        }
-    };
-    auto stash = [&](int buf, int64_t k0) {
-        const bool ok = k0 + k4 * 4 < k_end;
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_global_load_lds((ss_glb_void *)(uintptr_t)(a + i * 1024),
+                                             (ss_lds_void *)(uint32_t)(uintptr_t)(dst + i * 1024), 16, 0, 0);
+        if (!diag) {
+            const char *b = srcB + (int64_t)s * kbstride;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int r = r8 + 32 * i;
-            lds[buf][0][k4 * 4 + 0][r] = ok ? ra[i].x : 0.f;
-            lds[buf][0][k4 * 4 + 1][r] = ok ? ra[i].y : 0.f;
-            lds[buf][0][k4 * 4 + 2][r] = ok ? ra[i].z : 0.f;
-            lds[buf][0][k4 * 4 + 3][r] = ok ? ra[i].w : 0.f;
-            if (!diag) {
-                lds[buf][1][k4 * 4 + 0][r] = ok ? rb[i].x : 0.f;
-                lds[buf][1][k4 * 4 + 1][r] = ok ? rb[i].y : 0.f;
-                lds[buf][1][k4 * 4 + 2][r] = ok ? rb[i].z : 0.f;
-                lds[buf][1][k4 * 4 + 3][r] = ok ? rb[i].w : 0.f;
-            }
+            for (int i = 0; i < 4; ++i)
+                __builtin_amdgcn_global_load_lds((ss_glb_void *)(uintptr_t)(b + i * 1024),
+                                                 (ss_lds_void *)(uint32_t)(uintptr_t)(dst + kUnitBytes + i * 1024), 16, 0, 0);
         }
     };
 
-    f32x16 acc[4] = {{0}, {0}, {0}, {0}};
+    f32x16 acc0 = {0}, acc1 = {0}, acc2 = {0}, acc3 = {0};
     double acc64[4][16];
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc64[a][r] = 0.0;
 
-    const int nst = (int)((k_end - k_begin + kRK - 1) / kRK);
-    const int arow = lane >> 5;
-    const int acol = wi * 64 + (lane & 31), bcol = wj * 64 + (lane & 31);
-    if (nst > 0) {
-        fetch(k_begin);
-        stash(0, k_begin);
+    // fragment addresses (bytes in LDS): k-quad 2 g + half of rows wi * 64 + l31 (+ 32) resp. wj * 64 + l31 (+ 32); lanes
+    // 0-31 multiply k = 8 g + e, lanes 32-63 k = 8 g + 4 + e in the e-th MFMA of a group (the same choice for both operands)
+    const unsigned ring0 = (unsigned)(uintptr_t)ring;
+    const unsigned abase = ring0 + half * 2048 + (wi * 64 + l31) * 16;
+    const unsigned bbase = ring0 + (diag ? 0 : kUnitBytes) + half * 2048 + (wj * 64 + l31) * 16;
+
+#define GS_RG_READ(pa0, pa1, pb0, pb1, g)                 \
+    GS_DSR128(pa0, aaddr, (g) * 4096);                    \
+    GS_DSR128(pa1, aaddr, (g) * 4096 + 512);              \
+    GS_DSR128(pb0, baddr, (g) * 4096);                    \
+    GS_DSR128(pb1, baddr, (g) * 4096 + 512);
+#define GS_RG_STEP(pa0, pa1, pb0, pb1, e)                                          \
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(pa0.e, pb0.e, acc0, 0, 0, 0);      \
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(pa0.e, pb1.e, acc1, 0, 0, 0);      \
+    acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(pa1.e, pb0.e, acc2, 0, 0, 0);      \
+    acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(pa1.e, pb1.e, acc3, 0, 0, 0);
+#define GS_RG_MMA(pa0, pa1, pb0, pb1)                                              \
+    if (PROBE != 2) {                                                              \
+        GS_RG_STEP(pa0, pa1, pb0, pb1, x)                                          \
+        GS_RG_STEP(pa0, pa1, pb0, pb1, y)                                          \
+        GS_RG_STEP(pa0, pa1, pb0, pb1, z)                                          \
+        GS_RG_STEP(pa0, pa1, pb0, pb1, w)                                          \
     }
-    __syncthreads();
+
+    if (nst > 0) issue(0);
     for (int s = 0; s < nst; ++s) {
-        const int buf = s & 1;
-        fetch(k_begin + (int64_t)(s + 1 < nst ? s + 1 : s) * kRK);      // unconditional (clamped): no branch around loads
-        // the loads go out BEFORE the stage's MFMAs: left to itself the scheduler sinks them behind 56 of the 64 MFMAs
-        // (ISA, round 4), and stash() then waits for memory with the matrix pipe idle
+        // stage s has landed (this wave's pieces: vmcnt; everybody's: the barrier) and every wave is done reading stage
+        // s - 1, whose slot the next request overwrites
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        const unsigned aaddr = abase + (s & 1) * kStageBytes, baddr = bbase + (s & 1) * kStageBytes;
+        f32x4v p0, p1, p2, p3, q0, q1, q2, q3;
+        GS_RG_READ(p0, p1, p2, p3, 0)                       // (its LDS round trip hides behind the address arithmetic of the DMA)
         __builtin_amdgcn_sched_barrier(0);
-        const float *A = &lds[buf][0][arow][acol];
-        const float *B = &lds[buf][diag ? 0 : 1][arow][bcol];
-#pragma unroll
-        for (int k = 0; k < kRK; k += 2) {
-            const float a0 = A[k * kRP], a1 = A[k * kRP + 32];
-            const float b0 = B[k * kRP], b1 = B[k * kRP + 32];
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[1], 0, 0, 0);
-            acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[2], 0, 0, 0);
-            acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[3], 0, 0, 0);
-        }
+        if (s + 1 < nst && (PROBE != 1)) issue(s + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        // group g + 1's operands are requested BEFORE group g's sixteen MFMAs (scheduling barriers: left alone the
+        // compiler sinks the volatile reads behind the MFMAs and reuses the registers - an LDS round trip per group with
+        // the matrix pipe idle)
+        GS_DSWAIT4(p0, p1, p2, p3);
+        GS_RG_READ(q0, q1, q2, q3, 1)
+        __builtin_amdgcn_sched_barrier(0);
+        GS_RG_MMA(p0, p1, p2, p3)
+        __builtin_amdgcn_sched_barrier(0);
+        GS_DSWAIT4(q0, q1, q2, q3);
+        GS_RG_READ(p0, p1, p2, p3, 2)
+        __builtin_amdgcn_sched_barrier(0);
+        GS_RG_MMA(q0, q1, q2, q3)
+        __builtin_amdgcn_sched_barrier(0);
+        GS_DSWAIT4(p0, p1, p2, p3);
+        GS_RG_READ(q0, q1, q2, q3, 3)
+        __builtin_amdgcn_sched_barrier(0);
+        GS_RG_MMA(p0, p1, p2, p3)
+        __builtin_amdgcn_sched_barrier(0);
+        GS_DSWAIT4(q0, q1, q2, q3);
+        GS_RG_MMA(q0, q1, q2, q3)
         if ((s + 1) % kFlushStages == 0 || s + 1 == nst) {
             // float64 carry: bounds every float32 fma chain to 1024 products
 #pragma unroll
-            for (int a = 0; a < 4; ++a) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    acc64[a][r] += (double)acc[a][r];
-                    acc[a][r] = 0.f;
-                }
+            for (int r = 0; r < 16; ++r) {
+                acc64[0][r] += (double)acc0[r];
+                acc64[1][r] += (double)acc1[r];
+                acc64[2][r] += (double)acc2[r];
+                acc64[3][r] += (double)acc3[r];
+                acc0[r] = 0.f;
+                acc1[r] = 0.f;
+                acc2[r] = 0.f;
+                acc3[r] = 0.f;
             }
         }
-        if (s + 1 < nst) stash(buf ^ 1, k_begin + (int64_t)(s + 1) * kRK);
-        __syncthreads();
     }
-    double *out = slab + (int64_t)split * rp * rp;
-    const int row_base = I * kRT + wi * 64 + 4 * (lane >> 5);
-    const int col_base = J * kRT + wj * 64 + (lane & 31);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int row = row_base + (r & 3) + 8 * (r >> 2);
-        out[(int64_t)row * rp + col_base] = acc64[0][r];
-        out[(int64_t)row * rp + col_base + 32] = acc64[1][r];
-        out[(int64_t)(row + 32) * rp + col_base] = acc64[2][r];
-        out[(int64_t)(row + 32) * rp + col_base + 32] = acc64[3][r];
-    }
-}
-
-// ---- candidate for round 5 (measurement build only: GS_ROWGRAM_RK=1): the same kernel with the LDS image in the layout
-// the K-blocked M already has - [row][32 k, padded to 36 floats] instead of the transposed [k][row].  A stage is then
-// staged by eight 16-byte LDS writes per thread (32 scalar ones now) and the MFMA operands are read as four
-// ds_read_b128 per group of 8 k values (sixteen ds_read_b32 pairs now): lanes 0-31 take k = 8 g + e, lanes 32-63
-// k = 8 g + 4 + e for the e-th of the group's four MFMAs - any assignment of k values to the two halves works as long as
-// both operands use the same one.  Row stride 144 B: sixteen consecutive rows of a b128 access cover the 64 banks
-// exactly once.  Same decomposition, same float64 carry, same output as rowgram_kernel; written after round 4's GPU
-// budget was spent - NOT run yet.
-constexpr int kRKP = kRK + 4;
-
-__global__ __launch_bounds__(256, 1) void rowgram_rk_kernel(const float *__restrict__ M, int64_t d, int64_t ldm,
-                                                            double *__restrict__ slab, int rp, int nmt, int T,
-                                                            int64_t kchunk, const int2 *__restrict__ order, int total) {
-    __shared__ __attribute__((aligned(16))) float lds[2][2][kRT][kRKP];
-    int split, I, J;
-    if (!rowgram_assign(order, nmt, total, split, I, J)) return;
-    const bool diag = (I == J);
-    const int64_t k_begin = (int64_t)split * kchunk;
-    const int64_t k_end = (k_begin + kchunk < d) ? k_begin + kchunk : d;
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wi = wave >> 1, wj = wave & 1;
-    const int k4 = tid & 7, r8 = tid >> 3;
-    const int64_t rowA = (int64_t)I * kRT, rowB = (int64_t)J * kRT;
-
-    // (named registers and macros, not arrays captured by lambdas: those were materialised in 160 B of scratch here)
-    float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
-#define GS_RK_FETCH1(i, kc)                                                                        \
-    ra##i = *reinterpret_cast<const float4 *>(M + mblk(rowA + r8 + 32 * (i), (kc), ldm));          \
-    rb##i = *reinterpret_cast<const float4 *>(M + mblk(rowB + r8 + 32 * (i), (kc), ldm));
-#define GS_RK_FETCH(k0)                                                                            \
-    {                                                                                              \
-        const int64_t kk_ = (k0) + k4 * 4;                                                         \
-        const int64_t kc_ = kk_ < k_end ? kk_ : k_begin; /* d % 4 == 0 is required by the caller */ \
-        GS_RK_FETCH1(0, kc_) GS_RK_FETCH1(1, kc_) GS_RK_FETCH1(2, kc_) GS_RK_FETCH1(3, kc_)        \
-    }
-#define GS_RK_STASH1(i, buf, mk)                                                                   \
-    {                                                                                              \
-        float4 va_ = ra##i, vb_ = rb##i;                                                           \
-        va_.x *= (mk), va_.y *= (mk), va_.z *= (mk), va_.w *= (mk);                                \
-        vb_.x *= (mk), vb_.y *= (mk), vb_.z *= (mk), vb_.w *= (mk);                                \
-        *reinterpret_cast<float4 *>(&lds[buf][0][r8 + 32 * (i)][k4 * 4]) = va_;                    \
-        *reinterpret_cast<float4 *>(&lds[buf][1][r8 + 32 * (i)][k4 * 4]) = vb_;                    \
-    }
-#define GS_RK_STASH(buf, k0)                                                                       \
-    {                                                                                              \
-        float mk_ = ((k0) + k4 * 4 < k_end) ? 1.f : 0.f;                                           \
-        /* opaque and ordered behind the scheduling barrier: a plain multiply by the mask is placed right behind the \
-           loads (it is pure arithmetic: nothing orders it against the MFMAs), and the wait for memory with it */     \
-        asm volatile("" : "+v"(mk_));                                                              \
-        GS_RK_STASH1(0, buf, mk_) GS_RK_STASH1(1, buf, mk_) GS_RK_STASH1(2, buf, mk_) GS_RK_STASH1(3, buf, mk_) \
-    }
-
-    f32x16 acc[4] = {{0}, {0}, {0}, {0}};
-    double acc64[4][16];
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc64[a][r] = 0.0;
-
-    const int nst = (int)((k_end - k_begin + kRK - 1) / kRK);
-    const int half = lane >> 5;
-    const int arow = wi * 64 + (lane & 31), brow = wj * 64 + (lane & 31);
-    if (nst > 0) {
-        GS_RK_FETCH(k_begin)
-        GS_RK_STASH(0, k_begin)
-    }
-    __syncthreads();
-    for (int s = 0; s < nst; ++s) {
-        const int buf = s & 1;
-        GS_RK_FETCH(k_begin + (int64_t)(s + 1 < nst ? s + 1 : s) * kRK)
-        __builtin_amdgcn_sched_barrier(0);
-        const float *Ap = &lds[buf][0][arow][4 * half];
-        const float *Bp = &lds[buf][diag ? 0 : 1][brow][4 * half];
-#pragma unroll
-        for (int g = 0; g < kRK / 8; ++g) {
-            const float4 a0 = *reinterpret_cast<const float4 *>(Ap + 8 * g);
-            const float4 a1 = *reinterpret_cast<const float4 *>(Ap + 32 * kRKP + 8 * g);
-            const float4 b0 = *reinterpret_cast<const float4 *>(Bp + 8 * g);
-            const float4 b1 = *reinterpret_cast<const float4 *>(Bp + 32 * kRKP + 8 * g);
-#define GS_RK_STEP(e)                                                               \
-    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.e, b0.e, acc[0], 0, 0, 0);     \
-    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.e, b1.e, acc[1], 0, 0, 0);     \
-    acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.e, b0.e, acc[2], 0, 0, 0);     \
-    acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.e, b1.e, acc[3], 0, 0, 0);
-            GS_RK_STEP(x)
-            GS_RK_STEP(y)
-            GS_RK_STEP(z)
-            GS_RK_STEP(w)
-#undef GS_RK_STEP
-        }
-        // The stash follows the MFMAs in the SAME basic block, for both panels and every stage: with a branch between
-        // them (the float64 carry below, `s + 1 < nst`, `!diag`) the compiler sinks the LOADS into the block of their
-        // only use - behind the MFMAs, scheduling barrier or not.  Past the last stage the clamped stage is written once
-        // more into the buffer nobody reads any more; a diagonal tile writes a second panel it never reads.
-        __builtin_amdgcn_sched_barrier(0);
-        GS_RK_STASH(buf ^ 1, k_begin + (int64_t)(s + 1 < nst ? s + 1 : s) * kRK)
-        if ((s + 1) % kFlushStages == 0 || s + 1 == nst) {
-#pragma unroll
-            for (int a = 0; a < 4; ++a) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    acc64[a][r] += (double)acc[a][r];
-                    acc[a][r] = 0.f;
-                }
-            }
-        }
-        __syncthreads();
-    }
-#undef GS_RK_FETCH
-#undef GS_RK_FETCH1
-#undef GS_RK_STASH
-#undef GS_RK_STASH1
+#undef GS_RG_READ
+#undef GS_RG_STEP
+#undef GS_RG_MMA
     double *out = slab + (int64_t)split * rp * rp;
     const int row_base = I * kRT + wi * 64 + 4 * (lane >> 5);
     const int col_base = J * kRT + wj * 64 + (lane & 31);
@@ -302,8 +218,9 @@ __global__ __launch_bounds__(256, 1) void rowgram_rk_kernel(const float *__restr
 
 // ---- the same partial products on the bf16 matrix cores (opt-in: GS_PREC_BF16X6 / GS_PREC_BF16X3) -----------------
 // v_mfma_f32_32x32x16_bf16 wants 8 CONSECUTIVE k per lane for a fixed row of either operand - and both operands of
-// M M^T are rows of the row-major M, K-contiguous: no transpose anywhere (unlike X^T X, gs_gram_bf16.hip).  A thread
-// loads 8 consecutive floats of a row (two 16-byte loads; four threads cover a 128-byte line), splits them into
+// M M^T are rows of M, K-contiguous: no transpose anywhere (unlike X^T X, gs_gram_bf16.hip).  A thread
+// loads 8 consecutive floats of a row (two 16-byte pieces of the panel-blocked M; consecutive lanes take consecutive
+// rows = consecutive pieces), splits them into
 // bf16 planes  x = hi + mid (+ lo)  (each remainder exact in float32) and writes one 16-byte vector per plane into
 // the LDS image [plane][panel][row][32 k as bf16 = 64 B, padded to 80 B] (conflict-free 16-lane groups for both
 // ds_write_b128 and the ds_read_b128 fragment reads).  Products as in gs_gram_bf16.hip: six MFMAs rebuild x*y to
@@ -337,8 +254,8 @@ __device__ __forceinline__ void split8s(const float4 &lo4, const float4 &hi4, ui
 }
 
 template <int NPROD>
-__global__ __launch_bounds__(256, 1) void rowgram_bf16_kernel(const float *__restrict__ M, int64_t d, int64_t ldm,
-                                                              double *__restrict__ slab, int rp, int nmt, int T,
+__global__ __launch_bounds__(256, 1) void rowgram_bf16_kernel(const float *__restrict__ M, int64_t d, int npan,
+                                                              double *__restrict__ slab, int rp, int nmt,
                                                               int64_t kchunk, const int2 *__restrict__ order, int total) {
     constexpr int NPL = (NPROD == 3) ? 2 : 3;
     constexpr int kStage = NPL * 2 * kPanelB;            // [plane][panel A|B][128 rows][80 B]
@@ -352,7 +269,8 @@ __global__ __launch_bounds__(256, 1) void rowgram_bf16_kernel(const float *__res
     const int wi = wave >> 1, wj = wave & 1;
     const int64_t rowA = (int64_t)I * kRT, rowB = (int64_t)J * kRT;
 
-    // staging: item = (row, group of 8 columns); 512 items per panel and stage, two per thread.  With the matrix
+    // staging: item = (row, group of 8 columns), ROW fastest (consecutive lanes read consecutive 16-byte pieces of the
+    // panel-blocked M); 512 items per panel and stage, two per thread.  With the matrix
     // work this cheap a stage lasts ~0.6 us, far less than a trip to L2 / HBM: FOUR stages of loads stay in flight
     // (register ring of four fetch sets; one stage at a time was latency-bound - the split kernel measured no faster
     // than the f32 one).
@@ -364,7 +282,7 @@ __global__ __launch_bounds__(256, 1) void rowgram_bf16_kernel(const float *__res
     auto fetch = [&](FetchSet &f, int64_t k0) {
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
-            const int item = tid + 256 * g, row = item >> 2, kg = item & 3;
+            const int item = tid + 256 * g, row = item & 127, kg = item >> 7;
             const int64_t kk = k0 + kg * 8;
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
@@ -372,8 +290,8 @@ __global__ __launch_bounds__(256, 1) void rowgram_bf16_kernel(const float *__res
                 const int64_t ks = kc < k_end ? kc : k_begin;      // d % 4 == 0: a float4 is valid or not as a whole
                 // both panels unconditionally (a diagonal tile reads its panel twice - L1 hits): a branch around a
                 // load makes the compiler's s_waitcnt placement pessimistic for every load after the join
-                f.a[g][h] = *reinterpret_cast<const float4 *>(M + mblk(rowA + row, ks, ldm));
-                f.b[g][h] = *reinterpret_cast<const float4 *>(M + mblk(rowB + row, ks, ldm));
+                f.a[g][h] = *reinterpret_cast<const float4 *>(M + mpan(rowA + row, ks, npan));
+                f.b[g][h] = *reinterpret_cast<const float4 *>(M + mpan(rowB + row, ks, npan));
             }
         }
     };
@@ -383,7 +301,7 @@ __global__ __launch_bounds__(256, 1) void rowgram_bf16_kernel(const float *__res
     auto stash = [&](const FetchSet &f, int buf, int64_t k0) {
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
-            const int item = tid + 256 * g, row = item >> 2, kg = item & 3;
+            const int item = tid + 256 * g, row = item & 127, kg = item >> 7;
             const bool ok0 = k0 + kg * 8 < k_end, ok1 = k0 + kg * 8 + 4 < k_end;
             unsigned char *dst = rlds + buf * kStage + row * kRowBytes + kg * 16;
             uint4 pl[NPL];
@@ -506,11 +424,12 @@ __global__ void rowgram_fold_kernel(const double *__restrict__ slab, double *__r
     if (i < j) Tm[(int64_t)j * rp + i] = s;
 }
 
-// ---- out[kp x d] = Ct^T M   (Ct: [rp x kp] t-major coefficients, M: [rp x d]) -----------------------
-// Same operand pattern as the Gram kernel: contraction over ROWS of two row-major matrices, so both
-// MFMA operands are "row t, 32 consecutive columns" (coalesced reads, conflict-free ds_read_b32).
+// ---- out[kp x d] = Ct^T M   (Ct: [rp x kp] t-major coefficients, M: [rp x d] panel-blocked) ---------
+// Contraction over ROWS t: both MFMA operands are "row t, 32 consecutive columns" (conflict-free ds_read_b32).
+// Rows t >= r of Ct AND of M are zero (the coefficient kernels write 0 there / ss_build_kernel zero-fills up to rp), and
+// a stage never reaches past rp (a multiple of 128 >= r): no masks, no clamped rows, no select on a loaded value.
 __global__ __launch_bounds__(256, 2) void tn_gemm_kernel(const float *__restrict__ Ct, int kp,
-                                                         const float *__restrict__ M, int64_t d, int64_t ldm,
+                                                         const float *__restrict__ M, int64_t d, int npan,
                                                          int r, float *__restrict__ out, int64_t ldo) {
     __shared__ __attribute__((aligned(16))) float lds[2][2][32][kRT];
     const int64_t ntn = (d + kRT - 1) / kRT;
@@ -518,46 +437,54 @@ __global__ __launch_bounds__(256, 2) void tn_gemm_kernel(const float *__restrict
     const int64_t tj = blockIdx.x % ntn;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wi = wave >> 1, wj = wave & 1;
+    // A (coefficients, row-major [t][kp]): thread = (4 columns c4, rows rr + 8 i)
     const int c4 = tid & 31, rr = tid >> 5;
     const int colA = ti * kRT + c4 * 4;
-    const int64_t colB = tj * kRT + c4 * 4;
-    const bool okB = colB < d;
+    // B (M): thread = (row tl of the stage, k-quad kq of K-block 4 tj + i): consecutive lanes read consecutive 16-byte
+    // pieces (32 rows = 512 contiguous bytes per k-quad).  The image keeps [t][128 columns] with the column quads of
+    // row t XOR-ed by t & 7: the 16-byte writes of eight consecutive rows then cover the 32 banks once, and the 32
+    // consecutive columns an MFMA operand reads stay a permutation of quads inside their aligned group of 8.
+    const int tl = tid & 31, kq = tid >> 5;
+    const int64_t nkb = (d + 31) >> 5;
+    int64_t ub[4];      // K-block of piece i, clamped (columns >= d are never stored)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int64_t kb = tj * 4 + i;
+        ub[i] = (kb < nkb ? kb : nkb - 1) * npan;
+    }
+    const int sw = ((kq ^ (tl & 7)) << 2);
 
     // (named registers and macros instead of arrays captured by lambdas: the arrays were materialised in 80 B of scratch)
     float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
-    // rows t >= r of Ct are zero (the coefficient kernels write 0 there, the buffer is cleared per block): the product
-    // needs no mask, and no select on a freshly loaded value stalls the other loads
-#define GS_TN_FETCH1(i, t0)                                                                              \
-    {                                                                                                    \
-        const int t_ = (t0) + rr + 8 * (i);                                                              \
-        const int tc_ = t_ < r ? t_ : r - 1;                                                             \
-        ra##i = *reinterpret_cast<const float4 *>(Ct + (int64_t)(t_ < r ? t_ : r) * kp + colA);          \
-        rb##i = *reinterpret_cast<const float4 *>(M + mblk(tc_, okB ? colB : 0, ldm));                   \
-    }
+#define GS_TN_FETCH1(i, t0)                                                                                          \
+    ra##i = *reinterpret_cast<const float4 *>(Ct + (int64_t)((t0) + rr + 8 * (i)) * kp + colA);                      \
+    rb##i = *reinterpret_cast<const float4 *>(M + (((ub[i] + (((t0) + tl) >> 7)) * 8 + kq) * 128 + (((t0) + tl) & 127)) * 4);
 #define GS_TN_FETCH(t0) GS_TN_FETCH1(0, t0) GS_TN_FETCH1(1, t0) GS_TN_FETCH1(2, t0) GS_TN_FETCH1(3, t0)
 #define GS_TN_STASH1(i, buf)                                                        \
     *reinterpret_cast<float4 *>(&lds[buf][0][rr + 8 * (i)][c4 * 4]) = ra##i;        \
-    *reinterpret_cast<float4 *>(&lds[buf][1][rr + 8 * (i)][c4 * 4]) = rb##i;
+    *reinterpret_cast<float4 *>(&lds[buf][1][tl][32 * (i) + sw]) = rb##i;
 #define GS_TN_STASH(buf) GS_TN_STASH1(0, buf) GS_TN_STASH1(1, buf) GS_TN_STASH1(2, buf) GS_TN_STASH1(3, buf)
     f32x16 acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};
     const int nst = (r + 31) / 32;
     const int arow = lane >> 5;
     const int acol = wi * 64 + (lane & 31), bcol = wj * 64 + (lane & 31);
+    const int bq = bcol >> 2, be = bcol & 3;
     GS_TN_FETCH(0)
     GS_TN_STASH(0)
     __syncthreads();
     for (int s = 0; s < nst; ++s) {
         const int buf = s & 1;
-        // (unconditional: past the last stage the clamped rows are fetched again and stashed into the buffer nobody reads
-        //  any more)
-        GS_TN_FETCH((s + 1) * 32)
-        __builtin_amdgcn_sched_barrier(0);      // (loads before the MFMAs, as in rowgram_kernel)
+        // (unconditional: past the last stage the last stage is fetched again and stashed into the buffer nobody reads any
+        //  more - never a row >= rp)
+        GS_TN_FETCH((s + 1 < nst ? s + 1 : s) * 32)
+        __builtin_amdgcn_sched_barrier(0);      // (loads before the MFMAs)
         const float *A = &lds[buf][0][arow][acol];
-        const float *B = &lds[buf][1][arow][bcol];
+        const float *B = &lds[buf][1][arow][be];
 #pragma unroll
         for (int k = 0; k < 32; k += 2) {
+            const int bo = k * kRT + ((bq ^ ((k + arow) & 7)) << 2);
             const float a0 = A[k * kRT], a1 = A[k * kRT + 32];
-            const float b0 = B[k * kRT], b1 = B[k * kRT + 32];
+            const float b0 = B[bo], b1 = B[bo + 32];
             acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc00, 0, 0, 0);
             acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc01, 0, 0, 0);
             acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc10, 0, 0, 0);
@@ -588,41 +515,93 @@ __global__ __launch_bounds__(256, 2) void tn_gemm_kernel(const float *__restrict
 
 // ---- assembling M and the per-column statistics ------------------------------------------------------
 // rows [0,k): S_t V_t ; [k, k+m): X - bm ; k+m: mc ; beyond: zero.   vec = [bm | mc | delta] (float64)
+// Workgroup = one 128-row panel x kBuildKB K-blocks.  Reading wants consecutive lanes on consecutive COLUMNS (a row of
+// X / V is contiguous), the panel-blocked M wants them on consecutive ROWS (mpan()): each 128 x 32 unit is transposed
+// through LDS - thread (k-quad, row) reads 16 bytes, four rows each, writes them to the padded tile (9 pieces per
+// row: eight consecutive lanes cover the 32 banks once; sixteen consecutive rows of one k-quad cover the 64 banks once
+// on the way out) and the unit leaves as sixteen contiguous 1 KB stores.  Two tiles: one barrier per unit.
+constexpr int kBuildKB = 8;
 __global__ __launch_bounds__(256) void ss_build_kernel(const float *__restrict__ X, int64_t ldx, int m,
                                                        const float *__restrict__ V, const double *__restrict__ lam,
-                                                       const double *__restrict__ vec, int64_t d, int k, int rp, double n0,
+                                                       const double *__restrict__ vec, int64_t d, int k, int npan, double n0,
                                                        float *__restrict__ M, int w_state) {
-    // thread = 4 consecutive features of one row of M (d % 4 == 0, rows 16-byte aligned): 16-byte loads and stores; the 4
-    // features share a 32-column block of the K-blocked layout, so the store is one aligned float4
-    const int64_t j = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
-    const int t = blockIdx.y;
-    if (j >= d) return;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (t < k) {
-        // w_state: V already holds the rows whose Gram matrix is the truncated operator (W = Q^T M of the last block)
-        if (n0 > 0) {
-            v = *reinterpret_cast<const float4 *>(V + (int64_t)t * d + j);
-            if (!w_state) {
-                const double sq = sqrt(lam[t]);
-                v.x = (float)(sq * (double)v.x);
-                v.y = (float)(sq * (double)v.y);
-                v.z = (float)(sq * (double)v.z);
-                v.w = (float)(sq * (double)v.w);
+    __shared__ float4 tile[2][kRT * 9];
+    const int tid = threadIdx.x;
+    const int P = blockIdx.y;
+    const int kq = tid & 7, rl = tid >> 3;
+    const int64_t nkb = (d + 31) >> 5;
+    const int64_t kb_begin = (int64_t)blockIdx.x * kBuildKB;
+    // what the four rows of this thread hold
+    int kind[4];          // 0 zero, 1 state row, 2 data row, 3 mean-correction row
+    const float *src[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int t = P * kRT + rl + 32 * g;
+        kind[g] = 0;
+        src[g] = X;
+        if (t < k) {
+            if (n0 > 0) {
+                kind[g] = 1;
+                src[g] = V + (int64_t)t * d;
             }
+        } else if (t < k + m) {
+            kind[g] = 2;
+            src[g] = X + (int64_t)(t - k) * ldx;
+        } else if (t == k + m && n0 > 0) {
+            kind[g] = 3;
         }
-    } else if (t < k + m) {
-        const float4 x = *reinterpret_cast<const float4 *>(X + (int64_t)(t - k) * ldx + j);
-        v.x = (float)((double)x.x - vec[j]);
-        v.y = (float)((double)x.y - vec[j + 1]);
-        v.z = (float)((double)x.z - vec[j + 2]);
-        v.w = (float)((double)x.w - vec[j + 3]);
-    } else if (t == k + m && n0 > 0) {
-        v.x = (float)vec[d + j];
-        v.y = (float)vec[d + j + 1];
-        v.z = (float)vec[d + j + 2];
-        v.w = (float)vec[d + j + 3];
     }
-    *reinterpret_cast<float4 *>(M + mblk(t, j, rp)) = v;
+    // w_state: V already holds the rows whose Gram matrix is the truncated operator (W = Q^T M of the last block)
+    double sq[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int t = P * kRT + rl + 32 * g;
+        sq[g] = (kind[g] == 1 && !w_state) ? sqrt(lam[t]) : 1.0;
+    }
+    for (int it = 0; it < kBuildKB; ++it) {
+        const int64_t kb = kb_begin + it;
+        if (kb >= nkb) break;                     // (uniform)
+        const int64_t j = kb * 32 + kq * 4;
+        const bool in = j < d;                    // d % 4 == 0: a quad lies inside or outside as a whole
+        const int buf = it & 1;
+        double b0 = 0, b1 = 0, b2 = 0, b3 = 0, c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+        if (in) {
+            b0 = vec[j], b1 = vec[j + 1], b2 = vec[j + 2], b3 = vec[j + 3];
+            c0 = vec[d + j], c1 = vec[d + j + 1], c2 = vec[d + j + 2], c3 = vec[d + j + 3];
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (in) {
+                if (kind[g] == 1) {
+                    const float4 x = *reinterpret_cast<const float4 *>(src[g] + j);
+                    v = x;
+                    if (!w_state) {
+                        v.x = (float)(sq[g] * (double)x.x);
+                        v.y = (float)(sq[g] * (double)x.y);
+                        v.z = (float)(sq[g] * (double)x.z);
+                        v.w = (float)(sq[g] * (double)x.w);
+                    }
+                } else if (kind[g] == 2) {
+                    const float4 x = *reinterpret_cast<const float4 *>(src[g] + j);
+                    v.x = (float)((double)x.x - b0);
+                    v.y = (float)((double)x.y - b1);
+                    v.z = (float)((double)x.z - b2);
+                    v.w = (float)((double)x.w - b3);
+                } else if (kind[g] == 3) {
+                    v = make_float4((float)c0, (float)c1, (float)c2, (float)c3);
+                }
+            }
+            tile[buf][(rl + 32 * g) * 9 + kq] = v;
+        }
+        __syncthreads();
+        float4 *unit = reinterpret_cast<float4 *>(M) + (kb * npan + P) * (int64_t)(kRT * 8);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int idx = tid + 256 * g, row = idx & 127, q = idx >> 7;
+            unit[q * kRT + row] = tile[buf][row * 9 + q];
+        }
+    }
 }
 
 // bs = column sums of the block taken about the OLD running mean (column_moments with shift = mean; about 0 for the
@@ -783,14 +762,15 @@ int smallside_alloc(SmallSide &ss, int64_t d, int k, int m) {
     ss.rp = (int)round_up(ss.r_cap, kRT);
     ss.kp = (int)round_up(k, kRT);
     // split of the feature range over workgroups: the launch (macro tiles x splits) should fill whole rounds of the
-    // resident workgroups (one per CU) - 153 tiles x 4 splits = 612 workgroups on 256 CUs was three rounds at 80 %
+    // resident workgroups - 153 tiles x 4 splits = 612 workgroups on 256 slots was three rounds at 80 %
     {
         const int Tt = (int)ceil_div(ss.r_cap, kRT), nmt = Tt * (Tt + 1) / 2;
-        const int slots = 256;      // both kernels need the whole register file of a SIMD per wave: one workgroup per CU
-        int best = 4;
+        // rowgram_dma_kernel: two workgroups per CU; the split-bf16 kernels need a whole SIMD's registers per wave: one
+        const int slots = precision == GS_PREC_F32 ? 512 : 256;
+        int best = 1;
         double best_eff = 0.0;
-        for (int ns = 3; ns <= 12; ++ns) {
-            if ((int64_t)ns * 4096 > d) break;             // keep at least 4096 columns per workgroup
+        for (int ns = 1; ns <= 16; ++ns) {
+            if (ns > 1 && (int64_t)ns * 1024 > d) break;       // keep at least 1024 columns (one float64 carry) per workgroup
             const int64_t wgs = (int64_t)nmt * ns;
             const double eff = (double)wgs / (double)(ceil_div(wgs, slots) * slots);
             if (eff > best_eff + 1e-9) {
@@ -857,8 +837,9 @@ int smallside_update(SmallSide &ss, const float *X, int64_t rows, int64_t ldx, d
     hipLaunchKernelGGL(ss_stats_kernel, dim3(gd), dim3(256), 0, stream, bs, mean, vec, d, n0, (double)m);
     hipLaunchKernelGGL(ss_m2_kernel, dim3(gd), dim3(256), 0, stream, ss.colsq, bs, vec, m2, d, n0, (double)m, ss.colsq + d);
     // 2. M = [S V ; X - bm ; mc ; 0]
-    hipLaunchKernelGGL(ss_build_kernel, dim3((unsigned)ceil_div(d, 1024), (unsigned)rp), dim3(256), 0, stream, X, ldx, m, V,
-                       lam, vec, d, k, rp, n0, ss.M, ss.w_state ? 1 : 0);
+    const int npan = rp / kRT;
+    hipLaunchKernelGGL(ss_build_kernel, dim3((unsigned)ceil_div(ceil_div(d, 32), kBuildKB), (unsigned)npan), dim3(256), 0,
+                       stream, X, ldx, m, V, lam, vec, d, k, npan, n0, ss.M, ss.w_state ? 1 : 0);
     ss.last_r = r;
     // 4. T = M M^T
     const int Tt = (int)ceil_div(r, kRT), nmt = Tt * (Tt + 1) / 2;
@@ -882,13 +863,18 @@ int smallside_update(SmallSide &ss, const float *X, int64_t rows, int64_t ldx, d
     const int total = nmt * ss.nsplit;
     const unsigned rgrid = (unsigned)(((total + 7) / 8) * 8);
     const int2 *order = reinterpret_cast<const int2 *>(ss.tile_order);
-    static const bool rk_layout = gs_knob("GS_ROWGRAM_RK") != nullptr;      // (measurement build: the round-5 candidate)
-    if (ss.precision == GS_PREC_F32 && rk_layout) {
-        hipLaunchKernelGGL(rowgram_rk_kernel, dim3(rgrid), dim3(256), 0, stream, ss.M, d, (int64_t)rp, ss.slab, rp, nmt, Tt,
-                           kchunk, order, total);
-    } else if (ss.precision == GS_PREC_F32) {
-        hipLaunchKernelGGL(rowgram_kernel, dim3(rgrid), dim3(256), 0, stream, ss.M, d, (int64_t)rp, ss.slab, rp, nmt, Tt,
-                           kchunk, order, total);
+    if (ss.precision == GS_PREC_F32) {
+        // (measurement build: GS_ROWGRAM_PROBE=1 no DMA after the first stage, =2 no MFMA - what bounds a stage)
+        static const char *probe = gs_knob("GS_ROWGRAM_PROBE");
+        if (probe != nullptr && probe[0] == '1')
+            hipLaunchKernelGGL(rowgram_dma_kernel<1>, dim3(rgrid), dim3(256), 0, stream, ss.M, d, npan, ss.slab, rp, nmt,
+                               kchunk, order, total);
+        else if (probe != nullptr && probe[0] == '2')
+            hipLaunchKernelGGL(rowgram_dma_kernel<2>, dim3(rgrid), dim3(256), 0, stream, ss.M, d, npan, ss.slab, rp, nmt,
+                               kchunk, order, total);
+        else
+            hipLaunchKernelGGL(rowgram_dma_kernel<0>, dim3(rgrid), dim3(256), 0, stream, ss.M, d, npan, ss.slab, rp, nmt,
+                               kchunk, order, total);
     } else {
         const bool x6 = ss.precision == GS_PREC_BF16X6;
         const size_t lds = (size_t)2 * (x6 ? 3 : 2) * 2 * kPanelB;
@@ -899,11 +885,11 @@ int smallside_update(SmallSide &ss, const float *X, int64_t rows, int64_t ldx, d
             if (rco != GS_OK) return rco;
         }
         if (x6)
-            hipLaunchKernelGGL(rowgram_bf16_kernel<6>, dim3(rgrid), dim3(256), lds, stream, ss.M, d, (int64_t)rp, ss.slab,
-                               rp, nmt, Tt, kchunk, order, total);
+            hipLaunchKernelGGL(rowgram_bf16_kernel<6>, dim3(rgrid), dim3(256), lds, stream, ss.M, d, npan, ss.slab,
+                               rp, nmt, kchunk, order, total);
         else
-            hipLaunchKernelGGL(rowgram_bf16_kernel<3>, dim3(rgrid), dim3(256), lds, stream, ss.M, d, (int64_t)rp, ss.slab,
-                               rp, nmt, Tt, kchunk, order, total);
+            hipLaunchKernelGGL(rowgram_bf16_kernel<3>, dim3(rgrid), dim3(256), lds, stream, ss.M, d, npan, ss.slab,
+                               rp, nmt, kchunk, order, total);
     }
     const int rused = Tt * kRT;
     hipLaunchKernelGGL(rowgram_fold_kernel, dim3((unsigned)ceil_div(rused, 256), (unsigned)rused), dim3(256), 0,
@@ -929,7 +915,7 @@ int smallside_update(SmallSide &ss, const float *X, int64_t rows, int64_t ldx, d
             hipLaunchKernelGGL(ss_coef_plain_kernel, dim3((unsigned)ceil_div(rp, 256), (unsigned)k), dim3(256), 0, stream,
                                ss.Uk, (int64_t)rp, r, rp, k, kp, ss.Ct);
             hipLaunchKernelGGL(tn_gemm_kernel, dim3((unsigned)((kp / kRT) * ntn)), dim3(256), 0, stream, ss.Ct, kp, ss.M, d,
-                               (int64_t)rp, r, ss.Vtmp, d);
+                               npan, r, ss.Vtmp, d);
             GS_HIP_CHECK(hipMemcpyAsync(V, ss.Vtmp, sizeof(float) * (size_t)k * d, hipMemcpyDeviceToDevice, stream));
             GS_HIP_CHECK(hipGetLastError());
             ss.last_mults = mults;
@@ -963,7 +949,7 @@ int smallside_update(SmallSide &ss, const float *X, int64_t rows, int64_t ldx, d
     }
     // 6. V' = Ct^T M, sign convention
     hipLaunchKernelGGL(tn_gemm_kernel, dim3((unsigned)((kp / kRT) * ntn)), dim3(256), 0, stream, ss.Ct, kp, ss.M, d,
-                       (int64_t)rp, r, ss.Vtmp, d);
+                       npan, r, ss.Vtmp, d);
     hipLaunchKernelGGL(ss_sign_kernel, dim3((unsigned)k), dim3(1024), 0, stream, ss.Vtmp, d, V, d);
     GS_HIP_CHECK(hipGetLastError());
     return GS_OK;
@@ -971,7 +957,7 @@ int smallside_update(SmallSide &ss, const float *X, int64_t rows, int64_t ldx, d
 
 int smallside_materialize(SmallSide &ss, float *V, double *lam, int *sweeps_out, hipStream_t stream) {
     if (!ss.w_state) return GS_OK;
-    const int k = ss.k, rp = ss.rp, kp = ss.kp, r = ss.last_r;
+    const int k = ss.k, rp = ss.rp, kp = ss.kp, r = ss.last_r, npan = ss.rp / kRT;
     const int64_t d = ss.d;
     SubspaceWorkspace &ws = ss.sws;
     const int pj = (int)round_up(k, 8);
@@ -988,7 +974,7 @@ int smallside_materialize(SmallSide &ss, float *V, double *lam, int *sweeps_out,
                        (int64_t)kp, ws.theta, r, rp, k, kp, ss.Ct, lam);
     const int64_t ntn = ceil_div(d, kRT);
     hipLaunchKernelGGL(tn_gemm_kernel, dim3((unsigned)((kp / kRT) * ntn)), dim3(256), 0, stream, ss.Ct, kp, ss.M, d,
-                       (int64_t)rp, r, ss.Vtmp, d);
+                       npan, r, ss.Vtmp, d);
     hipLaunchKernelGGL(ss_sign_kernel, dim3((unsigned)k), dim3(1024), 0, stream, ss.Vtmp, d, V, d);
     int jhost[2] = {0, 0};
     GS_HIP_CHECK(hipMemcpyAsync(jhost, jinfo, sizeof(int) * 2, hipMemcpyDeviceToHost, stream));

@@ -91,6 +91,43 @@ def linear_forward(x, weight, bias=None):
     return y
 
 
+_project_scratch = {}
+
+
+def project_rows(x, dirs, shift=None, colscale=None, out=None):
+    """``((x - shift) @ dirs.T) * colscale`` for a few directions (``dirs`` [k, d], k small): the projection step of
+    the regression (decomposition.py:110-118).  ``out`` may be a column slice ``buf[r0:r1, :k]`` of a wider row-major
+    float32 buffer - the result is written in place, no intermediate copy of the batch or of the coordinates."""
+    import torch
+    lib = _lib.load()
+    _need_cuda(x, dirs, shift, colscale, out)
+    assert x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1
+    dirs = dirs.to(torch.float32).contiguous()
+    k, d = dirs.shape
+    assert x.shape[1] == d
+    rows = x.shape[0]
+    if shift is not None:
+        shift = shift.to(torch.float32).contiguous().reshape(-1)
+        assert shift.numel() == d
+    if colscale is not None:
+        colscale = colscale.to(torch.float32).contiguous().reshape(-1)
+        assert colscale.numel() == k
+    if out is None:
+        out = torch.empty((rows, k), dtype=torch.float32, device=x.device)
+    assert out.dtype == torch.float32 and out.shape == (rows, k) and out.stride(1) == 1
+    nb = C.c_int64(0)
+    _lib.check(lib.gs_project_rows_nbytes(rows, k, d, C.byref(nb)))
+    key = (x.device, torch.cuda.current_stream(x.device).cuda_stream)
+    scratch = _project_scratch.get(key)
+    if scratch is None or scratch.numel() < nb.value:
+        scratch = torch.empty(nb.value, dtype=torch.uint8, device=x.device)
+        _project_scratch[key] = scratch
+    _lib.check(lib.gs_project_rows(_p(x), x.stride(0), rows, d, _p(shift), _p(dirs), k, _p(colscale), _p(out),
+                                   out.stride(0) if rows > 1 else max(out.stride(0), k), _p(scratch), scratch.numel(),
+                                   _lib.current_stream_ptr()))
+    return out
+
+
 def eigh_topk(A, k, V0=None):
     """Leading ``k`` eigenpairs of a symmetric PSD float64 matrix (Chebyshev-filtered subspace iteration):
     returns ``(w [k] descending, V [k, n] eigenvectors as rows, info)`` with

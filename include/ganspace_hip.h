@@ -296,6 +296,17 @@ int gs_mapping_forward(const float *z, float *w, float *scratch, const float *we
 int gs_linear_forward(const float *x, const float *W, const float *b, float *y,
                       int64_t rows, int in_features, int out_features, void *stream);
 
+/* out[rows, directions] (leading dimension ldo) = ((x - shift) @ dirs^T) * colscale: the projection
+ * of the regression back to latent space, decomposition.py:110-118
+ * (`(act - mean) @ comp.T / stdev`; the reference centres first, so does this: while staging).
+ * x [rows, features] (leading dimension ldx), shift [features] or NULL, dirs [directions, features],
+ * colscale [directions] or NULL; `out` may be a column block of a wider row-major buffer (the
+ * [A|Z] rows handed to gs_gram_accumulate).  scratch: gs_project_rows_nbytes() bytes.            */
+int gs_project_rows_nbytes(int64_t rows, int directions, int features, int64_t *nbytes);
+int gs_project_rows(const float *x, int64_t ldx, int64_t rows, int features, const float *shift,
+                    const float *dirs, int directions, const float *colscale, float *out,
+                    int64_t ldo, void *scratch, int64_t scratch_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

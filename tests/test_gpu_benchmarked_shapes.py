@@ -115,3 +115,21 @@ def test_smallside_block_taller_than_4096_rows(dev):
     cos = O.signed_cosines(est.get_components()[0], orc.components_)
     assert cos.min() > 1 - 3e-6, cos.min()
     np.testing.assert_allclose(est.transformer.singular_values_, orc.singular_values_, rtol=2e-4)
+
+
+@pytest.mark.parametrize("k,rows", [(27, 100), (127, 128)])
+def test_smallside_stack_height_is_a_multiple_of_the_panel(dev, k, rows):
+    """r = k + rows + 1 a multiple of 128: the stacked matrix fills its last 128-row panel exactly, the coefficient
+    buffer has no spare row behind row r - 1 (round-4 advisor: ``tn_gemm_kernel`` read one row past it)."""
+    from ganspace_amd.estimators import IPCAEstimator
+    assert (k + rows + 1) % 128 == 0
+    d = 4128                                  # not a multiple of 128: a partial last column tile as well
+    orc = SmallSideTorchOracle(k)
+    est = IPCAEstimator(k, "smallside")
+    for X in lowrank_plus_noise_blocks(d, 7, rows=rows, latent=max(48, k + 16), decay=1.06, seed=9, device=dev):
+        assert est.fit_partial(X) is True
+        orc.partial_fit(X)
+    cos = O.signed_cosines(est.get_components()[0], orc.components_)
+    assert cos.min() > 1 - 3e-6, cos.min()
+    np.testing.assert_allclose(est.transformer.singular_values_, orc.singular_values_, rtol=2e-4)
+    np.testing.assert_allclose(est.transformer.mean_, orc.mean_, atol=2e-6)

@@ -431,6 +431,31 @@ def test_linear_forward_matches_float64(dev, rows, in_f, out_f):
     assert np.abs(y.cpu().numpy() - ref).max() < 1e-5 * np.abs(ref).max()
 
 
+@pytest.mark.parametrize("rows,d,k,use_shift", [(2000, 32768, 80, True), (333, 1028, 20, True), (1, 64, 130, False),
+                                                 (129, 4100, 128, True)])
+def test_project_rows_matches_float64(dev, rows, d, k, use_shift):
+    """Regression projection ``((x - mean) @ comp.T) / stdev`` (reference decomposition.py:110-118) written into a
+    column block of a wider staging buffer: float64 numpy is the checker; the columns next to the block stay untouched.
+    The data sit on a mean 5x their spread: centring AFTER the product would lose a digit, centring first does not."""
+    from ganspace_amd import ops
+    rs = np.random.RandomState(rows + d)
+    mean = (5.0 * rs.standard_normal(d)).astype(np.float32)
+    x = (rs.standard_normal((rows, d)) + mean).astype(np.float32)
+    comp = np.linalg.qr(rs.standard_normal((d, k)))[0].T.astype(np.float32) if k <= d else \
+        rs.standard_normal((k, d)).astype(np.float32)
+    scale = (1.0 / (0.5 + rs.rand(k))).astype(np.float32)
+    buf = torch.full((rows, k + 37), -7.0, dtype=torch.float32, device=dev)
+    out = ops.project_rows(torch.from_numpy(x).to(dev), torch.from_numpy(comp).to(dev),
+                           shift=torch.from_numpy(mean).to(dev) if use_shift else None,
+                           colscale=torch.from_numpy(scale).to(dev), out=buf[:, :k])
+    assert out.data_ptr() == buf.data_ptr()
+    xc = x.astype(np.float64) - (mean.astype(np.float64) if use_shift else 0.0)
+    ref = (xc @ comp.astype(np.float64).T) * scale.astype(np.float64)
+    got = buf.cpu().numpy()
+    assert np.abs(got[:, :k] - ref).max() < 2e-5 * np.abs(ref).max()
+    assert (got[:, k:] == -7.0).all()
+
+
 # ---- BASELINE-size properties (no oracle at this size: size-independent invariants) --------------
 
 def test_full_size_block_properties(dev):
