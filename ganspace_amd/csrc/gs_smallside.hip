@@ -81,29 +81,23 @@ using f32x4v = __attribute__((ext_vector_type(4))) float;
 #define GS_DSR128(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
 #define GS_DSWAIT4(a, b, c, e) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(e))
 
+// One wave's share of a macro tile.  PAT = which of the wave's four 32 x 32 accumulators T needs (see the kernel): 0 all
+// four, 1 all but (1,0), 2 column sub-block 0 only - (0,0) and (1,0) -, 3 (0,0) only, 4 none.  A template parameter, not a
+// run-time mask: predicated MFMAs (and even a per-stage branch between specialised stage bodies) made the accumulators
+// conditional values and spilled 84-112 registers; five copies of the loop cost code size only.
 // PROBE (measurement build only): 0 = the kernel; 1 = no DMA after the first stage (matrix pipe + LDS reads alone);
 // 2 = no MFMA (DMA + barriers alone)
-template <int PROBE>
-__global__ __launch_bounds__(256, 2) void rowgram_dma_kernel(const float *__restrict__ M, int64_t d, int npan,
-                                                             double *__restrict__ slab, int rp, int nmt,
-                                                             int64_t kchunk, const int2 *__restrict__ order, int total) {
-    // ring of two stages; stage = [panel A | panel B][8 k-quads][128 rows][16 B]
-    __shared__ __attribute__((aligned(1024))) unsigned char ring[2 * kStageBytes];
-    int split, I, J;
-    if (!rowgram_assign(order, nmt, total, split, I, J)) return;
+template <int PROBE, int PAT>
+__device__ __forceinline__ void rowgram_dma_body(unsigned char *ring, const float *__restrict__ M, int npan,
+                                                 double *__restrict__ out, int rp, int I, int J, int64_t kb0, int nst,
+                                                 int wave, int lane) {
     const bool diag = (I == J);
-    const int64_t k_begin = (int64_t)split * kchunk;
-    const int64_t k_end = (k_begin + kchunk < d) ? k_begin + kchunk : d;
-    // (columns d .. round_up(d, 32) of M are zero: allocated zeroed, never written - a partial last K-block needs no mask)
-    const int nst = k_end > k_begin ? (int)((k_end - k_begin + kRK - 1) / kRK) : 0;
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wi = wave >> 1, wj = wave & 1;
     const int half = lane >> 5, l31 = lane & 31;
+    constexpr bool U0 = PAT <= 3, U1 = PAT <= 1, U2 = PAT == 0 || PAT == 2, U3 = PAT <= 1;      // accumulators in use
 
     // DMA: a unit is sixteen 1 KB pieces; wave w moves pieces 4 w .. 4 w + 3 of each panel.  Source = unit base (uniform,
     // advances by npan units per stage) + this lane's 16 bytes; destination = M0 base (uniform) + lane * 16 (implicit).
-    const int64_t kb0 = k_begin >> 5;
     const char *srcA = reinterpret_cast<const char *>(M) + ((kb0 * npan + I) * (int64_t)kUnitBytes) + wave * 4096 + lane * 16;
     const char *srcB = reinterpret_cast<const char *>(M) + ((kb0 * npan + J) * (int64_t)kUnitBytes) + wave * 4096 + lane * 16;
     const int64_t kbstride = (int64_t)npan * kUnitBytes;
@@ -128,7 +122,7 @@ __global__ __launch_bounds__(256, 2) void rowgram_dma_kernel(const float *__rest
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc64[a][r] = 0.0;
+        for (int e = 0; e < 16; ++e) acc64[a][e] = 0.0;
 
     // fragment addresses (bytes in LDS): k-quad 2 g + half of rows wi * 64 + l31 (+ 32) resp. wj * 64 + l31 (+ 32); lanes
     // 0-31 multiply k = 8 g + e, lanes 32-63 k = 8 g + 4 + e in the e-th MFMA of a group (the same choice for both operands)
@@ -136,16 +130,17 @@ __global__ __launch_bounds__(256, 2) void rowgram_dma_kernel(const float *__rest
     const unsigned abase = ring0 + half * 2048 + (wi * 64 + l31) * 16;
     const unsigned bbase = ring0 + (diag ? 0 : kUnitBytes) + half * 2048 + (wj * 64 + l31) * 16;
 
-#define GS_RG_READ(pa0, pa1, pb0, pb1, g)                 \
-    GS_DSR128(pa0, aaddr, (g) * 4096);                    \
-    GS_DSR128(pa1, aaddr, (g) * 4096 + 512);              \
-    GS_DSR128(pb0, baddr, (g) * 4096);                    \
-    GS_DSR128(pb1, baddr, (g) * 4096 + 512);
-#define GS_RG_STEP(pa0, pa1, pb0, pb1, e)                                          \
-    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(pa0.e, pb0.e, acc0, 0, 0, 0);      \
-    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(pa0.e, pb1.e, acc1, 0, 0, 0);      \
-    acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(pa1.e, pb0.e, acc2, 0, 0, 0);      \
-    acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(pa1.e, pb1.e, acc3, 0, 0, 0);
+    // (an operand no needed accumulator uses is not read)
+#define GS_RG_READ(pa0, pa1, pb0, pb1, g)                                   \
+    if (U0 || U1) GS_DSR128(pa0, aaddr, (g) * 4096);                        \
+    if (U2 || U3) GS_DSR128(pa1, aaddr, (g) * 4096 + 512);                  \
+    if (U0 || U2) GS_DSR128(pb0, baddr, (g) * 4096);                        \
+    if (U1 || U3) GS_DSR128(pb1, baddr, (g) * 4096 + 512);
+#define GS_RG_STEP(pa0, pa1, pb0, pb1, e)                                                       \
+    if (U0) acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(pa0.e, pb0.e, acc0, 0, 0, 0);           \
+    if (U1) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(pa0.e, pb1.e, acc1, 0, 0, 0);           \
+    if (U2) acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(pa1.e, pb0.e, acc2, 0, 0, 0);           \
+    if (U3) acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(pa1.e, pb1.e, acc3, 0, 0, 0);
 #define GS_RG_MMA(pa0, pa1, pb0, pb1)                                              \
     if (PROBE != 2) {                                                              \
         GS_RG_STEP(pa0, pa1, pb0, pb1, x)                                          \
@@ -160,59 +155,96 @@ __global__ __launch_bounds__(256, 2) void rowgram_dma_kernel(const float *__rest
         // s - 1, whose slot the next request overwrites
         asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
         const unsigned aaddr = abase + (s & 1) * kStageBytes, baddr = bbase + (s & 1) * kStageBytes;
-        f32x4v p0, p1, p2, p3, q0, q1, q2, q3;
-        GS_RG_READ(p0, p1, p2, p3, 0)                       // (its LDS round trip hides behind the address arithmetic of the DMA)
+        f32x4v p0 = {0}, p1 = {0}, p2 = {0}, p3 = {0}, q0 = {0}, q1 = {0}, q2 = {0}, q3 = {0};
+        if (PAT != 4) {
+            GS_RG_READ(p0, p1, p2, p3, 0)                   // (its LDS round trip hides behind the address arithmetic of the DMA)
+        }
         __builtin_amdgcn_sched_barrier(0);
         if (s + 1 < nst && (PROBE != 1)) issue(s + 1);
         __builtin_amdgcn_sched_barrier(0);
-        // group g + 1's operands are requested BEFORE group g's sixteen MFMAs (scheduling barriers: left alone the
-        // compiler sinks the volatile reads behind the MFMAs and reuses the registers - an LDS round trip per group with
-        // the matrix pipe idle)
-        GS_DSWAIT4(p0, p1, p2, p3);
-        GS_RG_READ(q0, q1, q2, q3, 1)
-        __builtin_amdgcn_sched_barrier(0);
-        GS_RG_MMA(p0, p1, p2, p3)
-        __builtin_amdgcn_sched_barrier(0);
-        GS_DSWAIT4(q0, q1, q2, q3);
-        GS_RG_READ(p0, p1, p2, p3, 2)
-        __builtin_amdgcn_sched_barrier(0);
-        GS_RG_MMA(q0, q1, q2, q3)
-        __builtin_amdgcn_sched_barrier(0);
-        GS_DSWAIT4(p0, p1, p2, p3);
-        GS_RG_READ(q0, q1, q2, q3, 3)
-        __builtin_amdgcn_sched_barrier(0);
-        GS_RG_MMA(p0, p1, p2, p3)
-        __builtin_amdgcn_sched_barrier(0);
-        GS_DSWAIT4(q0, q1, q2, q3);
-        GS_RG_MMA(q0, q1, q2, q3)
-        if ((s + 1) % kFlushStages == 0 || s + 1 == nst) {
-            // float64 carry: bounds every float32 fma chain to 1024 products
+        if (PAT != 4) {
+            // group g + 1's operands are requested BEFORE group g's sixteen MFMAs (scheduling barriers: left alone the
+            // compiler sinks the volatile reads behind the MFMAs and reuses the registers - an LDS round trip per group
+            // with the matrix pipe idle)
+            GS_DSWAIT4(p0, p1, p2, p3);
+            GS_RG_READ(q0, q1, q2, q3, 1)
+            __builtin_amdgcn_sched_barrier(0);
+            GS_RG_MMA(p0, p1, p2, p3)
+            __builtin_amdgcn_sched_barrier(0);
+            GS_DSWAIT4(q0, q1, q2, q3);
+            GS_RG_READ(p0, p1, p2, p3, 2)
+            __builtin_amdgcn_sched_barrier(0);
+            GS_RG_MMA(q0, q1, q2, q3)
+            __builtin_amdgcn_sched_barrier(0);
+            GS_DSWAIT4(p0, p1, p2, p3);
+            GS_RG_READ(q0, q1, q2, q3, 3)
+            __builtin_amdgcn_sched_barrier(0);
+            GS_RG_MMA(p0, p1, p2, p3)
+            __builtin_amdgcn_sched_barrier(0);
+            GS_DSWAIT4(q0, q1, q2, q3);
+            GS_RG_MMA(q0, q1, q2, q3)
+            if ((s + 1) % kFlushStages == 0 || s + 1 == nst) {
+                // float64 carry: bounds every float32 fma chain to 1024 products
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                acc64[0][r] += (double)acc0[r];
-                acc64[1][r] += (double)acc1[r];
-                acc64[2][r] += (double)acc2[r];
-                acc64[3][r] += (double)acc3[r];
-                acc0[r] = 0.f;
-                acc1[r] = 0.f;
-                acc2[r] = 0.f;
-                acc3[r] = 0.f;
+                for (int e = 0; e < 16; ++e) {
+                    if (U0) acc64[0][e] += (double)acc0[e], acc0[e] = 0.f;
+                    if (U1) acc64[1][e] += (double)acc1[e], acc1[e] = 0.f;
+                    if (U2) acc64[2][e] += (double)acc2[e], acc2[e] = 0.f;
+                    if (U3) acc64[3][e] += (double)acc3[e], acc3[e] = 0.f;
+                }
             }
         }
     }
 #undef GS_RG_READ
 #undef GS_RG_STEP
 #undef GS_RG_MMA
-    double *out = slab + (int64_t)split * rp * rp;
     const int row_base = I * kRT + wi * 64 + 4 * (lane >> 5);
     const int col_base = J * kRT + wj * 64 + (lane & 31);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int row = row_base + (r & 3) + 8 * (r >> 2);
-        out[(int64_t)row * rp + col_base] = acc64[0][r];
-        out[(int64_t)row * rp + col_base + 32] = acc64[1][r];
-        out[(int64_t)(row + 32) * rp + col_base] = acc64[2][r];
-        out[(int64_t)(row + 32) * rp + col_base + 32] = acc64[3][r];
+    for (int e = 0; e < 16; ++e) {
+        const int row = row_base + (e & 3) + 8 * (e >> 2);
+        out[(int64_t)row * rp + col_base] = acc64[0][e];
+        out[(int64_t)row * rp + col_base + 32] = acc64[1][e];
+        out[(int64_t)(row + 32) * rp + col_base] = acc64[2][e];
+        out[(int64_t)(row + 32) * rp + col_base + 32] = acc64[3][e];
+    }
+}
+
+template <int PROBE>
+__global__ __launch_bounds__(256, 2) void rowgram_dma_kernel(const float *__restrict__ M, int64_t d, int npan,
+                                                             double *__restrict__ slab, int rp, int nmt,
+                                                             int64_t kchunk, const int2 *__restrict__ order, int total,
+                                                             int r) {
+    // ring of two stages; stage = [panel A | panel B][8 k-quads][128 rows][16 B]
+    __shared__ __attribute__((aligned(1024))) unsigned char ring[2 * kStageBytes];
+    int split, I, J;
+    if (!rowgram_assign(order, nmt, total, split, I, J)) return;
+    const int64_t k_begin = (int64_t)split * kchunk;
+    const int64_t k_end = (k_begin + kchunk < d) ? k_begin + kchunk : d;
+    // (columns d .. round_up(d, 32) of M are zero: allocated zeroed, never written - a partial last K-block needs no mask)
+    const int nst = k_end > k_begin ? (int)((k_end - k_begin + kRK - 1) / kRK) : 0;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // (scalar: `pat` below is a branch condition)
+    const int wi = wave >> 1, wj = wave & 1;
+
+    // Which of this wave's four 32 x 32 accumulators T needs: the fold reads the upper triangle only (sub-block row <=
+    // sub-block column) and rows >= r of M are zero.  r = 2081 fills 65.03 sub-blocks per side: 2211 of the 2448
+    // sub-block products the 153 macro tiles hold are needed - the rest (the lower half of the diagonal tiles, the empty
+    // half of the last panel) is a tenth of the launch's matrix-pipe time.  A skipped accumulator is written as zeros.
+    // Both sub-block offsets are even, so only five patterns exist (rowgram_dma_body).  Every wave runs the same
+    // barriers and moves its share of the panels whatever its pattern.
+    const int r32 = (r + 31) >> 5;
+    const int gi0 = I * 4 + wi * 2, gj0 = J * 4 + wj * 2;
+    const int cols = gj0 + 1 < r32 ? 2 : (gj0 < r32 ? 1 : 0);        // valid column sub-blocks
+    const int pat = (cols == 0 || gi0 > gj0) ? 4 : (gi0 < gj0 ? (cols == 2 ? 0 : 2) : (cols == 2 ? 1 : 3));
+    double *out = slab + (int64_t)split * rp * rp;
+    const int64_t kb0 = k_begin >> 5;
+    switch (pat) {
+        case 0: rowgram_dma_body<PROBE, 0>(ring, M, npan, out, rp, I, J, kb0, nst, wave, lane); break;
+        case 1: rowgram_dma_body<PROBE, 1>(ring, M, npan, out, rp, I, J, kb0, nst, wave, lane); break;
+        case 2: rowgram_dma_body<PROBE, 2>(ring, M, npan, out, rp, I, J, kb0, nst, wave, lane); break;
+        case 3: rowgram_dma_body<PROBE, 3>(ring, M, npan, out, rp, I, J, kb0, nst, wave, lane); break;
+        default: rowgram_dma_body<PROBE, 4>(ring, M, npan, out, rp, I, J, kb0, nst, wave, lane); break;
     }
 }
 
@@ -428,14 +460,14 @@ __global__ void rowgram_fold_kernel(const double *__restrict__ slab, double *__r
 // Contraction over ROWS t: both MFMA operands are "row t, 32 consecutive columns" (conflict-free ds_read_b32).
 // Rows t >= r of Ct AND of M are zero (the coefficient kernels write 0 there / ss_build_kernel zero-fills up to rp), and
 // a stage never reaches past rp (a multiple of 128 >= r): no masks, no clamped rows, no select on a loaded value.
-__global__ __launch_bounds__(256, 2) void tn_gemm_kernel(const float *__restrict__ Ct, int kp,
-                                                         const float *__restrict__ M, int64_t d, int npan,
-                                                         int r, float *__restrict__ out, int64_t ldo) {
-    __shared__ __attribute__((aligned(16))) float lds[2][2][32][kRT];
-    const int64_t ntn = (d + kRT - 1) / kRT;
-    const int ti = (int)(blockIdx.x / ntn);
-    const int64_t tj = blockIdx.x % ntn;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+// NA = how many of the wave's two 32-row fragments of out hold wanted rows (rows >= k of out are never read: k = 80 of
+// kp = 128 leaves the last fragment - a quarter of the matrix-pipe work - to skip).  A template parameter for the same
+// reason as in rowgram_dma_body.
+template <int NA>
+__device__ __forceinline__ void tn_gemm_body(float (*lds)[2][32][kRT], const float *__restrict__ Ct, int kp,
+                                             const float *__restrict__ M, int64_t d, int npan, int r,
+                                             float *__restrict__ out, int64_t ldo, int ti, int64_t tj, int wave, int lane,
+                                             int tid) {
     const int wi = wave >> 1, wj = wave & 1;
     // A (coefficients, row-major [t][kp]): thread = (4 columns c4, rows rr + 8 i)
     const int c4 = tid & 31, rr = tid >> 5;
@@ -478,17 +510,22 @@ __global__ __launch_bounds__(256, 2) void tn_gemm_kernel(const float *__restrict
         //  more - never a row >= rp)
         GS_TN_FETCH((s + 1 < nst ? s + 1 : s) * 32)
         __builtin_amdgcn_sched_barrier(0);      // (loads before the MFMAs)
-        const float *A = &lds[buf][0][arow][acol];
-        const float *B = &lds[buf][1][arow][be];
+        if (NA > 0) {
+            const float *A = &lds[buf][0][arow][acol];
+            const float *B = &lds[buf][1][arow][be];
 #pragma unroll
-        for (int k = 0; k < 32; k += 2) {
-            const int bo = k * kRT + ((bq ^ ((k + arow) & 7)) << 2);
-            const float a0 = A[k * kRT], a1 = A[k * kRT + 32];
-            const float b0 = B[bo], b1 = B[bo + 32];
-            acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc00, 0, 0, 0);
-            acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc01, 0, 0, 0);
-            acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc10, 0, 0, 0);
-            acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc11, 0, 0, 0);
+            for (int k = 0; k < 32; k += 2) {
+                const int bo = k * kRT + ((bq ^ ((k + arow) & 7)) << 2);
+                const float a0 = A[k * kRT];
+                const float b0 = B[bo], b1 = B[bo + 32];
+                acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc00, 0, 0, 0);
+                acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc01, 0, 0, 0);
+                if (NA > 1) {
+                    const float a1 = A[k * kRT + 32];
+                    acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc10, 0, 0, 0);
+                    acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc11, 0, 0, 0);
+                }
+            }
         }
         GS_TN_STASH(buf ^ 1)
         __syncthreads();
@@ -497,6 +534,7 @@ __global__ __launch_bounds__(256, 2) void tn_gemm_kernel(const float *__restrict
 #undef GS_TN_FETCH1
 #undef GS_TN_STASH
 #undef GS_TN_STASH1
+    if (NA == 0) return;
     const int row_base = ti * kRT + wi * 64 + 4 * (lane >> 5);
     const int64_t col0 = tj * kRT + wj * 64 + (lane & 31), col1 = col0 + 32;
 #pragma unroll
@@ -504,12 +542,30 @@ __global__ __launch_bounds__(256, 2) void tn_gemm_kernel(const float *__restrict
         const int row = row_base + (q & 3) + 8 * (q >> 2);
         if (col0 < d) {
             out[(int64_t)row * ldo + col0] = acc00[q];
-            out[(int64_t)(row + 32) * ldo + col0] = acc10[q];
+            if (NA > 1) out[(int64_t)(row + 32) * ldo + col0] = acc10[q];
         }
         if (col1 < d) {
             out[(int64_t)row * ldo + col1] = acc01[q];
-            out[(int64_t)(row + 32) * ldo + col1] = acc11[q];
+            if (NA > 1) out[(int64_t)(row + 32) * ldo + col1] = acc11[q];
         }
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void tn_gemm_kernel(const float *__restrict__ Ct, int kp,
+                                                         const float *__restrict__ M, int64_t d, int npan,
+                                                         int r, float *__restrict__ out, int64_t ldo, int kwant) {
+    __shared__ __attribute__((aligned(16))) float lds[2][2][32][kRT];
+    const int64_t ntn = (d + kRT - 1) / kRT;
+    const int ti = (int)(blockIdx.x / ntn);
+    const int64_t tj = blockIdx.x % ntn;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int first = ti * kRT + (wave >> 1) * 64;      // first row of out this wave owns
+    const int na = first + 32 < kwant ? 2 : (first < kwant ? 1 : 0);
+    switch (na) {
+        case 2: tn_gemm_body<2>(lds, Ct, kp, M, d, npan, r, out, ldo, ti, tj, wave, lane, tid); break;
+        case 1: tn_gemm_body<1>(lds, Ct, kp, M, d, npan, r, out, ldo, ti, tj, wave, lane, tid); break;
+        default: tn_gemm_body<0>(lds, Ct, kp, M, d, npan, r, out, ldo, ti, tj, wave, lane, tid); break;
     }
 }
 
@@ -779,6 +835,10 @@ int smallside_alloc(SmallSide &ss, int64_t d, int k, int m) {
             }
         }
         ss.nsplit = best;
+        if (const char *ov = gs_knob("GS_SS_NSPLIT")) {      // (measurement build: tail effect of the split count)
+            const int ns = atoi(ov);
+            if (ns >= 1 && ns <= 64 && (int64_t)ns * 32 <= d) ss.nsplit = ns;
+        }
     }
     auto alloc = [&](void **p, size_t bytes) -> int {
         if (hipMalloc(p, bytes) != hipSuccess) {
@@ -868,13 +928,13 @@ int smallside_update(SmallSide &ss, const float *X, int64_t rows, int64_t ldx, d
         static const char *probe = gs_knob("GS_ROWGRAM_PROBE");
         if (probe != nullptr && probe[0] == '1')
             hipLaunchKernelGGL(rowgram_dma_kernel<1>, dim3(rgrid), dim3(256), 0, stream, ss.M, d, npan, ss.slab, rp, nmt,
-                               kchunk, order, total);
+                               kchunk, order, total, r);
         else if (probe != nullptr && probe[0] == '2')
             hipLaunchKernelGGL(rowgram_dma_kernel<2>, dim3(rgrid), dim3(256), 0, stream, ss.M, d, npan, ss.slab, rp, nmt,
-                               kchunk, order, total);
+                               kchunk, order, total, r);
         else
             hipLaunchKernelGGL(rowgram_dma_kernel<0>, dim3(rgrid), dim3(256), 0, stream, ss.M, d, npan, ss.slab, rp, nmt,
-                               kchunk, order, total);
+                               kchunk, order, total, r);
     } else {
         const bool x6 = ss.precision == GS_PREC_BF16X6;
         const size_t lds = (size_t)2 * (x6 ? 3 : 2) * 2 * kPanelB;
@@ -915,7 +975,7 @@ int smallside_update(SmallSide &ss, const float *X, int64_t rows, int64_t ldx, d
             hipLaunchKernelGGL(ss_coef_plain_kernel, dim3((unsigned)ceil_div(rp, 256), (unsigned)k), dim3(256), 0, stream,
                                ss.Uk, (int64_t)rp, r, rp, k, kp, ss.Ct);
             hipLaunchKernelGGL(tn_gemm_kernel, dim3((unsigned)((kp / kRT) * ntn)), dim3(256), 0, stream, ss.Ct, kp, ss.M, d,
-                               npan, r, ss.Vtmp, d);
+                               npan, r, ss.Vtmp, d, k);
             GS_HIP_CHECK(hipMemcpyAsync(V, ss.Vtmp, sizeof(float) * (size_t)k * d, hipMemcpyDeviceToDevice, stream));
             GS_HIP_CHECK(hipGetLastError());
             ss.last_mults = mults;
@@ -949,7 +1009,7 @@ int smallside_update(SmallSide &ss, const float *X, int64_t rows, int64_t ldx, d
     }
     // 6. V' = Ct^T M, sign convention
     hipLaunchKernelGGL(tn_gemm_kernel, dim3((unsigned)((kp / kRT) * ntn)), dim3(256), 0, stream, ss.Ct, kp, ss.M, d,
-                       npan, r, ss.Vtmp, d);
+                       npan, r, ss.Vtmp, d, k);
     hipLaunchKernelGGL(ss_sign_kernel, dim3((unsigned)k), dim3(1024), 0, stream, ss.Vtmp, d, V, d);
     GS_HIP_CHECK(hipGetLastError());
     return GS_OK;
@@ -974,7 +1034,7 @@ int smallside_materialize(SmallSide &ss, float *V, double *lam, int *sweeps_out,
                        (int64_t)kp, ws.theta, r, rp, k, kp, ss.Ct, lam);
     const int64_t ntn = ceil_div(d, kRT);
     hipLaunchKernelGGL(tn_gemm_kernel, dim3((unsigned)((kp / kRT) * ntn)), dim3(256), 0, stream, ss.Ct, kp, ss.M, d,
-                       npan, r, ss.Vtmp, d);
+                       npan, r, ss.Vtmp, d, k);
     hipLaunchKernelGGL(ss_sign_kernel, dim3((unsigned)k), dim3(1024), 0, stream, ss.Vtmp, d, V, d);
     int jhost[2] = {0, 0};
     GS_HIP_CHECK(hipMemcpyAsync(jhost, jinfo, sizeof(int) * 2, hipMemcpyDeviceToHost, stream));

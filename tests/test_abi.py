@@ -100,7 +100,7 @@ def test_hot_kernels_have_no_scratch_and_products_use_the_f64_matrix_pipe(lib):
         _build.build(force=True)
     usage = json.load(open(path))
     hot = {k: u for k, u in usage.items() if _build.NO_SCRATCH.search(k)}
-    for needle in ("gram_f32_wide_kernel", "gram_bf16_glds_kernel", "gram_partial_kernel", "rowgram_kernel", "tn_gemm_kernel",
+    for needle in ("gram_f32_wide_kernel", "gram_bf16_glds_kernel", "gram_partial_kernel", "rowgram_dma_kernel", "tn_gemm_kernel", "project_rows_kernel",
                    "linear_act_fast_kernel", "mm64_kernel", "chol_inv_kernel"):
         assert any(needle in k for k in hot), f"{needle} missing from the resource record"
     for k, u in hot.items():

@@ -266,3 +266,19 @@ def test_regression_staging_is_bounded_in_rows_and_bytes():
     for B, wp in [(1, 8), (250, 208), (4096, 4096), (3, 7)]:
         n = stage(B, wp)
         assert n >= 1 and (n == 1 or (n * B <= 65536 and n * B * wp * 4 <= 256 << 20))
+
+
+@pytest.mark.parametrize("k,demod,up", [(3, True, False), (3, True, True), (1, False, False)])
+def test_modulated_conv_shared_weight_form_equals_the_grouped_form(k, demod, up):
+    """``ModulatedConv2d.forward`` (input scaling -> one dense convolution -> per-(sample, channel) demodulation) is the
+    same map as the published per-sample-weight / ``groups = B`` form (``forward_grouped``), float64 to roundoff."""
+    import torch
+    from ganspace_amd.wrappers import ModulatedConv2d
+    torch.manual_seed(3)
+    m = ModulatedConv2d(12, 7, k, 16, demodulate=demod, upsample=up).double()
+    x = torch.randn(5, 12, 6, 6, dtype=torch.float64)
+    style = torch.randn(5, 16, dtype=torch.float64)
+    with torch.no_grad():
+        a, b = m(x, style), m.forward_grouped(x, style)
+    assert a.shape == b.shape == (5, 7, 12 if up else 6, 12 if up else 6)
+    assert torch.allclose(a, b, rtol=1e-10, atol=1e-12)
