@@ -18,7 +18,7 @@ ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIBDIR = os.environ.get("GS_LIBDIR") or os.path.join(PKG, "lib")     # (GS_LIBDIR: side-by-side measurement builds)
 LIBNAME = "libganspace_hip.so"
-SOURCES = ["gs_collective.hip", "gs_gram.hip", "gs_eigh.hip", "gs_ipca.hip", "gs_linear.hip", "gs_smallside.hip", "gs_subspace.hip", "gs_topk.hip", "gs_gram_bf16.hip", "gs_gram_wide.hip", "gs_zgen.hip", "gs_rangefinder.hip", "gs_dense64.hip", "gs_tridiag.hip"]
+SOURCES = ["gs_collective.hip", "gs_gram.hip", "gs_eigh.hip", "gs_ipca.hip", "gs_linear.hip", "gs_smallside.hip", "gs_subspace.hip", "gs_topk.hip", "gs_gram_bf16.hip", "gs_gram_wide.hip", "gs_zgen.hip", "gs_zgen_device.hip", "gs_rangefinder.hip", "gs_dense64.hip", "gs_tridiag.hip"]
 
 
 MEASURE_LIBDIR = os.path.join(PKG, "lib_measure")    # -DGS_MEASURE_BUILD: the A/B switches (gs_knob) read the environment

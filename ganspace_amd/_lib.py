@@ -50,6 +50,7 @@ SIGNATURES = {
     "gs_zgen_wait": (_int, [_vp, _i64, C.POINTER(_vp)]),
     "gs_zgen_release": (_int, [_vp, _i64]),
     "gs_zgen_finish": (_int, [_vp]),
+    "gs_zgen_device": (_int, [_vp, _i64, _i64, _vp, _i64, _int, C.c_double, C.c_double, _f32, _vp]),
     "gs_gram_accumulate": (_int, [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp]),
     "gs_gram_accumulate_prec": (_int, [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _int, _vp]),
     "gs_gram_kernel_time": (_int, [_vp, _vp, _i64, _i64, _int, _vp, _vp, _vp]),

@@ -153,6 +153,46 @@ class NativeNormalStream:
             pass
 
 
+def device_generation_enabled(device) -> bool:
+    """The device generator (``gs_zgen_device``) serves every HIP run unless ``GANSPACE_ZGEN=host`` asks for the host thread
+    pool (A/B timing, or bit-for-bit glibc rows)."""
+    import torch
+    return torch.device(device).type == "cuda" and os.environ.get("GANSPACE_ZGEN", "device") != "host"
+
+
+def device_batches(kind: str, seeds, n: int, dim: int, device, truncation: float = 1.0, group: int = 256):
+    """Yield ``(index, z)`` for ``seeds`` in order, ``z`` a ``[n, dim]`` float32 DEVICE tensor holding
+    ``RandomState(seed).standard_normal(n * dim)`` (``kind="stylegan"``) or BigGAN's
+    ``truncation * truncnorm.rvs(-2, 2, size=(n, dim), random_state=RandomState(seed))`` - generated on the device, one wave
+    per seed, ``group`` seeds per launch (a launch lasts as long as ONE stream whatever the group: the groups are sized to put
+    a wave on every CU, 256 x n x dim floats of staging).  Nothing touches the host: no pinned ring, no H2D copy."""
+    import ctypes as C
+    import torch
+    from . import _lib
+    lib = _lib.load()
+    seeds = np.asarray([int(s) for s in seeds], dtype=np.uint32)
+    count = int(n) * int(dim)
+    if kind == "biggan":
+        knd, (la, lm), scale = 1, TRUNCNORM_M2_P2, float(truncation)
+    elif kind == "stylegan":
+        knd, (la, lm), scale = 0, (0.0, 0.0), 1.0
+    else:
+        raise ValueError(f"unknown latent kind {kind!r}")
+    if len(seeds) == 0:
+        return
+    seeds_dev = torch.from_numpy(seeds.view(np.int32).copy()).to(device)
+    # bound the staging buffer: <= 256 streams and <= 8 GiB per launch
+    group = max(1, min(int(group), len(seeds), (8 << 30) // max(1, 4 * count)))
+    stream = _lib.current_stream_ptr()
+    for lo in range(0, len(seeds), group):
+        m = min(group, len(seeds) - lo)
+        buf = torch.empty((m, int(n), int(dim)), dtype=torch.float32, device=device)
+        _lib.check(lib.gs_zgen_device(C.c_void_p(seeds_dev.data_ptr() + 4 * lo), m, count, C.c_void_p(buf.data_ptr()), count,
+                                      knd, la, lm, scale, stream))
+        for j in range(m):
+            yield lo + j, buf[j]
+
+
 def generate(kind: str, seeds, n: int, dim: int, truncation: float = 1.0, workers=None):
     """Yield the z batches for ``seeds`` in order (NumPy arrays the caller may keep).  StyleGAN batches come from the
     library's native generator; BigGAN's ``truncnorm.rvs`` batches from worker subprocesses when the job is large

@@ -61,7 +61,7 @@ __global__ void mm64_zero_kernel(double *__restrict__ C, int N, int64_t ldc) {
 // KSPLIT = true : grid (N/16, M/16, zsplit); the 4 waves of a workgroup take quarters of the K range of ONE tile.
 // KSPLIT = false: grid (N/32, M/32, zsplit); wave w owns tile (w >> 1, w & 1) of a 32 x 32 block, full K range.
 // CH: k values a wave loads ahead of its MFMAs (32 or 128).
-// LEAN (measurement build only, GS_MM64_LEAN=1; written after round 4's GPU budget was spent, not run yet): the ISA of the
+// LEAN (the variant the launcher uses since round 5): the ISA of the
 // plain variant guards each of the 2 x CH / 4 operand loads of a chunk with its own branch (`br G br G ...`, ~30 clk
 // each: ~0.8 us of a 7.5 us product) and reads the two epilogue operands with a round trip each.  LEAN takes whole
 // chunks of whole tiles - the only case the solver chains produce - without any predicate, and issues both epilogue
@@ -207,40 +207,23 @@ void mm64(int M, int N, int K, const double *A, int64_t a_i, int64_t a_t, const 
     const int ts = ksplit ? 16 : 32;
     const int ntc = (int)ceil_div(N, ts), nrl = (int)ceil_div(ceil_div(M, ts), 8);
     const dim3 grid((unsigned)(8 * nrl * ntc * zs));
-    static const bool lean = gs_knob("GS_MM64_LEAN") != nullptr;          // (measurement build: the round-5 candidate)
-    if (lean) {
+    // (the LEAN variant - round 5: validated by tests/test_gpu_topk.py, 0.95 -> 0.92 ms on the exact finalize - is the one
+    //  launched; it falls back to the predicated loads by itself for a partial tile or chunk)
 #define GS_MM64_GO(KS, CHV)                                                                                           \
     GS_LAUNCH((mm64_kernel<KS, CHV, true>), grid, dim3(256), 0, stream, M, N, K, A, a_i, a_t, B, b_t, b_j, C, ldc, alpha, \
               beta, kchunk, ntc, nrl, epi)
-        if (ksplit) {
-            if (kchunk <= 128)
-                GS_MM64_GO(true, 32);
-            else
-                GS_MM64_GO(true, 128);
-        } else {
-            if (kchunk <= 32)
-                GS_MM64_GO(false, 32);
-            else
-                GS_MM64_GO(false, 128);
-        }
-#undef GS_MM64_GO
-        return;
-    }
     if (ksplit) {
         if (kchunk <= 128)
-            GS_LAUNCH((mm64_kernel<true, 32>), grid, dim3(256), 0, stream, M, N, K, A, a_i, a_t, B, b_t, b_j, C, ldc, alpha,
-                      beta, kchunk, ntc, nrl, epi);
+            GS_MM64_GO(true, 32);
         else
-            GS_LAUNCH((mm64_kernel<true, 128>), grid, dim3(256), 0, stream, M, N, K, A, a_i, a_t, B, b_t, b_j, C, ldc, alpha,
-                      beta, kchunk, ntc, nrl, epi);
+            GS_MM64_GO(true, 128);
     } else {
         if (kchunk <= 32)
-            GS_LAUNCH((mm64_kernel<false, 32>), grid, dim3(256), 0, stream, M, N, K, A, a_i, a_t, B, b_t, b_j, C, ldc, alpha,
-                      beta, kchunk, ntc, nrl, epi);
+            GS_MM64_GO(false, 32);
         else
-            GS_LAUNCH((mm64_kernel<false, 128>), grid, dim3(256), 0, stream, M, N, K, A, a_i, a_t, B, b_t, b_j, C, ldc, alpha,
-                      beta, kchunk, ntc, nrl, epi);
+            GS_MM64_GO(false, 128);
     }
+#undef GS_MM64_GO
 }
 
 // ---------------------------------------------------------------------------------------------------------------

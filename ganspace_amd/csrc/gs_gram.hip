@@ -780,7 +780,8 @@ static void dump_trace(unsigned long long *trace_buf, int grid, hipStream_t stre
     }
 }
 
-static void launch_partial(const GramWorkspace &ws, const GramGeom &g, int buf, const float *Xb, int64_t n,
+// (returns the launcher's status: a launch that did not go out must not be folded - round-4 advisor)
+static int launch_partial(const GramWorkspace &ws, const GramGeom &g, int buf, const float *Xb, int64_t n,
                            int64_t ld, int64_t d, const float *shift, const FoldJob &fold, hipStream_t stream,
                            hipEvent_t done = nullptr) {
     const bool vec = (ld % 4 == 0) && (d % 4 == 0) && ((reinterpret_cast<uintptr_t>(Xb) & 15) == 0);
@@ -811,24 +812,22 @@ static void launch_partial(const GramWorkspace &ws, const GramGeom &g, int buf, 
         // rows not 16-byte aligned: the float4 staging of the wide kernel does not apply - same geometry through the
         // tiled kernel is not possible (different grid), so the caller's geometry must not have chosen it
         set_error("gram: internal - wide geometry for unaligned rows");
-        return;
+        return GS_ESTATE;
     }
     if (g.wide) {
         // (fold workgroups of the previous launch's slabs: the compute workgroups occupy every CU, so they run once
         //  those retire - a whole round of them, up to 128 slabs of 0.56 MB are waiting)
         if (ws.precision == GS_PREC_F32)
-            (void)launch_gram_f32_wide(g.grid, fold.P != nullptr ? 256 : 0, Xb, n, ld, shift, ws.partial[buf],
+            return launch_gram_f32_wide(g.grid, fold.P != nullptr ? 256 : 0, Xb, n, ld, shift, ws.partial[buf],
                                        ws.colsum_partial[buf], g.nchunks, g.plan, fj, stream, done);
-        else
-            (void)launch_gram_bf16_wide(ws.precision, g.grid, fold.P != nullptr ? 256 : 0, Xb, n, ld, shift, ws.partial[buf],
-                                        ws.colsum_partial[buf], g.nchunks, g.plan, fj, stream);
-        return;
+        return launch_gram_bf16_wide(ws.precision, g.grid, fold.P != nullptr ? 256 : 0, Xb, n, ld, shift, ws.partial[buf],
+                                     ws.colsum_partial[buf], g.nchunks, g.plan, fj, stream);
     }
     if (ws.precision != GS_PREC_F32) {
-        (void)launch_gram_bf16(ws.precision, g.grid, nfold, Xb, n, ld, (int)d, shift, ws.partial[buf],
-                               ws.colsum_partial[buf], dp, g.nchunks, g.plan, g.nmt, g.T, fj, stream);
+        const int rcb = launch_gram_bf16(ws.precision, g.grid, nfold, Xb, n, ld, (int)d, shift, ws.partial[buf],
+                                         ws.colsum_partial[buf], dp, g.nchunks, g.plan, g.nmt, g.T, fj, stream);
         dump_trace(trace_buf, g.grid, stream, g.nmt);
-        return;
+        return rcb;
     }
     const dim3 grid((unsigned)(g.grid + nfold));
     // chunks longer than one float32 accumulation span use the variant that carries into float64 registers
@@ -846,6 +845,8 @@ static void launch_partial(const GramWorkspace &ws, const GramGeom &g, int buf, 
         GS_GRAM_LAUNCH(false, false);
 #undef GS_GRAM_LAUNCH
     dump_trace(trace_buf, g.grid, stream, g.nmt);
+    GS_HIP_CHECK(hipGetLastError());
+    return GS_OK;
 }
 
 static FoldJob pending_job(const GramWorkspace &ws, double *G64, double *S1) {
@@ -952,7 +953,9 @@ int gram_update(GramWorkspace &ws, const float *X, int64_t rows, int64_t ld, int
             const bool ext = !no_ext_event && ws.precision == GS_PREC_F32 && !ws.profile;
             {
                 ProfScope prof(ws, stream, n);
-                launch_partial(ws, g, buf, X + base * ld, n, ld, d, shift, FoldJob{}, stream, ext ? ws.ev_comp[buf] : nullptr);
+                const int rcl = launch_partial(ws, g, buf, X + base * ld, n, ld, d, shift, FoldJob{}, stream,
+                                               ext ? ws.ev_comp[buf] : nullptr);
+                if (rcl != GS_OK) return rcl;      // (no kernel went out: nothing recorded ev_comp, nothing to fold)
             }
             if (!ext) GS_HIP_CHECK(hipEventRecord(ws.ev_comp[buf], stream));
             GS_HIP_CHECK(hipStreamWaitEvent(ws.aux, ws.ev_comp[buf], 0));
@@ -974,7 +977,8 @@ int gram_update(GramWorkspace &ws, const float *X, int64_t rows, int64_t ld, int
         const int buf = ws.cur;
         {
             ProfScope prof(ws, stream, n);
-            launch_partial(ws, g, buf, X + base * ld, n, ld, d, shift, f, stream);
+            const int rcl = launch_partial(ws, g, buf, X + base * ld, n, ld, d, shift, f, stream);
+            if (rcl != GS_OK) return rcl;
         }
         ws.pend_valid = true;
         ws.pend_buf = buf;
@@ -1003,9 +1007,9 @@ int gram_partial_time(GramWorkspace &ws, const float *X, int64_t rows, int64_t l
     hipEvent_t e0, e1;
     GS_HIP_CHECK(hipEventCreate(&e0));
     GS_HIP_CHECK(hipEventCreate(&e1));
-    launch_partial(ws, g, buf, X, n, ld, d, shift, nofold, stream);  // warm-up
+    if (const int rcl = launch_partial(ws, g, buf, X, n, ld, d, shift, nofold, stream); rcl != GS_OK) return rcl;  // warm-up
     GS_HIP_CHECK(hipEventRecord(e0, stream));
-    for (int i = 0; i < iters; ++i) launch_partial(ws, g, buf, X, n, ld, d, shift, nofold, stream);
+    for (int i = 0; i < iters; ++i) (void)launch_partial(ws, g, buf, X, n, ld, d, shift, nofold, stream);
     GS_HIP_CHECK(hipEventRecord(e1, stream));
     GS_HIP_CHECK(hipEventSynchronize(e1));
     float ms = 0.f;

@@ -1240,7 +1240,9 @@ int gs_ipca_launch_profile(gs_ipca_t *h, int *launches_host, double *total_ms_ho
 
 int gs_ipca_components_device(gs_ipca_t *h, const float **components, const float **mean) {
     GS_REQUIRE(h != nullptr, GS_EINVAL, "gs_ipca_components_device: NULL handle");
-    GS_REQUIRE(h->finalized && !h->pending_diag && !h->inv_pending, GS_ESTATE,
+    // chain_live: the chain that closes a faithful block runs on the handle's own stream and may still be writing comp32 /
+    // mean32 - this call has no stream argument to order the caller behind it; finalize / lowrank_export join the chain
+    GS_REQUIRE(h->finalized && !h->pending_diag && !h->inv_pending && !h->chain_live, GS_ESTATE,
                "gs_ipca_components_device: call finalize first");
     if (components) *components = h->comp32;
     if (mean) *mean = h->mean32;

@@ -1112,6 +1112,9 @@ int eigh_topk_cheb(SubspaceWorkspace &ws, const double *A, int n, int64_t lda, i
     GemmEpilogue none;
     *converged = 0;
     int mults = 0;
+    // (a clustered spectrum sends THIS solve's retries to the Jacobi projection step; the next matrix gets the
+    //  tridiagonal solver again - round-4 advisor: the flag used to stick to the workspace for good)
+    ws.rr_force_jacobi = false;
 
     // ---- segment A: start basis + estimate cycles, one graph ------------------------------------------------
     double *Qc = nullptr;                  // current orthonormal basis Q

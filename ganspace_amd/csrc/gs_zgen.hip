@@ -1,4 +1,5 @@
-// Host-side latent generation: the reference's z stream, bit for bit, on all the host's cores (no GPU code here).
+// Host-side latent generation: the reference's z stream, bit for bit, on all the host's cores (no GPU code here; the
+// device generator that the HIP path uses since round 5 is gs_zgen_device.hip - same arithmetic, gs_zgen_math.h).
 //
 // The reference draws one seed per mini-batch from NumPy's global legacy stream and generates the batch from a private
 // RandomState(seed).standard_normal(dim * n) (models/wrappers.py:167-174).  That generator - MT19937 (init_genrand
@@ -22,6 +23,7 @@
 #include <vector>
 
 #include "gs_common.h"
+#include "gs_zgen_math.h"
 
 using namespace gs;
 
@@ -135,87 +137,10 @@ struct Mt19937 {
             for (int64_t j = 0; j < n; ++j) {
                 const double u = ((double)(int32_t)(out[2 * j] >> 5) * 67108864.0 + (double)(int32_t)(out[2 * j + 1] >> 6)) /
                                  9007199254740992.0;
-                dst[p + j] = scale * (float)truncnorm_ppf_left(u, log_cdf_a, log_mass);
+                dst[p + j] = scale * (float)zmath::truncnorm_ppf_left(u, log_cdf_a, log_mass);
             }
             p += n;
         }
-    }
-
-    static double polevl(double x, const double *c, int n) {      // Cephes polevl: c[0] x^n + ... + c[n]
-        double a = c[0];
-        for (int i = 1; i <= n; ++i) a = a * x + c[i];
-        return a;
-    }
-    static double p1evl(double x, const double *c, int n) {       // ... with an implicit leading coefficient 1
-        double a = x + c[0];
-        for (int i = 1; i < n; ++i) a = a * x + c[i];
-        return a;
-    }
-    // Cephes ndtri (inverse of the normal CDF; scipy.special.ndtri), coefficients of cephes/ndtri.c
-    static double ndtri(double y0) {
-        static const double P0[5] = {-5.99633501014107895267E1, 9.80010754185999661536E1, -5.66762857469070293439E1,
-                                     1.39312609387279679503E1, -1.23916583867381258016E0};
-        static const double Q0[8] = {1.95448858338141759834E0, 4.67627912898881538453E0,  8.63602421390890590575E1,
-                                     -2.25462687854119370527E2, 2.00260212380060660359E2, -8.20372256168333339912E1,
-                                     1.59056225126211695515E1, -1.18331621121330003142E0};
-        if (y0 == 0.0) return -INFINITY;
-        if (y0 == 1.0) return INFINITY;
-        if (!(y0 > 0.0 && y0 < 1.0)) return NAN;
-        bool negate = true;
-        double y = y0;
-        if (y > 1.0 - 0.13533528323661269189) {       // exp(-2)
-            y = 1.0 - y;
-            negate = false;
-        }
-        if (y > 0.13533528323661269189) {
-            y = y - 0.5;
-            const double y2 = y * y;
-            const double x = y + y * (y2 * polevl(y2, P0, 4) / p1evl(y2, Q0, 8));
-            return x * 2.50662827463100050242E0;      // sqrt(2 pi)
-        }
-        const double x = std::sqrt(-2.0 * std::log(y));
-        const double t = tail(x);
-        return negate ? -t : t;
-    }
-    // x0 - x1 of Cephes ndtri's tail branch for x = sqrt(-2 log y)
-    static double tail(double x) {
-        static const double P1[9] = {4.05544892305962419923E0, 3.15251094599893866154E1,  5.71628192246421288162E1,
-                                     4.40805073893200834700E1, 1.46849561928858024014E1,  2.18663306850790267539E0,
-                                     -1.40256079171354495875E-1, -3.50424626827848203418E-2, -8.57456785154685413611E-4};
-        static const double Q1[8] = {1.57799883256466749731E1,  4.53907635128879210584E1,  4.13172038254672030440E1,
-                                     1.50425385692907503408E1,  2.50464946208309415979E0,  -1.42182922854787788574E-1,
-                                     -3.80806407691578277194E-2, -9.33259480895457427372E-4};
-        static const double P2[9] = {3.23774891776946035970E0, 6.91522889068984211695E0, 3.93881025292474443415E0,
-                                     1.33303460815807542389E0, 2.01485389549179081538E-1, 1.23716634817820021358E-2,
-                                     3.01581553508235416007E-4, 2.65806974686737550832E-6, 6.23974539184983293730E-9};
-        static const double Q2[8] = {6.02427039364742014255E0, 3.67983563856160859403E0, 1.37702099489081330271E0,
-                                     2.16236993594496635890E-1, 1.34204006088543189037E-2, 3.28014464682127739104E-4,
-                                     2.89247864745380683936E-6, 6.79019408009981274425E-9};
-        const double x0 = x - std::log(x) / x;
-        const double z = 1.0 / x;
-        const double x1 = (x < 8.0) ? z * polevl(z, P1, 8) / p1evl(z, Q1, 8) : z * polevl(z, P2, 8) / p1evl(z, Q2, 8);
-        return x0 - x1;
-    }
-    // scipy.special.ndtri_exp (scipy/special/_ndtri_exp.pxd): ndtri(exp(y)) without forming exp(y) where it would lose bits
-    static double ndtri_exp(double y) {
-        if (y < -1.7976931348623157e308) return -INFINITY;
-        if (y < -2.0) {
-            const double x = (y >= -1.7976931348623157e308 * 0.5) ? std::sqrt(-2.0 * y) : 1.4142135623730951 * std::sqrt(-y);
-            return -tail(x);                          // x1 - x0
-        }
-        if (y > -0.14541345786885906) return -ndtri(-std::expm1(y));      // log1p(-exp(-2))
-        return ndtri(std::exp(y));
-    }
-    static double truncnorm_ppf_left(double u, double log_cdf_a, double log_mass) {
-        const double c = std::log(u) + log_mass;
-        double lse;
-        if (c == log_cdf_a) {
-            lse = std::log(2.0) + c;                  // both elements are the maximum: log1p(0 / 2) + log(2) + max
-        } else {
-            const double hi = c > log_cdf_a ? c : log_cdf_a, lo = c > log_cdf_a ? log_cdf_a : c;
-            lse = (std::log1p(std::exp(lo - hi)) + 0.0) + hi;
-        }
-        return ndtri_exp(lse) * 1.0 + 0.0;            // (vals * scale + loc of rv_generic.rvs: turns -0.0 into 0.0)
     }
 };
 

@@ -282,6 +282,16 @@ int gs_zgen_wait(gs_zgen_t *z, int64_t batch, float **slot_host);
 int gs_zgen_release(gs_zgen_t *z, int64_t upto);
 int gs_zgen_finish(gs_zgen_t *z);
 
+/* The same streams generated ON THE DEVICE, one wave per seed (round 5): `out_dev[s * stride + i]`, i < count, is value i
+ * of RandomState(seeds[s]).standard_normal(count) (kind 0; models/wrappers.py:167-174) or of
+ * scale * truncnorm.rvs(-2, 2, size=count, random_state=RandomState(seeds[s])) (kind 1; biggan/.../utils.py:21-33, with
+ * log_cdf_a / log_mass as in gs_zgen_start_truncnorm), cast to float32.  Same arithmetic as the host generator; the device
+ * libm's log / exp stand in for glibc's (float32 rows identical up to isolated 1-ulp differences).  seeds_dev: uint32 on
+ * the device.  Asynchronous on `stream`.                                                                                 */
+int gs_zgen_device(const uint32_t *seeds_dev, int64_t n_seeds, int64_t count, float *out_dev,
+                   int64_t stride, int kind, double log_cdf_a, double log_mass, float scale,
+                   void *stream);
+
 /* z -> w: the StyleGAN2 mapping network `Generator.style` called from
  * models/wrappers.py:177,200 (PixelNorm + L x EqualLinear(dim, dim, lr_mul,
  * activation='fused_lrelu')); in-tree analogue models/stylegan/model.py:190-216.

@@ -1,0 +1,91 @@
+"""The device latent generator (csrc/gs_zgen_device.hip, one wave per seed) against the generators the reference calls:
+``np.random.RandomState(seed).standard_normal`` (models/wrappers.py:167-174) and BigGAN's
+``truncnorm.rvs(-2, 2, random_state=RandomState(seed))`` (biggan/.../utils.py:21-33).
+
+The integer part of the stream (MT19937, the 53-bit doubles, the polar method's accept / reject decisions, the order of
+the accepted pairs) must agree exactly - one flipped decision would shift every later value.  The float64 ``log`` /
+``exp`` behind the accepted values are the device libm's instead of glibc's: the float32 rows may differ in isolated
+values by ONE float32 ulp (expected: about one value in 1e8); the bound asserted here is <= 1 ulp, <= 1e-5 of the values."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a HIP device")
+    return torch.device("cuda", 0)
+
+
+def _ulp_diff(a, b):
+    ai = a.view(np.int32).astype(np.int64)
+    bi = b.view(np.int32).astype(np.int64)
+    ai = np.where(ai < 0, np.int64(-2147483648) - ai, ai)      # order-preserving map of the float32 bit patterns
+    bi = np.where(bi < 0, np.int64(-2147483648) - bi, bi)
+    return np.abs(ai - bi)
+
+
+def _check_rows(got, want):
+    assert got.shape == want.shape and got.dtype == want.dtype == np.float32
+    d = _ulp_diff(got, want)
+    assert d.max() <= 1, (d.max(), int((d > 0).sum()))
+    assert (d > 0).mean() <= 1e-5, int((d > 0).sum())
+
+
+@pytest.mark.parametrize("n,dim", [(37, 64), (3, 5), (1, 1), (1, 2), (61, 4), (1000, 512)])
+def test_device_normals_match_numpy_randomstate(dev, n, dim):
+    from ganspace_amd import _zgen
+    seeds = [0, 1, 12345, 2 ** 31 - 2, 987654321]
+    got = {i: z.cpu().numpy() for i, z in _zgen.device_batches("stylegan", seeds, n, dim, dev)}
+    assert sorted(got) == list(range(len(seeds)))
+    for i, s in enumerate(seeds):
+        want = np.random.RandomState(s).standard_normal(n * dim).astype(np.float32).reshape(n, dim)
+        _check_rows(got[i], want)
+
+
+@pytest.mark.parametrize("n,dim,trunc", [(20, 128, 1.0), (7, 128, 0.7), (1, 3, 1.0), (500, 128, 0.4)])
+def test_device_truncated_normals_match_scipy(dev, n, dim, trunc):
+    from scipy.stats import truncnorm
+    from ganspace_amd import _zgen
+    seeds = [3, 250, 2 ** 31 - 7]
+    got = {i: z.cpu().numpy() for i, z in _zgen.device_batches("biggan", seeds, n, dim, dev, truncation=trunc)}
+    for i, s in enumerate(seeds):
+        vals = truncnorm.rvs(-2, 2, size=(n, dim), random_state=np.random.RandomState(s)).astype(np.float32)
+        _check_rows(got[i], (np.float32(trunc) * vals).astype(np.float32))
+        assert np.abs(got[i]).max() <= 2.0 * trunc + 1e-6
+
+
+def test_device_generator_groups_and_many_seeds(dev):
+    """More seeds than one launch group takes: the groups tile the seed list in order."""
+    from ganspace_amd import _zgen
+    seeds = list(range(100, 100 + 21))
+    got = [z.cpu().numpy() for _, z in _zgen.device_batches("stylegan", seeds, 16, 8, dev, group=8)]
+    assert len(got) == 21
+    for s, g in zip(seeds, got):
+        _check_rows(g, np.random.RandomState(s).standard_normal(128).astype(np.float32).reshape(16, 8))
+
+
+def test_presample_device_and_host_generators_agree(dev, monkeypatch):
+    """``decomposition._presample`` through the device generator and through the host thread pool (``GANSPACE_ZGEN=host``):
+    the same latents (W space: the mapping network of equal z rows) and the same state of the global stream afterwards."""
+    from ganspace_amd import decomposition as dec
+    from ganspace_amd.wrappers import get_instrumented_model
+    inst = get_instrumented_model("StyleGAN2", "ffhq", "style", dev)
+    model = inst.model
+    model.use_w()
+    plan = dec._Plan.make(3000, 500, 20)
+    outs = []
+    for mode in ("device", "host"):
+        monkeypatch.setenv("GANSPACE_ZGEN", mode)
+        np.random.seed(dec.SEED_SAMPLING)
+        lat, row0 = dec._presample(model, plan, model.get_latent_shape(), dev)
+        outs.append((lat.cpu().numpy(), row0, np.random.randint(1 << 30)))
+    (a, ra, sa), (b, rb, sb) = outs
+    assert ra == rb == 0 and sa == sb and a.shape == b.shape
+    # the mapping network amplifies a one-ulp difference of a z entry: allow isolated rows to differ at float32 roundoff
+    rel = np.abs(a - b).max(axis=1) / np.abs(b).max()
+    assert (rel > 1e-5).mean() <= 1e-3 and rel.max() < 1e-3, (rel.max(), (rel > 1e-5).mean())
+    inst.close()

@@ -282,3 +282,32 @@ def test_modulated_conv_shared_weight_form_equals_the_grouped_form(k, demod, up)
         a, b = m(x, style), m.forward_grouped(x, style)
     assert a.shape == b.shape == (5, 7, 12 if up else 6, 12 if up else 6)
     assert torch.allclose(a, b, rtol=1e-10, atol=1e-12)
+
+
+@pytest.mark.parametrize("k,cin,cout", [(3, 12, 8), (1, 10, 3), (3, 5, 7)])
+def test_modulated_conv_im2col_product_equals_conv2d(monkeypatch, k, cin, cout):
+    """``ModulatedConv2d._conv_hip`` (device path: NHWC patches x weight matrix through ``gs_linear_forward``) indexes the
+    same products as ``F.conv2d``: the GEMM call is replaced by a float64 matmul here, the patch / weight layout, the
+    padding to multiples of 4 columns and the sub-batching are the product's own."""
+    import torch
+    import torch.nn.functional as F
+    from ganspace_amd import wrappers
+    torch.manual_seed(5)
+    m = wrappers.ModulatedConv2d(cin, cout, k, 16).double()
+    x = torch.randn(6, cin, 5, 7, dtype=torch.float64)
+    calls = []
+
+    def fake_linear(cols, w, b):
+        assert cols.shape[1] % 4 == 0 and cols.shape[1] == w.shape[1] and b is None
+        calls.append(cols.shape[0])
+        return cols @ w.T
+    monkeypatch.setattr(wrappers.ops, "linear_forward", fake_linear)
+    with torch.no_grad():
+        got = m._conv_hip(x)
+        ref = F.conv2d(x, m.scale * m.weight[0], padding=k // 2)
+    assert got.shape == ref.shape and torch.allclose(got, ref, rtol=1e-12, atol=1e-12)
+    assert sum(calls) == 6 * 5 * 7
+    # a weight update invalidates the cached matrix
+    with torch.no_grad():
+        m.weight.mul_(2.0)
+        assert torch.allclose(m._conv_hip(x), 2 * ref, rtol=1e-12, atol=1e-12)
