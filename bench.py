@@ -105,7 +105,8 @@ def gram_kernel_us(lib, _lib, est, block, iters=50, reps=3):
 def e2e_runs(dev, args):
     """``get_or_compute`` for BASELINE config 3 (BigGAN-512 ``generator.gen_z``, n = 1e6, ``-b`` pinned to 2000: the README
     command leaves it to the auto-tuner) and config 5 (StyleGAN2 ``convs.2``, d = 131 072, at the n the run
-    can afford: the conv prefix is PyTorch-ROCm).  Phase times from ``decomposition.LAST_TIMINGS``.  cfg3's activation is
+    run is asked for - BASELINE's 1e6 by default since round 5: the synthetic generator's convolutions go through the f32-MFMA
+    GEMM, 24 us per sample).  Phase times from ``decomposition.LAST_TIMINGS``.  cfg3's activation is
     affine in z, so the exact PCA of ALL n activations follows from the 128 x 128 latent covariance: an independent
     float64 reference at the full n for the top components (parity with scikit-learn itself at reduced n:
     tests/test_gpu_decomposition.py)."""
@@ -120,7 +121,7 @@ def e2e_runs(dev, args):
     jobs = (("cfg3_biggan512_gen_z", dict(model="BigGAN-512", layer="generator.gen_z", output_class=250, n=1_000_000,
                                           batch_size=2000, components=K_COMP, estimator="ipca")),
             ("cfg5_stylegan2_convs2", dict(model="StyleGAN2", layer="convs.2", output_class="ffhq", n=args.e2e_cfg5_n,
-                                           batch_size=250, components=K_COMP, estimator="ipca")))
+                                           batch_size=500, components=K_COMP, estimator="ipca")))
     for name, kw in jobs:
         run_dir = tempfile.mkdtemp(prefix="gs_bench_e2e_")
         try:
@@ -246,7 +247,9 @@ def main():
                          "d = 131 072) come last and stop taking blocks when the next one would not fit (>= 2 are always timed)")
     ap.add_argument("--wide-cpu-blocks", type=int, default=6, help="blocks of that baseline (first + steady-state ones)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end get_or_compute runs of cfg3 / cfg5")
-    ap.add_argument("--e2e-cfg5-n", type=int, default=20_000, help="samples of the cfg5 end-to-end run (conv prefix in PyTorch)")
+    ap.add_argument("--e2e-cfg5-n", type=int, default=1_000_000,
+                    help="samples of the cfg5 end-to-end run (BASELINE's n; ~60 s: the conv prefix runs twice - fit and regression - "
+                         "at ~24 us per sample through the f32-MFMA GEMM)")
     ap.add_argument("--wide-cpu-threads", type=int, default=32, help="BLAS threads of that baseline")
     ap.add_argument("--no-extras", action="store_true", help="headline + roofline only (profiling runs)")
     args = ap.parse_args()

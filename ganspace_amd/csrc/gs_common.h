@@ -386,7 +386,7 @@ struct SmallSide {
     int64_t d = 0;
     int k = 0, m_cap = 0, r_cap = 0, rp = 0, kp = 0, nsplit = 0;
     int precision = 0;       // GS_PREC_*: contraction of T = M M^T (f32 MFMA, or split-bf16 MFMA)
-    int *tile_order = nullptr;   // [nmt][2] upper-triangle tiles of T in 4 x 4 blocks (XCD-local panel reuse)
+    int *tile_order = nullptr;   // [nmt][2] upper-triangle tiles of T in 8 x 8 blocks (XCD-local panel reuse)
     int order_T = 0;             // tile count per side the table was built for
     int order_cap = 0;           // entries the table can hold
     float *M = nullptr;      // [rp][d]  stacked matrix
