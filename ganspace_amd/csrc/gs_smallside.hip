@@ -87,7 +87,7 @@ using f32x4v = __attribute__((ext_vector_type(4))) float;
 // conditional values and spilled 84-112 registers; five copies of the loop cost code size only.
 // PROBE (measurement build only): 0 = the kernel; 1 = no DMA after the first stage (matrix pipe + LDS reads alone);
 // 2 = no MFMA (DMA + barriers alone)
-template <int PROBE, int PAT, bool SPREAD>
+template <int PROBE, int PAT>
 __device__ __forceinline__ void rowgram_dma_body(unsigned char *ring, const float *__restrict__ M, int npan,
                                                  double *__restrict__ out, int rp, int I, int J, int64_t kb0, int nst,
                                                  int wave, int lane) {
@@ -117,18 +117,7 @@ __device__ __forceinline__ void rowgram_dma_body(unsigned char *ring, const floa
         }
     };
 
-    // SPREAD (measurement build, GS_ROWGRAM_SPREAD=1): piece i of the next stage goes out in front of MFMA group i instead of
-    // all eight pieces in front of group 0
-    auto issue_part = [&](int s, int i) {
-        unsigned char *dst = ring + (s & 1) * kStageBytes + wave * 4096 + i * 1024;
-        __builtin_amdgcn_global_load_lds((ss_glb_void *)(uintptr_t)(srcA + (int64_t)s * kbstride + i * 1024),
-                                         (ss_lds_void *)(uint32_t)(uintptr_t)dst, 16, 0, 0);
-        if (!diag)
-            __builtin_amdgcn_global_load_lds((ss_glb_void *)(uintptr_t)(srcB + (int64_t)s * kbstride + i * 1024),
-                                             (ss_lds_void *)(uint32_t)(uintptr_t)(dst + kUnitBytes), 16, 0, 0);
-    };
-    constexpr bool kSpread = SPREAD && PAT != 4 && PROBE == 0;
-
+    // (issuing the pieces one per MFMA group instead of all eight in front of group 0 measured 8 % SLOWER, round 5)
     f32x16 acc0 = {0}, acc1 = {0}, acc2 = {0}, acc3 = {0};
     double acc64[4][16];
 #pragma unroll
@@ -172,8 +161,7 @@ __device__ __forceinline__ void rowgram_dma_body(unsigned char *ring, const floa
             GS_RG_READ(p0, p1, p2, p3, 0)                   // (its LDS round trip hides behind the address arithmetic of the DMA)
         }
         __builtin_amdgcn_sched_barrier(0);
-        const bool more = s + 1 < nst;
-        if (!kSpread && more && (PROBE != 1)) issue(s + 1);
+        if (s + 1 < nst && (PROBE != 1)) issue(s + 1);
         __builtin_amdgcn_sched_barrier(0);
         if (PAT != 4) {
             // group g + 1's operands are requested BEFORE group g's sixteen MFMAs (scheduling barriers: left alone the
@@ -181,25 +169,20 @@ __device__ __forceinline__ void rowgram_dma_body(unsigned char *ring, const floa
             // with the matrix pipe idle)
             GS_DSWAIT4(p0, p1, p2, p3);
             GS_RG_READ(q0, q1, q2, q3, 1)
-            if (kSpread && more) issue_part(s + 1, 0);
             __builtin_amdgcn_sched_barrier(0);
             GS_RG_MMA(p0, p1, p2, p3)
             __builtin_amdgcn_sched_barrier(0);
             GS_DSWAIT4(q0, q1, q2, q3);
             GS_RG_READ(p0, p1, p2, p3, 2)
-            if (kSpread && more) issue_part(s + 1, 1);
             __builtin_amdgcn_sched_barrier(0);
             GS_RG_MMA(q0, q1, q2, q3)
             __builtin_amdgcn_sched_barrier(0);
             GS_DSWAIT4(p0, p1, p2, p3);
             GS_RG_READ(q0, q1, q2, q3, 3)
-            if (kSpread && more) issue_part(s + 1, 2);
             __builtin_amdgcn_sched_barrier(0);
             GS_RG_MMA(p0, p1, p2, p3)
             __builtin_amdgcn_sched_barrier(0);
             GS_DSWAIT4(q0, q1, q2, q3);
-            if (kSpread && more) issue_part(s + 1, 3);
-            __builtin_amdgcn_sched_barrier(0);
             GS_RG_MMA(q0, q1, q2, q3)
             if ((s + 1) % kFlushStages == 0 || s + 1 == nst) {
                 // float64 carry: bounds every float32 fma chain to 1024 products
@@ -228,7 +211,7 @@ __device__ __forceinline__ void rowgram_dma_body(unsigned char *ring, const floa
     }
 }
 
-template <int PROBE, bool SPREAD = false>
+template <int PROBE>
 __global__ __launch_bounds__(256, 2) void rowgram_dma_kernel(const float *__restrict__ M, int64_t d, int npan,
                                                              double *__restrict__ slab, int rp, int nmt,
                                                              int64_t kchunk, const int2 *__restrict__ order, int total,
@@ -258,11 +241,11 @@ __global__ __launch_bounds__(256, 2) void rowgram_dma_kernel(const float *__rest
     double *out = slab + (int64_t)split * rp * rp;
     const int64_t kb0 = k_begin >> 5;
     switch (pat) {
-        case 0: rowgram_dma_body<PROBE, 0, SPREAD>(ring, M, npan, out, rp, I, J, kb0, nst, wave, lane); break;
-        case 1: rowgram_dma_body<PROBE, 1, SPREAD>(ring, M, npan, out, rp, I, J, kb0, nst, wave, lane); break;
-        case 2: rowgram_dma_body<PROBE, 2, SPREAD>(ring, M, npan, out, rp, I, J, kb0, nst, wave, lane); break;
-        case 3: rowgram_dma_body<PROBE, 3, SPREAD>(ring, M, npan, out, rp, I, J, kb0, nst, wave, lane); break;
-        default: rowgram_dma_body<PROBE, 4, SPREAD>(ring, M, npan, out, rp, I, J, kb0, nst, wave, lane); break;
+        case 0: rowgram_dma_body<PROBE, 0>(ring, M, npan, out, rp, I, J, kb0, nst, wave, lane); break;
+        case 1: rowgram_dma_body<PROBE, 1>(ring, M, npan, out, rp, I, J, kb0, nst, wave, lane); break;
+        case 2: rowgram_dma_body<PROBE, 2>(ring, M, npan, out, rp, I, J, kb0, nst, wave, lane); break;
+        case 3: rowgram_dma_body<PROBE, 3>(ring, M, npan, out, rp, I, J, kb0, nst, wave, lane); break;
+        default: rowgram_dma_body<PROBE, 4>(ring, M, npan, out, rp, I, J, kb0, nst, wave, lane); break;
     }
 }
 
@@ -923,9 +906,11 @@ int smallside_update(SmallSide &ss, const float *X, int64_t rows, int64_t ldx, d
     const int Tt = (int)ceil_div(r, kRT), nmt = Tt * (Tt + 1) / 2;
     const int64_t kchunk = round_up(ceil_div(d, ss.nsplit), kRK);
     if (ss.order_T != Tt) {
-        // upper-triangle tiles listed in 8 x 8 blocks (see rowgram_assign): the 64 workgroups resident on an XCD then
-        // share 16 panels (4 x 4 blocks: up to 32 - 43 % L2 hit rate, 12.6 GB of fabric reads per launch for a 1.09 GB
-        // matrix, profiles/r05_smallside.md)
+        // upper-triangle tiles listed in 8 x 8 blocks (see rowgram_assign): the 64 workgroups resident on an XCD share 16
+        // panels.  Measured (profiles/r05_smallside.md): 4 x 4, 8 x 8 and one 17 x 17 block give the same 35-43 % L2 hit
+        // rate and the same launch time - the co-resident workgroups drift apart by more stages than the 4 MB L2 holds
+        // (2 MB of panels per stage and XCD); the 12 GB of fabric reads per launch come out of the Infinity Cache at
+        // 2.1 TB/s and do not bound the launch (no-MFMA probe: 1.3 ms)
         static const int blk = (gs_knob("GS_SS_ORDER_BLOCK") && atoi(gs_knob("GS_SS_ORDER_BLOCK")) > 0)
                                    ? atoi(gs_knob("GS_SS_ORDER_BLOCK")) : 8;      // (measurement build: 4 = rounds 3-4)
         std::vector<int> ord;
@@ -948,11 +933,7 @@ int smallside_update(SmallSide &ss, const float *X, int64_t rows, int64_t ldx, d
     if (ss.precision == GS_PREC_F32) {
         // (measurement build: GS_ROWGRAM_PROBE=1 no DMA after the first stage, =2 no MFMA - what bounds a stage)
         static const char *probe = gs_knob("GS_ROWGRAM_PROBE");
-        static const bool spread = gs_knob("GS_ROWGRAM_SPREAD") != nullptr;
-        if (spread)
-            hipLaunchKernelGGL((rowgram_dma_kernel<0, true>), dim3(rgrid), dim3(256), 0, stream, ss.M, d, npan, ss.slab, rp, nmt,
-                               kchunk, order, total, r);
-        else if (probe != nullptr && probe[0] == '1')
+        if (probe != nullptr && probe[0] == '1')
             hipLaunchKernelGGL(rowgram_dma_kernel<1>, dim3(rgrid), dim3(256), 0, stream, ss.M, d, npan, ss.slab, rp, nmt,
                                kchunk, order, total, r);
         else if (probe != nullptr && probe[0] == '2')
