@@ -3,6 +3,7 @@ the command the rocprofv3 kernel traces under profiles/ are taken of.
 
     python tools/e2e_job.py cfg3 [n] [batch]      BigGAN-512 generator.gen_z (d = 32 768)
     python tools/e2e_job.py cfg5 [n] [batch]      StyleGAN2 convs.2          (d = 131 072)
+    python tools/e2e_job.py cfg2 [n] [batch]      StyleGAN2 W space, ipca-exact (d = 512; cfg2f: the faithful `ipca`)
 """
 import contextlib, json, os, shutil, sys, tempfile, time
 from types import SimpleNamespace
@@ -16,6 +17,9 @@ which = sys.argv[1] if len(sys.argv) > 1 else "cfg3"
 if which == "cfg3":
     kw = dict(model="BigGAN-512", layer="generator.gen_z", output_class=250, n=1_000_000, batch_size=2000, components=80,
               estimator="ipca")
+elif which in ("cfg2", "cfg2f"):
+    kw = dict(model="StyleGAN2", layer="style", output_class="ffhq", use_w=True, n=1_000_000, batch_size=10_000, components=80,
+              estimator="ipca-exact" if which == "cfg2" else "ipca")
 else:
     kw = dict(model="StyleGAN2", layer="convs.2", output_class="ffhq", n=20_000, batch_size=250, components=80,
               estimator="ipca")
@@ -27,7 +31,7 @@ dev = torch.device("cuda", 0)
 cfg = Config(**kw)
 run_dir = tempfile.mkdtemp(prefix="gs_e2e_")
 try:
-    inst = get_instrumented_model(cfg.model, cfg.output_class, cfg.layer, dev)
+    inst = get_instrumented_model(cfg.model, cfg.output_class, cfg.layer, dev, **({"use_w": True} if kw.get("use_w") else {}))
     torch.cuda.synchronize()
     dec.PROFILE = True
     t0 = time.perf_counter()
