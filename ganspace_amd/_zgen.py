@@ -163,9 +163,9 @@ def device_generation_enabled(device) -> bool:
 def device_batches(kind: str, seeds, n: int, dim: int, device, truncation: float = 1.0, group: int = 256):
     """Yield ``(index, z)`` for ``seeds`` in order, ``z`` a ``[n, dim]`` float32 DEVICE tensor holding
     ``RandomState(seed).standard_normal(n * dim)`` (``kind="stylegan"``) or BigGAN's
-    ``truncation * truncnorm.rvs(-2, 2, size=(n, dim), random_state=RandomState(seed))`` - generated on the device, one wave
-    per seed, ``group`` seeds per launch (a launch lasts as long as ONE stream whatever the group: the groups are sized to put
-    a wave on every CU, 256 x n x dim floats of staging).  Nothing touches the host: no pinned ring, no H2D copy."""
+    ``truncation * truncnorm.rvs(-2, 2, size=(n, dim), random_state=RandomState(seed))`` - generated on the device, one
+    workgroup (four waves) per seed, ``group`` seeds per launch (a launch lasts as long as ONE stream whatever the group: the
+    groups are sized to put a stream on every CU, 256 x n x dim floats of staging).  Nothing touches the host: no pinned ring, no H2D copy."""
     import ctypes as C
     import torch
     from . import _lib

@@ -282,7 +282,7 @@ int gs_zgen_wait(gs_zgen_t *z, int64_t batch, float **slot_host);
 int gs_zgen_release(gs_zgen_t *z, int64_t upto);
 int gs_zgen_finish(gs_zgen_t *z);
 
-/* The same streams generated ON THE DEVICE, one wave per seed (round 5): `out_dev[s * stride + i]`, i < count, is value i
+/* The same streams generated ON THE DEVICE, one workgroup (four waves) per seed (round 5): `out_dev[s * stride + i]`, i < count, is value i
  * of RandomState(seeds[s]).standard_normal(count) (kind 0; models/wrappers.py:167-174) or of
  * scale * truncnorm.rvs(-2, 2, size=count, random_state=RandomState(seeds[s])) (kind 1; biggan/.../utils.py:21-33, with
  * log_cdf_a / log_mass as in gs_zgen_start_truncnorm), cast to float32.  Same arithmetic as the host generator; the device
