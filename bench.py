@@ -530,7 +530,7 @@ def main():
         out["end_to_end"] = {
             "gpu": {"T_sample_s": round(t_sample, 3), "T_fit_s": round(dt, 5), "T_total_s": round(gpu_total, 3),
                     "samples_per_s": round(samples / gpu_total, 1),
-                    "note": "T_sample = z stream on host worker processes + pinned H2D + HIP mapping network; T_fit = the "
+                    "note": "T_sample = z stream from the device generator (gs_zgen_device) + HIP mapping network; T_fit = the "
                             "timed region of `value`"},
             "cpu": {"T_sample_s": round(cpu_sample, 2), "T_fit_s": round(t_job_cpu, 2),
                     "T_total_s": round(cpu_sample + t_job_cpu, 2),
