@@ -403,9 +403,6 @@ struct SmallSide {
     // diagonalisation deferred (see invsub_iterate): the caller's V then holds W = Q^T M (k x d, W W^T = Bk, the
     // truncated operator in an undiagonalised basis) instead of unit components, and lam is stale
     bool w_state = false;
-    // the invariant-subspace step of the last block is enqueued, its verdict not read yet (smallside_resolve): V / lam /
-    // w_state describe the block BEFORE it until then
-    bool pending = false;
     int last_r = 0;          // rows of M in the last update
     double *Bk = nullptr;    // [k][k]   Q^T T Q of the last deferred block
     double *Qc = nullptr;    // [rp][kp] Q U scratch of smallside_materialize
@@ -414,11 +411,7 @@ int smallside_alloc(SmallSide &ss, int64_t d, int k, int m);
 void smallside_free(SmallSide &ss);
 int smallside_update(SmallSide &ss, const float *X, int64_t rows, int64_t ldx, double n0, float *V, double *lam,
                      double *mean, double *m2, double *vec, double *bs, int *sweeps_out, hipStream_t stream);
-// finish the step smallside_update left in flight (no-op otherwise); smallside_update and smallside_materialize call it
-int smallside_resolve(SmallSide &ss, float *V, double *lam, int *sweeps_out, hipStream_t stream);
-int smallside_solve_rr(SmallSide &ss, int r, bool warm, float *V, double *lam, int *sweeps_out, hipStream_t stream);
-void smallside_abandon(SmallSide &ss);      // wait for and drop a step in flight (reset / free)
-// (pending or) w_state -> unit components in V (sklearn's sign convention) and their eigenvalues in lam
+// w_state -> unit components in V (sklearn's sign convention) and their eigenvalues in lam
 int smallside_materialize(SmallSide &ss, float *V, double *lam, int *sweeps_out, hipStream_t stream);
 
 }  // namespace gs

@@ -914,7 +914,6 @@ int gs_ipca_reset(gs_ipca_t *h) {
     h->sws.plan_valid = false;
     h->sws.inv_plan = 0;
     h->sws.inv_ratio1 = 0.0;
-    smallside_abandon(h->ss);
     h->ss.sws.inv_plan = 0;
     h->ss.sws.inv_ratio1 = 0.0;
     h->ss.w_state = false;
@@ -945,7 +944,7 @@ int gs_ipca_update(gs_ipca_t *h, const float *X, int64_t rows, int64_t ld, void 
             // A block taller than any before (sklearn's fit() merges a short tail into the last batch: up to
             // batch_size + k - 1 rows) needs larger buffers.  A deferred state (comp32 = W = Q^T M, lam stale) refers
             // to the M and Bk about to be freed: fold the pending diagonalisation back into (V, lam) first.
-            if (h->ss.M != nullptr && (h->ss.w_state || h->ss.pending)) {
+            if (h->ss.M != nullptr && h->ss.w_state) {
                 int rcm = smallside_materialize(h->ss, h->comp32, h->lam, &h->last_sweeps, stream);
                 if (rcm != GS_OK) return rcm;
                 h->pending_diag = false;
@@ -962,9 +961,7 @@ int gs_ipca_update(gs_ipca_t *h, const float *X, int64_t rows, int64_t ld, void 
         h->last_mults = h->ss.last_mults;
         h->n_seen += rows;
         h->blocks += 1;
-        // comp32 holds W and lam is stale (w_state), or the block's subspace step is still in flight (pending): gs_ipca_finalize
-        // resolves / materialises
-        h->pending_diag = h->ss.w_state || h->ss.pending;
+        h->pending_diag = h->ss.w_state;    // comp32 holds W, lam is stale: gs_ipca_finalize materialises
         // (sum of m2 left behind the second moments by ss_m2_kernel)
         hipLaunchKernelGGL(derive_outputs_kernel, dim3(1), dim3(256), 0, stream, h->lam, h->ss.colsq + h->d, 1, h->outs,
                            h->k, (double)h->n_seen);

@@ -869,16 +869,7 @@ int smallside_alloc(SmallSide &ss, int64_t d, int k, int m) {
     return rc;
 }
 
-// a deferred invariant-subspace step (ss.pending) still owns T, M, Uk, Bk and the solver workspace: wait it out and drop it
-void smallside_abandon(SmallSide &ss) {
-    if (!ss.pending) return;
-    (void)hipDeviceSynchronize();
-    ss.sws.inv.active = false;
-    ss.pending = false;
-}
-
 void smallside_free(SmallSide &ss) {
-    smallside_abandon(ss);
     void *ptrs[] = {ss.M, ss.T, ss.slab, ss.Ct, ss.Vtmp, ss.colsq, ss.Uk, ss.wk, ss.tile_order, ss.Bk, ss.Qc};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -906,9 +897,6 @@ int smallside_update(SmallSide &ss, const float *X, int64_t rows, int64_t ldx, d
     const unsigned gd = (unsigned)ceil_div(d, 256);
     hipLaunchKernelGGL(ss_stats_kernel, dim3(gd), dim3(256), 0, stream, bs, mean, vec, d, n0, (double)m);
     hipLaunchKernelGGL(ss_m2_kernel, dim3(gd), dim3(256), 0, stream, ss.colsq, bs, vec, m2, d, n0, (double)m, ss.colsq + d);
-    // (the previous block's invariant-subspace step: its verdict decides what the state rows of this block's M are)
-    rc = smallside_resolve(ss, V, lam, sweeps_out, stream);
-    if (rc != GS_OK) return rc;
     // 2. M = [S V ; X - bm ; mc ; 0]
     const int npan = rp / kRT;
     hipLaunchKernelGGL(ss_build_kernel, dim3((unsigned)ceil_div(ceil_div(d, 32), kBuildKB), (unsigned)npan), dim3(256), 0,
@@ -977,44 +965,37 @@ int smallside_update(SmallSide &ss, const float *X, int64_t rows, int64_t ldx, d
     // 5. leading k eigenpairs of T: subspace iteration (the top-left k x k block of T is diag(S^2), so the
     //    first k unit vectors are a good start from the second block on); full Jacobi as the fallback
     GS_HIP_CHECK(hipMemsetAsync(ss.Ct, 0, sizeof(float) * (size_t)rp * kp, stream));
+    bool done = false;
+    ss.last_mults = 0;
     static const bool no_subspace = gs_knob("GS_EIGH_FULL") != nullptr;
     static const bool eager = gs_knob("GS_FAITHFUL_EAGER") != nullptr;
-    static const bool sync_verdict = gs_knob("GS_SS_SYNC_VERDICT") != nullptr;      // (measurement build: rounds 3-4 behaviour)
+    const int64_t ntn = ceil_div(d, kRT);
     // From the fifth block on: carry W = Q^T M for an orthonormal basis Q of T's leading invariant subspace (rows
     // whose Gram matrix is the truncated operator - exactly what the next block stacks on top of its data) and leave
-    // the diagonalisation to smallside_materialize.  The step is only ENQUEUED here (acceptance test and emit run on the
-    // device): its verdict is read by smallside_resolve - at the start of the next block, behind that block's column
-    // moments, or by whoever reads the state - so that the caller's next forward pass and the moments are already queued
-    // when the host waits: the GPU used to idle through that round trip and the enqueueing around it (0.4 of cfg3's 3.1 ms
-    // per block, profiles/r05_smallside.md).
+    // the diagonalisation to smallside_materialize.
     if (ss.sws.Q != nullptr && !no_subspace && !eager && k <= 128 && k <= ss.sws.p_cap && n0 >= 4.0 * m) {
-        int started = 0;
-        rc = invsub_begin(ss.sws, ss.T, r, rp, k, ss.Uk, rp, ss.Bk, k, n0 / m, stream, /*identity_start=*/true, &started);
+        int mults = 0, converged = 0;
+        rc = invsub_iterate(ss.sws, ss.T, r, rp, k, ss.Uk, rp, ss.Bk, k, n0 / m, &mults, &converged, stream,
+                            /*identity_start=*/true);
         if (rc != GS_OK) return rc;
-        if (started) {
-            ss.pending = true;
-            if (sync_verdict) return smallside_resolve(ss, V, lam, sweeps_out, stream);
+        if (converged) {
+            hipLaunchKernelGGL(ss_coef_plain_kernel, dim3((unsigned)ceil_div(rp, 256), (unsigned)k), dim3(256), 0, stream,
+                               ss.Uk, (int64_t)rp, r, rp, k, kp, ss.Ct);
+            hipLaunchKernelGGL(tn_gemm_kernel, dim3((unsigned)((kp / kRT) * ntn)), dim3(256), 0, stream, ss.Ct, kp, ss.M, d,
+                               npan, r, ss.Vtmp, d, k);
+            GS_HIP_CHECK(hipMemcpyAsync(V, ss.Vtmp, sizeof(float) * (size_t)k * d, hipMemcpyDeviceToDevice, stream));
+            GS_HIP_CHECK(hipGetLastError());
+            ss.last_mults = mults;
+            ss.w_state = true;
+            if (sweeps_out) *sweeps_out = 0;
             return GS_OK;
         }
     }
-    return smallside_solve_rr(ss, r, n0 > 0, V, lam, sweeps_out, stream);
-}
-
-// Rayleigh-Ritz (or full Jacobi) solve of the block whose T and M sit in the workspace: unit components (sklearn's sign
-// convention) in V, their eigenvalues in lam
-int smallside_solve_rr(SmallSide &ss, int r, bool warm, float *V, double *lam, int *sweeps_out, hipStream_t stream) {
-    const int64_t d = ss.d;
-    const int k = ss.k, rp = ss.rp, kp = ss.kp, npan = ss.rp / kRT;
-    const int64_t ntn = ceil_div(d, kRT);
-    static const bool no_subspace = gs_knob("GS_EIGH_FULL") != nullptr;
-    bool done = false;
-    int rc = GS_OK;
-    ss.w_state = false;    // these paths return unit components and their eigenvalues
-    ss.last_mults = 0;     // (diagnostics of the last RESOLVED block: a deferred step reports one block late)
+    ss.w_state = false;    // the Rayleigh-Ritz paths below return unit components and their eigenvalues
     if (ss.sws.Q != nullptr && subspace_dim(r, k) > 0 && !no_subspace) {
         int mults = 0, converged = 0;
-        rc = eigh_topk_subspace(ss.sws, ss.T, r, rp, k, nullptr, warm ? k : 0, 0, ss.Uk, rp, ss.wk, &mults, &converged,
-                                stream);
+        rc = eigh_topk_subspace(ss.sws, ss.T, r, rp, k, nullptr, n0 > 0 ? k : 0, 0, ss.Uk, rp, ss.wk, &mults,
+                                &converged, stream);
         if (rc != GS_OK) return rc;
         if (converged) {
             hipLaunchKernelGGL(ss_coef_rows_kernel, dim3((unsigned)ceil_div(rp, 256), (unsigned)k), dim3(256), 0,
@@ -1033,7 +1014,7 @@ int smallside_solve_rr(SmallSide &ss, int r, bool warm, float *V, double *lam, i
                            ss.T, (int64_t)rp, ss.ews.norms, ss.ews.offmax + 1, ss.ews.rank, r, rp, k, kp, ss.Ct,
                            lam);
     }
-    // V' = Ct^T M, sign convention
+    // 6. V' = Ct^T M, sign convention
     hipLaunchKernelGGL(tn_gemm_kernel, dim3((unsigned)((kp / kRT) * ntn)), dim3(256), 0, stream, ss.Ct, kp, ss.M, d,
                        npan, r, ss.Vtmp, d, k);
     hipLaunchKernelGGL(ss_sign_kernel, dim3((unsigned)k), dim3(1024), 0, stream, ss.Vtmp, d, V, d);
@@ -1041,36 +1022,7 @@ int smallside_solve_rr(SmallSide &ss, int r, bool warm, float *V, double *lam, i
     return GS_OK;
 }
 
-// The verdict of the invariant-subspace step smallside_update left in flight: on success the caller's V receives
-// W = Q^T M (w_state), otherwise the block is solved again by the Rayleigh-Ritz path - its T and M are still in place,
-// nothing of the next block has touched them.
-int smallside_resolve(SmallSide &ss, float *V, double *lam, int *sweeps_out, hipStream_t stream) {
-    if (!ss.pending) return GS_OK;
-    ss.pending = false;
-    const int64_t d = ss.d;
-    const int k = ss.k, rp = ss.rp, kp = ss.kp, r = ss.last_r, npan = ss.rp / kRT;
-    int mults = 0, converged = 0;
-    const int rc = invsub_finish(ss.sws, stream, &mults, &converged);
-    if (rc != GS_OK) return rc;
-    if (!converged) return smallside_solve_rr(ss, r, true, V, lam, sweeps_out, stream);
-    const int64_t ntn = ceil_div(d, kRT);
-    hipLaunchKernelGGL(ss_coef_plain_kernel, dim3((unsigned)ceil_div(rp, 256), (unsigned)k), dim3(256), 0, stream, ss.Uk,
-                       (int64_t)rp, r, rp, k, kp, ss.Ct);
-    hipLaunchKernelGGL(tn_gemm_kernel, dim3((unsigned)((kp / kRT) * ntn)), dim3(256), 0, stream, ss.Ct, kp, ss.M, d, npan,
-                       r, ss.Vtmp, d, k);
-    GS_HIP_CHECK(hipMemcpyAsync(V, ss.Vtmp, sizeof(float) * (size_t)k * d, hipMemcpyDeviceToDevice, stream));
-    GS_HIP_CHECK(hipGetLastError());
-    ss.last_mults = mults;
-    ss.w_state = true;
-    if (sweeps_out) *sweeps_out = 0;
-    return GS_OK;
-}
-
 int smallside_materialize(SmallSide &ss, float *V, double *lam, int *sweeps_out, hipStream_t stream) {
-    {
-        const int rcp = smallside_resolve(ss, V, lam, sweeps_out, stream);      // (a step still in flight decides w_state)
-        if (rcp != GS_OK) return rcp;
-    }
     if (!ss.w_state) return GS_OK;
     const int k = ss.k, rp = ss.rp, kp = ss.kp, r = ss.last_r, npan = ss.rp / kRT;
     const int64_t d = ss.d;
