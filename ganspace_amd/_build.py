@@ -18,14 +18,14 @@ ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIBDIR = os.environ.get("GS_LIBDIR") or os.path.join(PKG, "lib")     # (GS_LIBDIR: side-by-side measurement builds)
 LIBNAME = "libganspace_hip.so"
-SOURCES = ["gs_collective.hip", "gs_gram.hip", "gs_eigh.hip", "gs_ipca.hip", "gs_linear.hip", "gs_smallside.hip", "gs_subspace.hip", "gs_topk.hip", "gs_gram_bf16.hip", "gs_gram_wide.hip", "gs_zgen.hip", "gs_zgen_device.hip", "gs_rangefinder.hip", "gs_dense64.hip", "gs_tridiag.hip"]
+SOURCES = ["gs_collective.hip", "gs_gram.hip", "gs_eigh.hip", "gs_ipca.hip", "gs_linear.hip", "gs_smallside.hip", "gs_subspace.hip", "gs_topk.hip", "gs_gram_bf16.hip", "gs_gram_wide.hip", "gs_zgen.hip", "gs_zgen_device.hip", "gs_rangefinder.hip", "gs_dense64.hip", "gs_tridiag.hip", "gs_gemm_blocked.hip"]
 
 
 MEASURE_LIBDIR = os.path.join(PKG, "lib_measure")    # -DGS_MEASURE_BUILD: the A/B switches (gs_knob) read the environment
 
 
 # kernels whose build fails if the register allocator gives them scratch (mangled-name substrings)
-NO_SCRATCH = re.compile(r"gram_|rowgram|tn_gemm|tn_rows|linear_act|project_rows|ss_build|mm64_|chol_inv|jacobi_lds|tridiag")
+NO_SCRATCH = re.compile(r"gemm_blocked|block_rows|gram_|rowgram|tn_gemm|tn_rows|linear_act|project_rows|ss_build|mm64_|chol_inv|jacobi_lds|tridiag")
 
 
 def _kernel_usage(remarks: str) -> dict:

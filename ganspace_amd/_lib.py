@@ -67,6 +67,10 @@ SIGNATURES = {
     "gs_linear_forward": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _int, _vp]),
     "gs_project_rows_nbytes": (_int, [_i64, _int, _int, C.POINTER(_i64)]),
     "gs_project_rows": (_int, [_vp, _i64, _i64, _int, _vp, _vp, _int, _vp, _vp, _i64, _vp, _i64, _vp]),
+    "gs_blocked_nbytes": (_int, [_i64, _i64, C.POINTER(_i64)]),
+    "gs_block_rows": (_int, [_vp, _i64, _i64, _i64, _vp, _vp]),
+    "gs_im2col3x3_blocked": (_int, [_vp, _i64, _int, _int, _int, _vp, _vp]),
+    "gs_gemm_blocked_nt": (_int, [_vp, _i64, _vp, _int, _i64, _vp, _i64, _vp]),
 }
 
 _lib = None

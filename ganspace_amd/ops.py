@@ -91,6 +91,48 @@ def linear_forward(x, weight, bias=None):
     return y
 
 
+def _blocked_empty(rows, cols, device):
+    import torch
+    nb = C.c_int64(0)
+    _lib.check(_lib.load().gs_blocked_nbytes(int(rows), int(cols), C.byref(nb)))
+    return torch.empty(nb.value // 4, dtype=torch.float32, device=device)
+
+
+def block_rows(mat):
+    """Row-major ``[rows, cols]`` float32 matrix -> the panel-blocked operand of :func:`gemm_blocked_nt`."""
+    import torch
+    lib = _lib.load()
+    _need_cuda(mat)
+    mat = mat.to(torch.float32).contiguous()
+    rows, cols = mat.shape
+    dst = _blocked_empty(rows, cols, mat.device)
+    _lib.check(lib.gs_block_rows(_p(mat), rows, cols, mat.stride(0), _p(dst), _lib.current_stream_ptr()))
+    return dst
+
+
+def im2col3x3_blocked(x_nhwc):
+    """3 x 3 patches (zero padding 1) of a contiguous NHWC float32 tensor as the blocked ``[B*H*W, 9*C]`` operand."""
+    import torch
+    lib = _lib.load()
+    _need_cuda(x_nhwc)
+    assert x_nhwc.dtype == torch.float32 and x_nhwc.dim() == 4 and x_nhwc.is_contiguous()
+    b, h, w, c = x_nhwc.shape
+    dst = _blocked_empty(b * h * w, 9 * c, x_nhwc.device)
+    _lib.check(lib.gs_im2col3x3_blocked(_p(x_nhwc), b, h, w, c, _p(dst), _lib.current_stream_ptr()))
+    return dst
+
+
+def gemm_blocked_nt(a_blocked, rows_a, b_blocked, rows_b, cols):
+    """``A @ B.T`` (``[rows_a, rows_b]`` float32, row-major) from two panel-blocked operands with ``cols`` columns."""
+    import torch
+    lib = _lib.load()
+    _need_cuda(a_blocked, b_blocked)
+    out = torch.empty((rows_a, rows_b), dtype=torch.float32, device=a_blocked.device)
+    _lib.check(lib.gs_gemm_blocked_nt(_p(a_blocked), rows_a, _p(b_blocked), rows_b, cols, _p(out), rows_b,
+                                      _lib.current_stream_ptr()))
+    return out
+
+
 _project_scratch = {}
 
 

@@ -30,6 +30,7 @@ stage-generator form of ``StyleGAN2.partial_forward`` - is this repository's own
 from __future__ import annotations
 
 import math
+import os
 import random
 import re
 from abc import ABC as AbstractBaseClass
@@ -180,22 +181,38 @@ class ModulatedConv2d(nn.Module):
             self._wmat_key = key
         return self._wmat
 
+    def _weight_blocked(self):
+        """The same matrix in the panel-blocked layout of ``gs_gemm_blocked_nt`` (cached with it)."""
+        wm = self._weight_matrix()
+        if getattr(self, "_wblk_key", None) != self._wmat_key:
+            self._wblk = ops.block_rows(wm)
+            self._wblk_key = self._wmat_key
+        return self._wblk
+
     def _conv_hip(self, x):
-        """The dense convolution as ONE f32-MFMA product per (sub-)batch: rows = output pixels (NHWC patches, im2col by a
-        strided view of the padded input), columns = output channels, through ``gs_linear_forward`` - the kernel the
-        mapping network and BigGAN's ``gen_z`` already run on.  MIOpen's float32 convolutions reach ~6 TFLOP/s at these
-        shapes on this image (round-5 measurement: 85 ms per 250 samples for the ``convs.2`` prefix); the product runs at
-        ~100.  Returns a channels-last view ``[B, out, H, W]``."""
+        """The dense convolution as ONE f32-MFMA product per (sub-)batch: rows = output pixels (NHWC patches), columns =
+        output channels.  MIOpen's float32 convolutions fall back to naive kernels on this image (~6 TFLOP/s: 85 ms per
+        250 samples for the ``convs.2`` prefix, round-5 measurement).  3 x 3 layers with a multiple of 32 channels - every
+        layer of the prefix - go through the blocked path: ``gs_im2col3x3_blocked`` writes the patches straight into the
+        panel-blocked operand layout (one pass; the im2col IS the blocking) and ``gs_gemm_blocked_nt`` multiplies from
+        LDS-DMA stages (csrc/gs_gemm_blocked.hip); anything else (1 x 1 ``to_rgb``, odd channel counts) takes a strided-view
+        im2col and ``gs_linear_forward``.  Returns a channels-last view ``[B, out, H, W]``."""
         b, c, h, w = x.shape
         k = self.k
         wm = self._weight_matrix()
         kk = wm.shape[1]
         xn = x.permute(0, 2, 3, 1)                                                        # NHWC view
         per = max(1, int((1 << 31) // max(1, h * w * kk * 4)))                            # <= 2 GiB of patches per product
+        blocked = k == 3 and c % 32 == 0 and os.environ.get("GANSPACE_CONV", "blocked") == "blocked"
+        wblk = self._weight_blocked() if blocked else None
         outs = []
         for lo in range(0, b, per):
             xb = xn[lo:lo + per]
             nb = xb.shape[0]
+            if blocked:
+                cols = ops.im2col3x3_blocked(xb.contiguous())
+                outs.append(ops.gemm_blocked_nt(cols, nb * h * w, wblk, self.out_ch, kk))
+                continue
             if k == 1:
                 cols = xb.reshape(nb * h * w, c)
             else:

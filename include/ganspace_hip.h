@@ -317,6 +317,23 @@ int gs_project_rows(const float *x, int64_t ldx, int64_t rows, int features, con
                     const float *dirs, int directions, const float *colscale, float *out,
                     int64_t ldo, void *scratch, int64_t scratch_bytes, void *stream);
 
+/* c[rows_a, rows_b] (leading dimension ldc) = A B^T on the f32 MFMA from PANEL-BLOCKED operands
+ * ([cols / 32][rows / 128][8][128][4] floats, gs_blocked_nbytes bytes; zero beyond the matrix):
+ * the 3 x 3 convolutions of the generator prefix that `StyleGAN2.partial_forward` runs up to a
+ * conv layer (models/wrappers.py:194-259; BASELINE config 5, `--layer=convs.2`).
+ *   gs_block_rows         row-major [rows, cols] (ld) -> blocked (the weight matrix, once per layer)
+ *   gs_im2col3x3_blocked  NHWC tensor [batch, height, width, channels] -> the blocked patch matrix
+ *                         [batch * height * width, 9 * channels], column (kh * 3 + kw) * channels + c,
+ *                         zero padding of 1 (`F.conv2d(..., padding=1)`); channels % 32 == 0
+ *   gs_gemm_blocked_nt    the product (LDS-DMA stages, two workgroups per CU; csrc/gs_gemm_blocked.hip)  */
+int gs_blocked_nbytes(int64_t rows, int64_t cols, int64_t *nbytes);
+int gs_block_rows(const float *src, int64_t rows, int64_t cols, int64_t ld, float *dst_blocked,
+                  void *stream);
+int gs_im2col3x3_blocked(const float *x_nhwc, int64_t batch, int height, int width, int channels,
+                         float *dst_blocked, void *stream);
+int gs_gemm_blocked_nt(const float *a_blocked, int64_t rows_a, const float *b_blocked, int rows_b,
+                       int64_t cols, float *c, int64_t ldc, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -456,6 +456,57 @@ def test_project_rows_matches_float64(dev, rows, d, k, use_shift):
     assert (got[:, k:] == -7.0).all()
 
 
+@pytest.mark.parametrize("rows_a,rows_b,cols", [(300, 200, 96), (128, 128, 32), (1000, 512, 4608), (5, 3, 8), (257, 129, 100)])
+def test_gemm_blocked_nt_matches_float64(dev, rows_a, rows_b, cols):
+    """``A @ B.T`` from panel-blocked operands (csrc/gs_gemm_blocked.hip: LDS-DMA stages, the same fma chains over K as
+    ``gs_linear_forward``): float64 numpy is the checker; ragged panel and K-block tails included."""
+    from ganspace_amd import ops
+    rs = np.random.RandomState(rows_a + cols)
+    a = rs.standard_normal((rows_a, cols)).astype(np.float32)
+    b = (rs.standard_normal((rows_b, cols)) / np.sqrt(cols)).astype(np.float32)
+    ab, bb = ops.block_rows(torch.from_numpy(a).to(dev)), ops.block_rows(torch.from_numpy(b).to(dev))
+    got = ops.gemm_blocked_nt(ab, rows_a, bb, rows_b, cols).cpu().numpy()
+    ref = a.astype(np.float64) @ b.astype(np.float64).T
+    assert got.shape == ref.shape
+    assert np.abs(got - ref).max() < 2e-5 * np.abs(ref).max()
+
+
+@pytest.mark.parametrize("b,h,w,c,out", [(3, 5, 7, 32, 40), (2, 16, 16, 64, 128), (1, 4, 4, 512, 512)])
+def test_im2col3x3_blocked_product_matches_conv2d(dev, b, h, w, c, out):
+    """The blocked patch matrix of an NHWC tensor (``gs_im2col3x3_blocked``: zero padding 1, column (kh, kw, c)) times the
+    blocked weight matrix IS ``F.conv2d(x, W, padding=1)`` (float64 torch on the device is the checker)."""
+    import torch.nn.functional as F
+    from ganspace_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(b * 100 + c)
+    x = torch.randn(b, c, h, w, generator=g)
+    wgt = torch.randn(out, c, 3, 3, generator=g) / np.sqrt(9 * c)
+    xd = x.to(dev)
+    cols = ops.im2col3x3_blocked(xd.permute(0, 2, 3, 1).contiguous())
+    wblk = ops.block_rows(wgt.permute(0, 2, 3, 1).reshape(out, 9 * c).contiguous().to(dev))
+    y = ops.gemm_blocked_nt(cols, b * h * w, wblk, out, 9 * c).view(b, h, w, out).permute(0, 3, 1, 2)
+    ref = F.conv2d(xd.double(), wgt.to(dev).double(), padding=1)
+    assert (y.double() - ref).abs().max().item() < 2e-5 * ref.abs().max().item()
+
+
+def test_modulated_conv_blocked_path_equals_strided_path(dev, monkeypatch):
+    """``ModulatedConv2d`` on the device: the blocked convolution path and the strided-view im2col + ``gs_linear_forward``
+    path (``GANSPACE_CONV=strided``) give the same layer output to float32 roundoff, upsampling included."""
+    from ganspace_amd.wrappers import ModulatedConv2d
+    torch.manual_seed(11)
+    m = ModulatedConv2d(64, 96, 3, 32, upsample=True).to(dev)
+    x = torch.randn(6, 64, 8, 8, device=dev)
+    style = torch.randn(6, 32, device=dev)
+    with torch.no_grad():
+        monkeypatch.setenv("GANSPACE_CONV", "blocked")
+        a = m(x, style)
+        monkeypatch.setenv("GANSPACE_CONV", "strided")
+        b_ = m(x, style)
+        ref = m.double().forward_grouped(x.double(), style.double())
+    assert a.shape == b_.shape == (6, 96, 16, 16)
+    assert (a - b_).abs().max().item() < 1e-5 * b_.abs().max().item()
+    assert (a.double() - ref).abs().max().item() < 2e-5 * ref.abs().max().item()
+
+
 # ---- BASELINE-size properties (no oracle at this size: size-independent invariants) --------------
 
 def test_full_size_block_properties(dev):
