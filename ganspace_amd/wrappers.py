@@ -202,8 +202,10 @@ class ModulatedConv2d(nn.Module):
         wm = self._weight_matrix()
         kk = wm.shape[1]
         xn = x.permute(0, 2, 3, 1)                                                        # NHWC view
-        per = max(1, int((1 << 31) // max(1, h * w * kk * 4)))                            # <= 2 GiB of patches per product
         blocked = k == 3 and c % 32 == 0 and os.environ.get("GANSPACE_CONV", "blocked") == "blocked"
+        # patches per product: <= 8 GiB on the blocked path (64-bit addressing; -b 500 at 16 x 16 is 2.4 GB), <= 2 GiB on the
+        # strided one (the fast path of gs_linear_forward addresses its operands through 32-bit buffer offsets)
+        per = max(1, int((1 << (33 if blocked else 31)) // max(1, h * w * kk * 4)))
         wblk = self._weight_blocked() if blocked else None
         outs = []
         for lo in range(0, b, per):
