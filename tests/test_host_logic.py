@@ -311,3 +311,14 @@ def test_modulated_conv_im2col_product_equals_conv2d(monkeypatch, k, cin, cout):
     with torch.no_grad():
         m.weight.mul_(2.0)
         assert torch.allclose(m._conv_hip(x), 2 * ref, rtol=1e-12, atol=1e-12)
+
+
+def test_device_z_generator_switch(monkeypatch):
+    """``_zgen.device_generation_enabled``: HIP devices use the device generator unless ``GANSPACE_ZGEN=host`` asks for the
+    host thread pool; CPU runs never do (no device code without a device)."""
+    from ganspace_amd import _zgen
+    monkeypatch.delenv("GANSPACE_ZGEN", raising=False)
+    assert _zgen.device_generation_enabled("cuda:0") is True
+    assert _zgen.device_generation_enabled("cpu") is False
+    monkeypatch.setenv("GANSPACE_ZGEN", "host")
+    assert _zgen.device_generation_enabled("cuda:0") is False
