@@ -15,7 +15,7 @@ the job is completed inside the timed region (multi-GPU: the RCCL all-reduce of 
 the eigensolve and the device->host copy of the components), so ``value`` is whole-job throughput and
 ``ms_per_step * steps`` is the timed region.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--mode exact|faithful]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--mode exact|faithful]     (N > 1: re-executes itself under the launcher below)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -102,8 +102,12 @@ def gram_kernel_us(lib, _lib, est, block, iters=50, reps=3):
     return seen[-1], rows.value
 
 
-def e2e_runs(dev, args):
-    """``get_or_compute`` for BASELINE config 3 (BigGAN-512 ``generator.gen_z``, n = 1e6, ``-b`` pinned to 2000: the README
+def e2e_runs(dev, args, only=None):
+    """``get_or_compute`` for BASELINE config 4 at its own n on ONE GPU (StyleGAN2-car Z-space ``--layer=style``, n = 8e6,
+    -b 10 000: the N = 1 anchor of the 8-GPU scaling curve, and the one config whose fit loop contains the mapping GEMMs - 800
+    blocks x 8 layers - next to a 16 GB resident latent array), for ``ipca-exact`` (the sharded design's estimator) and ``ipca``
+    (the reference's default), each checked at a reduced n against scikit-learn on the very blocks the estimator received;
+    then for BASELINE config 3 (BigGAN-512 ``generator.gen_z``, n = 1e6, ``-b`` pinned to 2000: the README
     command leaves it to the auto-tuner) and config 5 (StyleGAN2 ``convs.2``, d = 131 072, at the n the run
     run is asked for - BASELINE's 1e6 by default since round 5: the synthetic generator's convolutions go through the f32-MFMA
     GEMM, 24 us per sample).  Phase times from ``decomposition.LAST_TIMINGS``.  cfg3's activation is
@@ -118,10 +122,15 @@ def e2e_runs(dev, args):
     from ganspace_amd.config import Config
     from ganspace_amd.wrappers import get_instrumented_model
     res = {}
-    jobs = (("cfg3_biggan512_gen_z", dict(model="BigGAN-512", layer="generator.gen_z", output_class=250, n=1_000_000,
+    cfg4 = dict(model="StyleGAN2", layer="style", output_class="car", n=args.e2e_cfg4_n, batch_size=10_000,
+                components=K_COMP)
+    jobs = (("cfg4_stylegan2_car_zspace_ipca_exact", dict(cfg4, estimator="ipca-exact")),
+            ("cfg4_stylegan2_car_zspace_ipca", dict(cfg4, estimator="ipca")),
+            ("cfg3_biggan512_gen_z", dict(model="BigGAN-512", layer="generator.gen_z", output_class=250, n=1_000_000,
                                           batch_size=2000, components=K_COMP, estimator="ipca")),
             ("cfg5_stylegan2_convs2", dict(model="StyleGAN2", layer="convs.2", output_class="ffhq", n=args.e2e_cfg5_n,
                                            batch_size=500, components=K_COMP, estimator="ipca")))
+    jobs = tuple(j for j in jobs if not only or any(j[0].startswith(o) for o in only))
     for name, kw in jobs:
         run_dir = tempfile.mkdtemp(prefix="gs_bench_e2e_")
         try:
@@ -185,6 +194,47 @@ def e2e_runs(dev, args):
                             "test_cfg3_biggan_gen_z_small_side)"}
                 del comp_ref
                 del lat, zz, zc
+            if name.startswith("cfg4"):
+                # parity at a reduced n ON BOTH SIDES (scikit-learn needs 0.25 s per 10 000-row block: 200 s for the 800
+                # blocks): the same job at n = 200 000, every row group the product's estimator receives is also cut into the
+                # job's NB-row blocks and handed to sklearn's IncrementalPCA configured as the reference does (estimators.py:59)
+                from oracle import reference_cpu
+                from oracle.ipca import signed_cosines
+                from ganspace_amd import estimators as est_mod
+                seen = []
+                orig_fit_partial = est_mod.IPCAEstimator.fit_partial
+
+                def spy4(self, X, *a, **k_):
+                    seen.append(X.detach().cpu().numpy().copy())
+                    return orig_fit_partial(self, X, *a, **k_)
+                est_mod.IPCAEstimator.fit_partial = spy4
+                try:
+                    small = Config(**{**kw, "n": args.e2e_cfg4_check_n})
+                    with contextlib.redirect_stdout(sys.stderr):
+                        path2 = dec.get_or_compute(small, inst, submit_config=SimpleNamespace(run_dir_root=run_dir, run_dir=run_dir))
+                finally:
+                    est_mod.IPCAEstimator.fit_partial = orig_fit_partial
+                d2 = np.load(path2, allow_pickle=False)
+                rows4 = np.concatenate(seen)
+                del seen
+                nb4 = dec._Plan.make(small.n, small.batch_size, small.components).NB
+                sk = reference_cpu.make_reference_ipca(cfg.components)
+                with reference_cpu.blas_threads(16):
+                    for lo4 in range(0, rows4.shape[0], nb4):
+                        sk.partial_fit(rows4[lo4:lo4 + nb4])
+                c = signed_cosines(d2["act_comp"].reshape(cfg.components, -1), sk.components_)
+                entry["vs_sklearn_at_reduced_n"] = {
+                    "n": int(rows4.shape[0]), "blocks": int(rows4.shape[0] // nb4),
+                    "top20_signed_cosine_min": round(float(c[:20].min()), 8),
+                    "top20_signed_cosine_ok": bool(c[:20].min() >= 0.999),
+                    "all80_signed_cosine_min": round(float(c.min()), 8),
+                    "all80_abs_cosine_min": round(float(np.abs(c).min()), 6),
+                    "act_stdev_top20_max_rel_err": float(np.abs(d2["act_stdev"][:20] /
+                                                                np.sqrt(sk.explained_variance_[:20]) - 1).max()),
+                    "checker": "scikit-learn IncrementalPCA.partial_fit on the rows the estimator itself received, cut into "
+                               "the job's NB-row blocks (ipca-exact: the leading components agree, the trailing ones are the "
+                               "exact PCA where IPCA truncates - DESIGN.md 3)"}
+                del rows4, sk
             if name.startswith("cfg5"):
                 # per-direction parity at a reduced n ON BOTH SIDES (the CPU reference needs 26 s per block at
                 # this width): the same job at n = 12 000 (six 2000-row blocks: Rayleigh-Ritz blocks and the deferred-basis
@@ -229,6 +279,18 @@ def e2e_runs(dev, args):
     return res
 
 
+def launcher_command(argv, n_ranks, port=None):
+    """The command line that runs this script as ``n_ranks`` ranks on one node - exactly what the driver uses for N > 1:
+    ``python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py ...``."""
+    if port is None:
+        import socket
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={int(n_ranks)}",
+            "--master-addr", "127.0.0.1", "--master-port", str(int(port)), os.path.abspath(__file__), *argv]
+
+
 def main():
     global T_BENCH0
     T_BENCH0 = time.perf_counter()
@@ -247,6 +309,10 @@ def main():
                          "d = 131 072) come last and stop taking blocks when the next one would not fit (>= 2 are always timed)")
     ap.add_argument("--wide-cpu-blocks", type=int, default=6, help="blocks of that baseline (first + steady-state ones)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end get_or_compute runs of cfg3 / cfg5")
+    ap.add_argument("--e2e-cfg4-n", type=int, default=8_000_000,
+                    help="samples of the cfg4 end-to-end runs (BASELINE's n; 16 GB of resident latents, a few seconds per run)")
+    ap.add_argument("--e2e-cfg4-check-n", type=int, default=200_000, help="reduced n of cfg4's scikit-learn comparison")
+    ap.add_argument("--e2e-only", default="", help="comma-separated prefixes of end-to-end jobs to run (cfg3, cfg4, cfg5)")
     ap.add_argument("--e2e-cfg5-n", type=int, default=1_000_000,
                     help="samples of the cfg5 end-to-end run (BASELINE's n; ~60 s: the conv prefix runs twice - fit and regression - "
                          "at ~24 us per sample through the f32-MFMA GEMM)")
@@ -254,6 +320,13 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="headline + roofline only (profiling runs)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` (how the driver's 1-GPU line is invoked, with N > 1): start the N ranks ourselves
+        cmd = launcher_command(sys.argv[1:], args.gpus)
+        log("bench.py: --gpus %d without a launcher: exec %s" % (args.gpus, " ".join(cmd)))
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        sys.stdout.flush()
+        os.execv(cmd[0], cmd)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -587,7 +660,8 @@ def main():
                 "cpu_parts": {"z_s_per_batch": round(min(t_z), 4), "mapping_s_per_batch": round(min(t_map), 4),
                               "gelsd_s_per_100k_rows": round(t_gelsd, 3), "blas_threads": threads},
                 "speedup": round(cpu_reg / min(reg_runs), 1),
-                "note": "device time is the native z stream (host threads) + H2D; the kernels are < 0.1 s of it"}
+                "note": "z streams from the device generator (gs_zgen_device), mapping network, projection and "
+                        "[A|Z]^T [A|Z] all on the device; 8 mini-batches per partial_forward call (decomposition._forward_rows)"}
         except Exception as ex:                                   # an extra must never take the headline line down
             out["regression_cfg4_share"] = {"error": repr(ex)}
         cos = {}
@@ -767,7 +841,7 @@ def main():
     #      reference: pre-sampling, "Fitting batches" loop with the hooked generator, read-out, regression back to latent
     #      space, .npz), phase by phase (ganspace_amd.decomposition.LAST_TIMINGS) ---------------------------------------
     if extras and not args.no_e2e:
-        out["end_to_end_cfg3_cfg5"] = e2e_runs(dev, args)
+        out["end_to_end_cfg3_cfg4_cfg5"] = e2e_runs(dev, args, [o for o in args.e2e_only.split(",") if o])
 
     # ---- the wide shapes' CPU baselines, LAST and alone on the host (beside the GPU legs they ran 2-5x slower and slowed
     #      the host-bound GPU legs down in turn): scikit-learn's IncrementalPCA.partial_fit - the reference's arithmetic,

@@ -160,12 +160,17 @@ def device_generation_enabled(device) -> bool:
     return torch.device(device).type == "cuda" and os.environ.get("GANSPACE_ZGEN", "device") != "host"
 
 
-def device_batches(kind: str, seeds, n: int, dim: int, device, truncation: float = 1.0, group: int = 256):
-    """Yield ``(index, z)`` for ``seeds`` in order, ``z`` a ``[n, dim]`` float32 DEVICE tensor holding
-    ``RandomState(seed).standard_normal(n * dim)`` (``kind="stylegan"``) or BigGAN's
+ZGEN_STAGING_BYTES = 1 << 30      # device staging of one gs_zgen_device launch (device_groups)
+
+
+def device_groups(kind: str, seeds, n: int, dim: int, device, truncation: float = 1.0, group: int = 256):
+    """Yield ``(lo, z)`` for ``seeds`` in order, ``z`` a ``[m, n, dim]`` float32 DEVICE tensor whose slice ``z[j]`` holds
+    ``RandomState(seeds[lo + j]).standard_normal(n * dim)`` (``kind="stylegan"``) or BigGAN's
     ``truncation * truncnorm.rvs(-2, 2, size=(n, dim), random_state=RandomState(seed))`` - generated on the device, one
-    workgroup (four waves) per seed, ``group`` seeds per launch (a launch lasts as long as ONE stream whatever the group: the
-    groups are sized to put a stream on every CU, 256 x n x dim floats of staging).  Nothing touches the host: no pinned ring, no H2D copy."""
+    workgroup (four waves) per seed, up to ``group`` seeds per launch.  A launch lasts as long as ONE stream whatever the
+    group, so the groups only have to be long enough to keep most CUs busy: they are bounded by ``ZGEN_STAGING_BYTES``
+    (1 GiB: 52 streams of 10 000 x 512; round 5 staged up to 8 GiB next to the resident latents) and by a quarter of the
+    free device memory.  Nothing touches the host: no pinned ring, no H2D copy."""
     import ctypes as C
     import torch
     from . import _lib
@@ -181,15 +186,26 @@ def device_batches(kind: str, seeds, n: int, dim: int, device, truncation: float
     if len(seeds) == 0:
         return
     seeds_dev = torch.from_numpy(seeds.view(np.int32).copy()).to(device)
-    # bound the staging buffer: <= 256 streams and <= 8 GiB per launch
-    group = max(1, min(int(group), len(seeds), (8 << 30) // max(1, 4 * count)))
+    budget = ZGEN_STAGING_BYTES
+    try:
+        budget = min(budget, torch.cuda.mem_get_info(device)[0] // 4)
+    except Exception:
+        pass
+    group = max(1, min(int(group), len(seeds), budget // max(1, 4 * count)))
     stream = _lib.current_stream_ptr()
     for lo in range(0, len(seeds), group):
         m = min(group, len(seeds) - lo)
         buf = torch.empty((m, int(n), int(dim)), dtype=torch.float32, device=device)
         _lib.check(lib.gs_zgen_device(C.c_void_p(seeds_dev.data_ptr() + 4 * lo), m, count, C.c_void_p(buf.data_ptr()), count,
                                       knd, la, lm, scale, stream))
-        for j in range(m):
+        yield lo, buf
+
+
+def device_batches(kind: str, seeds, n: int, dim: int, device, truncation: float = 1.0, group: int = 256):
+    """:func:`device_groups` one stream at a time: yields ``(index, z)`` with ``z`` the ``[n, dim]`` batch of
+    ``seeds[index]``."""
+    for lo, buf in device_groups(kind, seeds, n, dim, device, truncation, group):
+        for j in range(buf.shape[0]):
             yield lo + j, buf[j]
 
 

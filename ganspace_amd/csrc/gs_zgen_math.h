@@ -1,5 +1,5 @@
 // Arithmetic of the reference's latent streams shared by the host generator (gs_zgen.hip: std::thread pool) and the
-// device generator (gs_zgen_device.hip: one wave per seed): MT19937 tempering, the 53-bit doubles NumPy builds from two
+// device generator (gs_zgen_device.hip: one workgroup of four waves per seed): MT19937 tempering, the 53-bit doubles NumPy builds from two
 // draws, and SciPy's truncated-normal inverse CDF (Cephes ndtri / scipy.special.ndtri_exp).  Restated operation by
 // operation - see the header of gs_zgen.hip for the reference call sites - with floating-point contraction OFF: the host
 // build has no fused multiply-add to contract into (x86-64 baseline), the device build would otherwise fuse the Horner

@@ -193,21 +193,34 @@ class _DeviceIncrementalPCA:
         """``(X - mean_) @ components_.T`` on the device; returns a host ndarray ``[m, k]``."""
         torch = _torch()
         r = self._results()                # finalizes once (the faithful mode defers its diagonalisation until here)
-        Xd = self._as_device_rows(X).contiguous()
-        # the components stay where gs_ipca_finalize left them (device, float32 [k, d]): only the k projections of the
-        # mean travel - X @ C^T - mean @ C^T, the second term evaluated once per fit in float64 from the host copies
-        comp, mean = C.c_void_p(), C.c_void_p()
-        _lib.check(self._lib.gs_ipca_components_device(self._h, C.byref(comp), C.byref(mean)))
+        Xd = self._as_device_rows(X)
         k, d = self.n_components, self._d
-        if d % 4 != 0:
-            raise NotImplementedError("transform() needs n_features to be a multiple of 4")
-        if "_proj_bias" not in r:
-            r["_proj_bias"] = -(r["components_"].astype(np.float64) @ r["mean_"]).astype(np.float32)
-        bias = torch.from_numpy(r["_proj_bias"]).to(Xd.device)
-        out = torch.empty((Xd.shape[0], k), dtype=torch.float32, device=Xd.device)
-        _lib.check(self._lib.gs_linear_forward(C.c_void_p(Xd.data_ptr()), comp, C.c_void_p(bias.data_ptr()),
-                                               C.c_void_p(out.data_ptr()), Xd.shape[0], d, k,
-                                               _lib.current_stream_ptr()))
+        if Xd.shape[1] != d:
+            raise ValueError(f"X has {Xd.shape[1]} features, but IncrementalPCA is expecting {d} features as input.")
+        # sklearn's order (``X - mean_`` first, then ``@ components_.T``): the rows are centred while gs_project_rows stages
+        # its tiles, so data that sits on a mean many times its spread does not cancel in float32 (X C^T - mean C^T would)
+        from . import ops
+        if d % 4 == 0:
+            if Xd.stride(0) % 4 or Xd.data_ptr() % 16:
+                Xd = Xd.contiguous()
+            # the components stay where gs_ipca_finalize left them (device, float32 [k, d] + the float32 mean)
+            comp, mean = C.c_void_p(), C.c_void_p()
+            _lib.check(self._lib.gs_ipca_components_device(self._h, C.byref(comp), C.byref(mean)))
+            out = ops.project_rows_ptr(Xd, comp, k, mean)
+        else:
+            # the kernel reads 16-byte pieces of a row: zero-pad the features (a zero column of X, of the mean and of every
+            # component changes nothing - the same device _WholeMatrixPCA.fit uses); padded operands cached with the results
+            dp = d + (-d) % 4
+            if "_comp_dev" not in r:
+                comp_p = np.zeros((k, dp), np.float32)
+                comp_p[:, :d] = r["components_"]
+                mean_p = np.zeros(dp, np.float32)
+                mean_p[:d] = r["mean_"]
+                r["_comp_dev"] = torch.from_numpy(comp_p).to(Xd.device)
+                r["_mean_dev"] = torch.from_numpy(mean_p).to(Xd.device)
+            Xp = torch.zeros((Xd.shape[0], dp), dtype=torch.float32, device=Xd.device)
+            Xp[:, :d] = Xd
+            out = ops.project_rows(Xp, r["_comp_dev"], shift=r["_mean_dev"])
         return out.cpu().numpy()
 
     def inverse_transform(self, Y):

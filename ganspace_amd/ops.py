@@ -154,6 +154,13 @@ def project_rows(x, dirs, shift=None, colscale=None, out=None):
     if colscale is not None:
         colscale = colscale.to(torch.float32).contiguous().reshape(-1)
         assert colscale.numel() == k
+    return _project_launch(x, _p(dirs), k, _p(shift), _p(colscale), out)
+
+
+def _project_launch(x, dirs_ptr, k, shift_ptr, colscale_ptr, out):
+    import torch
+    lib = _lib.load()
+    rows, d = x.shape
     if out is None:
         out = torch.empty((rows, k), dtype=torch.float32, device=x.device)
     assert out.dtype == torch.float32 and out.shape == (rows, k) and out.stride(1) == 1
@@ -164,10 +171,19 @@ def project_rows(x, dirs, shift=None, colscale=None, out=None):
     if scratch is None or scratch.numel() < nb.value:
         scratch = torch.empty(nb.value, dtype=torch.uint8, device=x.device)
         _project_scratch[key] = scratch
-    _lib.check(lib.gs_project_rows(_p(x), x.stride(0), rows, d, _p(shift), _p(dirs), k, _p(colscale), _p(out),
+    _lib.check(lib.gs_project_rows(_p(x), x.stride(0), rows, d, shift_ptr, dirs_ptr, k, colscale_ptr, _p(out),
                                    out.stride(0) if rows > 1 else max(out.stride(0), k), _p(scratch), scratch.numel(),
                                    _lib.current_stream_ptr()))
     return out
+
+
+def project_rows_ptr(x, dirs_ptr, k, shift_ptr=None, out=None):
+    """:func:`project_rows` with the directions (float32 ``[k, d]``, contiguous) and the shift (float32 ``[d]``) given as
+    raw device pointers - the arrays ``gs_ipca_components_device`` hands out (``IncrementalPCA.transform``)."""
+    import torch
+    _need_cuda(x, out)
+    assert x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1 and x.shape[1] % 4 == 0
+    return _project_launch(x, dirs_ptr, int(k), shift_ptr if shift_ptr is not None else C.c_void_p(0), C.c_void_p(0), out)
 
 
 def eigh_topk(A, k, V0=None):

@@ -160,3 +160,19 @@ def test_bench_two_ranks_smoke(tmp_path):
     assert line1["n_gpus"] == 1
     a, b = np.load(tmp_path / "one.npy"), np.load(tmp_path / "two.npy")
     assert O.signed_cosines(a[:20], b[:20]).min() > 1 - 1e-6
+
+
+def test_bench_launches_its_own_ranks(tmp_path):
+    """``python bench.py --gpus 2`` with NO launcher around it (how the driver invokes the N = 1 line; round-5 verdict: the
+    same form with N > 1 died on ``assert args.gpus == world``): bench.py re-executes itself under
+    ``torch.distributed.run --nproc-per-node 2`` and rank 0 prints the one JSON line."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(GS_BENCH_BACKEND="gloo", GS_BENCH_ONE_DEVICE="1", PYTHONPATH=ROOT + os.pathsep + env.get("PYTHONPATH", ""))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, f"--- stdout ---\n{r.stdout[-3000:]}\n--- stderr ---\n{r.stderr[-6000:]}"
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-3000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 2 and line["value"] > 0
+    assert len(line["multi_gpu"]["per_rank"]) == 2

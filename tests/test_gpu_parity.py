@@ -401,6 +401,52 @@ def test_transform_projects_onto_components(dev):
     np.testing.assert_allclose(Y, Yref, atol=2e-4 * np.abs(Yref).max())
 
 
+def test_transform_bigmean_matches_sklearn_transform(dev):
+    """``est.transformer.transform(X)`` on data that sits on a mean 40 x its spread: sklearn centres
+    first (``X - mean_`` in float64), and so does the device path (rows centred while the projection kernel stages them);
+    ``X C^T - mean C^T`` in float32 would lose ~ |mean| / sigma x eps32 of every coordinate.  Checked against scikit-learn's
+    own ``IncrementalPCA.transform`` fitted on the same blocks."""
+    from sklearn.decomposition import IncrementalPCA
+    case = gin.IPCA_CASES["d96_k12_bigmean"]
+    est = _fit_device("d96_k12_bigmean", "faithful", dev)
+    sk = IncrementalPCA(n_components=case["k"], batch_size=max(100, 2 * case["k"]))
+    blocks = list(gin.ipca_blocks(case))
+    for X in blocks:
+        sk.partial_fit(X)
+    X = blocks[-1][:257]                                    # ragged row count
+    Y = est.transformer.transform(X)
+    Ysk = sk.transform(X)
+    assert Y.shape == Ysk.shape == (257, case["k"])
+    # float32 rows of magnitude ~ |mean| = 40 sigma carry 40 eps32 sigma of representation error before anything is computed
+    np.testing.assert_allclose(Y, Ysk, atol=3e-5 * np.abs(Ysk).max())
+    # device tensor in, strided rows (a column slice of a wider buffer)
+    wide = torch.zeros((257, 128), dtype=torch.float32, device=dev)
+    wide[:, :96] = torch.from_numpy(X).to(dev)
+    np.testing.assert_allclose(est.transformer.transform(wide[:, :96]), Y, atol=1e-6 * np.abs(Ysk).max())
+
+
+def test_transform_accepts_any_feature_width(dev):
+    """n_features not a multiple of 4 (sklearn's transform accepts any width; round 5 raised NotImplementedError)."""
+    from ganspace_amd.estimators import IPCAEstimator
+    rs = np.random.RandomState(5)
+    d, k = 37, 6
+    A = rs.standard_normal((10, d)) * (1.5 ** -np.arange(10))[:, None]
+    mu = rs.standard_normal(d) * 5.0
+    est = IPCAEstimator(k, "faithful")
+    blocks = [(rs.standard_normal((200, 10)) @ A + mu + 0.01 * rs.standard_normal((200, d))).astype(np.float32)
+              for _ in range(3)]
+    for X in blocks:
+        assert est.fit_partial(X)
+    t = est.transformer
+    X = blocks[1][:33]
+    Y = t.transform(X)
+    Yref = (X.astype(np.float64) - t.mean_) @ t.components_.astype(np.float64).T
+    assert Y.shape == (33, k)
+    np.testing.assert_allclose(Y, Yref, atol=2e-5 * np.abs(Yref).max())
+    with pytest.raises(ValueError):
+        t.transform(np.zeros((4, d + 1), np.float32))
+
+
 # ---- z -> activation layers --------------------------------------------------------------------
 
 def test_mapping_network_matches_oracle_and_reference_gmapping(dev, golden_dir):

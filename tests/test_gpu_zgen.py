@@ -1,4 +1,4 @@
-"""The device latent generator (csrc/gs_zgen_device.hip, one wave per seed) against the generators the reference calls:
+"""The device latent generator (csrc/gs_zgen_device.hip, one workgroup of four waves per seed) against the generators the reference calls:
 ``np.random.RandomState(seed).standard_normal`` (models/wrappers.py:167-174) and BigGAN's
 ``truncnorm.rvs(-2, 2, random_state=RandomState(seed))`` (biggan/.../utils.py:21-33).
 

@@ -256,16 +256,31 @@ def test_two_live_native_streams_do_not_share_a_ring():
 
 
 def test_regression_staging_is_bounded_in_rows_and_bytes():
-    """``linreg_lstsq`` stages mini-batches of [A|Z] rows per Gram call: as many as fit 65 536 rows / 256 MB, at least one
-    mini-batch, never a partial one."""
-    from ganspace_amd.decomposition import _regression_stage_batches as stage
-    assert stage(2000, 208) == 32                      # cfg3: 500 mini-batches -> 16 Gram calls (was 250)
-    assert stage(10000, 592) == 6                      # cfg4: 100 -> 17
-    assert stage(10000, 8192) == 1                     # a mini-batch wider than the byte budget still goes through whole
-    assert stage(70000, 208) == 1
+    """``linreg_lstsq`` stages [A|Z] rows per Gram call: as many whole mini-batches as fit 65 536 rows / 256 MB, at least
+    one mini-batch and at least one forward group."""
+    from ganspace_amd.decomposition import _regression_stage_rows as stage
+    assert stage(2000, 208, 2000) == 64000             # cfg3: 500 mini-batches -> 16 Gram calls (was 250)
+    assert stage(10000, 592, 80000) == 80000           # cfg4: one forward group of 8 mini-batches per Gram call
+    assert stage(10000, 592, 10000) == 60000
+    assert stage(10000, 8192, 10000) == 10000          # a mini-batch wider than the byte budget still goes through whole
+    assert stage(70000, 208, 70000) == 70000
     for B, wp in [(1, 8), (250, 208), (4096, 4096), (3, 7)]:
-        n = stage(B, wp)
-        assert n >= 1 and (n == 1 or (n * B <= 65536 and n * B * wp * 4 <= 256 << 20))
+        n = stage(B, wp, B)
+        assert n >= B and n % B == 0 and (n == B or (n <= 65536 and n * wp * 4 <= 256 << 20))
+
+
+def test_forward_rows_groups_narrow_layers_only():
+    """Rows per ``partial_forward`` call: several mini-batches for a narrow layer (Z-space ``style``: the mapping GEMM needs
+    tens of thousands of rows to fill the chip), the configured mini-batch for wide ones; always whole mini-batches."""
+    from ganspace_amd.decomposition import _forward_rows as fr
+    assert fr(10_000, 512) == 80_000                   # cfg4: 8 mini-batches per call
+    assert fr(512, 512) == 81_920 // 512 * 512         # cfg1
+    assert fr(2000, 32_768) == 2000                    # cfg3: 262 MB per mini-batch
+    assert fr(500, 131_072) == 500                     # cfg5
+    assert fr(100_000, 512) == 100_000                 # a mini-batch above the cap stays whole
+    for B, d in [(1, 4), (20, 8192), (333, 37), (4096, 2048)]:
+        r = fr(B, d)
+        assert r >= B and r % B == 0
 
 
 @pytest.mark.parametrize("k,demod,up", [(3, True, False), (3, True, True), (1, False, False)])
@@ -322,3 +337,23 @@ def test_device_z_generator_switch(monkeypatch):
     assert _zgen.device_generation_enabled("cpu") is False
     monkeypatch.setenv("GANSPACE_ZGEN", "host")
     assert _zgen.device_generation_enabled("cuda:0") is False
+
+
+def test_bench_builds_the_launcher_line_for_multi_gpu_runs():
+    """``bench.py --gpus N`` without WORLD_SIZE re-executes itself under the launcher the driver uses for N > 1
+    (``python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py ...``)."""
+    import importlib.util
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_for_test", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    cmd = bench.launcher_command(["--gpus", "8", "--steps", "20", "--warmup", "5"], 8, port=29511)
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nnodes=1" in cmd and "--nproc-per-node=8" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29511"
+    i = cmd.index(os.path.join(root, "bench.py"))
+    assert cmd[i + 1:] == ["--gpus", "8", "--steps", "20", "--warmup", "5"]
+    auto = bench.launcher_command([], 2)                       # a free port is picked when none is given
+    assert 1024 <= int(auto[auto.index("--master-port") + 1]) <= 65535

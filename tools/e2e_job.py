@@ -4,6 +4,7 @@ the command the rocprofv3 kernel traces under profiles/ are taken of.
     python tools/e2e_job.py cfg3 [n] [batch]      BigGAN-512 generator.gen_z (d = 32 768)
     python tools/e2e_job.py cfg5 [n] [batch]      StyleGAN2 convs.2          (d = 131 072)
     python tools/e2e_job.py cfg2 [n] [batch]      StyleGAN2 W space, ipca-exact (d = 512; cfg2f: the faithful `ipca`)
+    python tools/e2e_job.py cfg4 [n] [batch]      StyleGAN2-car Z space --layer=style, n = 8e6, ipca-exact (cfg4f: `ipca`)
 """
 import contextlib, json, os, shutil, sys, tempfile, time
 from types import SimpleNamespace
@@ -20,6 +21,9 @@ if which == "cfg3":
 elif which in ("cfg2", "cfg2f"):
     kw = dict(model="StyleGAN2", layer="style", output_class="ffhq", use_w=True, n=1_000_000, batch_size=10_000, components=80,
               estimator="ipca-exact" if which == "cfg2" else "ipca")
+elif which in ("cfg4", "cfg4f"):
+    kw = dict(model="StyleGAN2", layer="style", output_class="car", n=8_000_000, batch_size=10_000, components=80,
+              estimator="ipca-exact" if which == "cfg4" else "ipca")
 else:
     kw = dict(model="StyleGAN2", layer="convs.2", output_class="ffhq", n=20_000, batch_size=250, components=80,
               estimator="ipca")

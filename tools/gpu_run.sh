@@ -1,0 +1,56 @@
+#!/bin/bash
+# The ONE script gpurun calls on the GPU box (replaces the per-call r0X_run*.sh files of rounds 3-5).
+#
+#   gpurun --timeout S -- 'bash tools/gpu_run.sh <tag> <step> [<step> ...]'       -> gpurun_out/<tag>/...
+#
+# steps (run in the order given; each writes under gpurun_out/<tag>/):
+#   tests[:<pytest -k expr or file list>]   pytest -m gpu (whole suite, or a selection)        -> tests.log
+#   smoke                                   __graft_entry__.smoke()                            -> smoke.log
+#   bench[:<extra flags>]                   python bench.py <flags>                            -> bench.json / bench.err
+#   benchprof[:<extra flags>]               rocprofv3 --kernel-trace --stats of bench.py       -> benchprof_kernel_stats.csv
+#   e2e:<job>[:n[:batch]]                   tools/e2e_job.py <job> (cfg2 cfg2f cfg3 cfg4 cfg4f cfg5) -> e2e_<job>.json
+#   e2eprof:<job>[:n[:batch]]               the same under rocprofv3 --kernel-trace --stats    -> e2eprof_<job>_kernel_stats.csv
+#   py:<script>[:args...]                   python tools/<script> args (':'-separated)        -> <script>.log
+#   pyprof:<script>[:args...]               the same under rocprofv3 --kernel-trace --stats    -> <script>_kernel_stats.csv
+#   pmc:<counters '+'-joined>:<script>[:args...]   one rocprofv3 --pmc pass (never combined with other tracing domains)
+#   measure                                 export GANSPACE_HIP_LIB=lib_measure for the following steps
+set -u
+R=$GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp && cd "$R"
+TAG=$1; shift
+O=gpurun_out/$TAG; mkdir -p "$O"
+stats() {   # <trace dir> <out csv>: copy the kernel-stats table of a rocprofv3 --stats run
+  f=$(find "$1" -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp "$f" "$2" && head -25 "$2"
+}
+for step in "$@"; do
+  IFS=':' read -r kind a1 rest <<< "$step"
+  echo "=== $step"
+  case $kind in
+    tests)
+      if [ -z "${a1:-}" ]; then timeout 3000 python -m pytest tests -m gpu -x -q > "$O/tests.log" 2>&1
+      elif [[ "$a1" == tests/* ]]; then timeout 3000 python -m pytest ${a1//,/ } -m gpu -x -q > "$O/tests.log" 2>&1
+      else timeout 3000 python -m pytest tests -m gpu -x -q -k "$a1" > "$O/tests.log" 2>&1; fi
+      tail -15 "$O/tests.log" ;;
+    smoke) timeout 600 python __graft_entry__.py --smoke > "$O/smoke.log" 2>&1; tail -4 "$O/smoke.log" ;;
+    bench)
+      ( time timeout 1500 python bench.py ${a1:-} ${rest//:/ } > "$O/bench.json" 2> "$O/bench.err" ) 2>&1 | grep real
+      tail -c 1500 "$O/bench.json" ;;
+    benchprof)
+      timeout 1500 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/benchprof" -o b -- python bench.py ${a1:-} ${rest//:/ } > "$O/benchprof.json" 2> "$O/benchprof.err"
+      stats "$O/benchprof" "$O/benchprof_kernel_stats.csv" ;;
+    e2e) timeout 1500 python tools/e2e_job.py $a1 ${rest//:/ } > "$O/e2e_$a1.json" 2> "$O/e2e_$a1.err"; cat "$O/e2e_$a1.json" ;;
+    e2eprof)
+      timeout 1500 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/e2eprof_$a1" -o e -- python tools/e2e_job.py $a1 ${rest//:/ } > "$O/e2eprof_$a1.json" 2> "$O/e2eprof_$a1.err"
+      cat "$O/e2eprof_$a1.json"; stats "$O/e2eprof_$a1" "$O/e2eprof_${a1}_kernel_stats.csv" ;;
+    py) timeout 1500 python tools/$a1 ${rest//:/ } > "$O/${a1%.py}.log" 2>&1; tail -40 "$O/${a1%.py}.log" ;;
+    pyprof)
+      timeout 1500 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof_${a1%.py}" -o p -- python tools/$a1 ${rest//:/ } > "$O/${a1%.py}.log" 2>&1
+      tail -20 "$O/${a1%.py}.log"; stats "$O/prof_${a1%.py}" "$O/${a1%.py}_kernel_stats.csv" ;;
+    pmc)
+      IFS=':' read -r script args <<< "$rest"
+      timeout 1500 rocprofv3 --pmc ${a1//+/ } --kernel-trace --output-format csv -d "$O/pmc_${a1%%+*}" -o p -- python tools/$script ${args//:/ } > /dev/null 2>&1
+      python tools/pmc_table.py "$O/pmc_${a1%%+*}" | tee "$O/pmc_${a1%%+*}.txt" ;;
+    measure) export GANSPACE_HIP_LIB="$R/ganspace_amd/lib_measure/libganspace_hip.so" ;;
+    *) echo "unknown step $step" ;;
+  esac
+done
