@@ -160,17 +160,21 @@ def device_generation_enabled(device) -> bool:
     return torch.device(device).type == "cuda" and os.environ.get("GANSPACE_ZGEN", "device") != "host"
 
 
-ZGEN_STAGING_BYTES = 1 << 30      # device staging of one gs_zgen_device launch (device_groups)
+ZGEN_STAGING_BYTES = 8 << 30      # device staging of one gs_zgen_device launch (device_groups), and never more than a
+ZGEN_STAGING_FRACTION = 4         # quarter of the free device memory
+ZGEN_GROUP = 256                  # streams per launch: one workgroup (four waves) per stream
 
 
-def device_groups(kind: str, seeds, n: int, dim: int, device, truncation: float = 1.0, group: int = 256):
+def device_groups(kind: str, seeds, n: int, dim: int, device, truncation: float = 1.0, group: int = None, out=None):
     """Yield ``(lo, z)`` for ``seeds`` in order, ``z`` a ``[m, n, dim]`` float32 DEVICE tensor whose slice ``z[j]`` holds
     ``RandomState(seeds[lo + j]).standard_normal(n * dim)`` (``kind="stylegan"``) or BigGAN's
     ``truncation * truncnorm.rvs(-2, 2, size=(n, dim), random_state=RandomState(seed))`` - generated on the device, one
-    workgroup (four waves) per seed, up to ``group`` seeds per launch.  A launch lasts as long as ONE stream whatever the
-    group, so the groups only have to be long enough to keep most CUs busy: they are bounded by ``ZGEN_STAGING_BYTES``
-    (1 GiB: 52 streams of 10 000 x 512; round 5 staged up to 8 GiB next to the resident latents) and by a quarter of the
-    free device memory.  Nothing touches the host: no pinned ring, no H2D copy."""
+    workgroup (four waves) per seed, up to ``group`` seeds per launch.  A launch lasts as long as ONE stream (22 ms for
+    10 000 x 512 normals) however many streams it holds, so a job's generation time is its NUMBER OF LAUNCHES: the groups are
+    as long as memory allows - ``out`` (``[len(seeds), n, dim]``, e.g. the resident latent array of a Z-space job: no staging
+    at all) or a staging buffer of at most ``ZGEN_STAGING_BYTES`` / a quarter of the free device memory.  (Round 6 first
+    capped the staging at 1 GiB: cfg4's 801 streams became 16 launches instead of 4, 0.35 s instead of 0.09 s.)  Nothing
+    touches the host: no pinned ring, no H2D copy."""
     import ctypes as C
     import torch
     from . import _lib
@@ -186,22 +190,27 @@ def device_groups(kind: str, seeds, n: int, dim: int, device, truncation: float 
     if len(seeds) == 0:
         return
     seeds_dev = torch.from_numpy(seeds.view(np.int32).copy()).to(device)
-    budget = ZGEN_STAGING_BYTES
-    try:
-        budget = min(budget, torch.cuda.mem_get_info(device)[0] // 4)
-    except Exception:
-        pass
-    group = max(1, min(int(group), len(seeds), budget // max(1, 4 * count)))
+    group = max(1, min(int(group or ZGEN_GROUP), len(seeds)))
+    if out is None:
+        budget = ZGEN_STAGING_BYTES
+        try:
+            budget = min(budget, torch.cuda.mem_get_info(device)[0] // ZGEN_STAGING_FRACTION)
+        except Exception:
+            pass
+        group = max(1, min(group, budget // max(1, 4 * count)))
+    else:
+        assert out.dtype == torch.float32 and out.is_contiguous() and out.numel() == len(seeds) * count and out.is_cuda
+        out = out.view(len(seeds), int(n), int(dim))
     stream = _lib.current_stream_ptr()
     for lo in range(0, len(seeds), group):
         m = min(group, len(seeds) - lo)
-        buf = torch.empty((m, int(n), int(dim)), dtype=torch.float32, device=device)
+        buf = out[lo:lo + m] if out is not None else torch.empty((m, int(n), int(dim)), dtype=torch.float32, device=device)
         _lib.check(lib.gs_zgen_device(C.c_void_p(seeds_dev.data_ptr() + 4 * lo), m, count, C.c_void_p(buf.data_ptr()), count,
                                       knd, la, lm, scale, stream))
         yield lo, buf
 
 
-def device_batches(kind: str, seeds, n: int, dim: int, device, truncation: float = 1.0, group: int = 256):
+def device_batches(kind: str, seeds, n: int, dim: int, device, truncation: float = 1.0, group: int = None):
     """:func:`device_groups` one stream at a time: yields ``(index, z)`` with ``z`` the ``[n, dim]`` batch of
     ``seeds[index]``."""
     for lo, buf in device_groups(kind, seeds, n, dim, device, truncation, group):

@@ -55,22 +55,35 @@ def eigh_sym(A):
     return w, V, sweeps.value
 
 
-def mapping_forward(z, weights, bias=None, lr_mul=0.01, slope=0.2, gain=math.sqrt(2.0), pixelnorm=True):
-    """StyleGAN2 mapping network ``style(z)``: ``weights [L, dim, dim]``, ``bias [L, dim]``."""
+_mapping_ws = {}
+
+
+def mapping_forward(z, weights, bias=None, lr_mul=0.01, slope=0.2, gain=math.sqrt(2.0), pixelnorm=True, out=None):
+    """StyleGAN2 mapping network ``style(z)``: ``weights [L, dim, dim]``, ``bias [L, dim]``.  Row-wise: any number of
+    mini-batches may go through one call (long calls run on the panel-blocked GEMM, ``gs_mapping_forward_ws``); ``out``
+    may be a row slice of a larger array (the resident latents)."""
     import torch
     lib = _lib.load()
-    _need_cuda(z, weights, bias)
+    _need_cuda(z, weights, bias, out)
     z = z.to(torch.float32).contiguous()
     weights = weights.to(torch.float32).contiguous()
     L, dim, dim2 = weights.shape
     assert dim == dim2 and z.shape[1] == dim
     if bias is not None:
         bias = bias.to(torch.float32).contiguous()
-    w = torch.empty_like(z)
-    scratch = torch.empty_like(z)
-    _lib.check(lib.gs_mapping_forward(_p(z), _p(w), _p(scratch), _p(weights), _p(bias), L, dim,
-                                      lr_mul / math.sqrt(dim), lr_mul, slope, gain, 1 if pixelnorm else 0,
-                                      z.shape[0], _lib.current_stream_ptr()))
+    w = out if out is not None else torch.empty_like(z)
+    assert w.dtype == torch.float32 and w.shape == z.shape and w.is_contiguous()
+    nb = C.c_int64(0)
+    _lib.check(lib.gs_mapping_workspace_nbytes(z.shape[0], dim, L, C.byref(nb)))
+    # one workspace per (device, stream), grown on demand: consecutive calls on a stream are ordered, so they may share it
+    key = (z.device, torch.cuda.current_stream(z.device).cuda_stream)
+    ws = _mapping_ws.get(key)
+    if ws is None or ws.numel() < nb.value:
+        ws = torch.empty(max(nb.value, 16), dtype=torch.uint8, device=z.device)
+        _mapping_ws[key] = ws
+    _lib.check(lib.gs_mapping_forward_ws(_p(z), _p(w), _p(weights), _p(bias), L, dim, lr_mul / math.sqrt(dim), lr_mul,
+                                         slope, gain, 1 if pixelnorm else 0, z.shape[0], _p(ws), ws.numel(),
+                                         _lib.current_stream_ptr()))
     return w
 
 

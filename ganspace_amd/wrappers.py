@@ -375,8 +375,13 @@ class StyleGAN2(BaseModel):
     # parallel worker processes while keeping the reference's seeding protocol bit for bit
     z_spec = ("stylegan", 512)
 
+    def latent_is_z(self):
+        """``latent_from_z`` is the identity (Z is the primary latent space)."""
+        return not self.w_primary
+
     def latent_from_z(self, z_host):
-        """z (host ndarray, or a tensor already on its way to the device) -> the latent the block loop uses."""
+        """z (host ndarray, or a tensor already on its way to the device) -> the latent the block loop uses.  Row-wise:
+        callers may hand over any number of mini-batches at once."""
         z = z_host if torch.is_tensor(z_host) else torch.from_numpy(z_host)
         z = z.float().to(self.device)
         if self.w_primary:
@@ -583,6 +588,9 @@ class BigGAN(BaseModel):
         return torch.from_numpy(noise_vector).to(self.device)
 
     z_spec = ("biggan", 128)
+
+    def latent_is_z(self):
+        return True
 
     def latent_from_z(self, z_host):
         z = z_host if torch.is_tensor(z_host) else torch.from_numpy(z_host)

@@ -1,17 +1,28 @@
-"""Time the mapping network (8 x [10000 x 512 x 512] f32-MFMA layers) and gen_z-shaped Linear on the device."""
+"""Time the mapping network (8 x [rows x 512 x 512] f32-MFMA layers) per call length - the per-layer kernels below 24 576 rows,
+the panel-blocked path (gs_gemm_blocked.hip) from there on - and the gen_z-shaped Linear, on the device.
+    python tools/mapping_probe.py [rows ...]"""
 import os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import bench
 from ganspace_amd import ops
 dev = torch.device("cuda", 0)
-W, b = bench.make_mapping_weights(dev)
-z = torch.randn(10000, 512, device=dev)
-for rep in range(3):
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    for i in range(20): w = ops.mapping_forward(z, W, b)
-    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 20
-    fl = 8 * 2 * 10000 * 512 * 512
-    print(f"mapping 10000x512, 8 layers: {dt*1e6:.0f} us  ({fl/dt/1e12:.1f} TF/s, {dt/8*1e6:.1f} us per layer)")
+torch.manual_seed(0)
+W = torch.randn(8, 512, 512, device=dev) / 0.01
+b = torch.zeros(8, 512, device=dev)
+rows_list = [int(a) for a in sys.argv[1:]] or [10000, 16384, 24576, 32768, 40000, 65536, 80000, 131072, 520000]
+for rows in rows_list:
+    z = torch.randn(rows, 512, device=dev)
+    out = torch.empty_like(z)
+    iters = max(3, min(20, int(2e6 // rows)))
+    best = None
+    for rep in range(3):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for i in range(iters): ops.mapping_forward(z, W, b, out=out)
+        torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / iters
+        best = dt if best is None else min(best, dt)
+    fl = 8 * 2 * rows * 512 * 512
+    print(f"mapping {rows:7d} x 512, 8 layers: {best*1e6:9.0f} us  ({fl/best/1e12:6.1f} TF/s = {fl/best/157.3e12:.3f} of peak, "
+          f"{best/8*1e6*10000/rows:6.1f} us per 10 000-row layer equivalent)", flush=True)
+    del z, out
 x = torch.randn(2000, 256, device=dev); Wg = torch.randn(32768, 256, device=dev) * 0.05; bg = torch.zeros(32768, device=dev)
 for rep in range(2):
     torch.cuda.synchronize(); t0 = time.perf_counter()

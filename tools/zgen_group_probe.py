@@ -1,0 +1,27 @@
+"""gs_zgen_device: duration of ONE launch against the number of streams in it (one workgroup of four waves per seed; 182
+VGPRs per wave leave room for two workgroups per CU).  python tools/zgen_group_probe.py"""
+import ctypes as C, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from ganspace_amd import _lib
+lib = _lib.load()
+dev = torch.device("cuda", 0)
+n, dim = 10000, 512
+count = n * dim
+for kind, cnt in ((0, count), (1, 2000 * 128)):
+    for nseeds in (64, 128, 256, 384, 512, 768, 1024, 1536, 2048):
+        if nseeds * cnt * 4 > 60e9:
+            continue
+        seeds = torch.from_numpy(np.random.RandomState(1).randint(0, 2**31 - 1, size=nseeds).astype(np.int32)).to(dev)
+        buf = torch.empty((nseeds, cnt), dtype=torch.float32, device=dev)
+        la, lm = (float.fromhex("-0x1.e43f625df3b24p+1"), float.fromhex("-0x1.7d7bfd8ad78c5p-5")) if kind else (0.0, 0.0)
+        best = None
+        for rep in range(3):
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            _lib.check(lib.gs_zgen_device(C.c_void_p(seeds.data_ptr()), nseeds, cnt, C.c_void_p(buf.data_ptr()), cnt, kind, la, lm,
+                                          1.0, _lib.current_stream_ptr()))
+            torch.cuda.synchronize(); dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+        print(f"kind {kind} count {cnt}: {nseeds:5d} seeds in one launch: {best*1e3:7.2f} ms  = {best/nseeds*1e3:.3f} ms per seed, "
+              f"{nseeds*cnt/best/1e9:.1f} G values/s", flush=True)
+        del buf
