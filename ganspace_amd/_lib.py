@@ -64,8 +64,6 @@ SIGNATURES = {
     "gs_gemm_f64": (_int, [_int, _int, _int, _vp, _i64, _i64, _vp, _i64, _i64, _vp, _i64, C.c_double, C.c_double, _vp, _vp,
                             _vp, _vp]),
     "gs_mapping_forward": (_int, [_vp, _vp, _vp, _vp, _vp, _int, _int, _f32, _f32, _f32, _f32, _int, _i64, _vp]),
-    "gs_mapping_workspace_nbytes": (_int, [_i64, _int, _int, C.POINTER(_i64)]),
-    "gs_mapping_forward_ws": (_int, [_vp, _vp, _vp, _vp, _int, _int, _f32, _f32, _f32, _f32, _int, _i64, _vp, _i64, _vp]),
     "gs_linear_forward": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _int, _vp]),
     "gs_project_rows_nbytes": (_int, [_i64, _int, _int, C.POINTER(_i64)]),
     "gs_project_rows": (_int, [_vp, _i64, _i64, _int, _vp, _vp, _int, _vp, _vp, _i64, _vp, _i64, _vp]),

@@ -38,25 +38,10 @@ __host__ __device__ inline int64_t blocked_elems(int64_t rows, int64_t K) {
 #define GB_DSR128(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
 #define GB_DSWAIT4(a, b, c, e) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(e))
 
-// Epilogues.  EPI_PLAIN: C = A B^T, row-major (the convolution GEMMs).  EPI_ACT: row-major
-// C = act((A B^T) wscale + bias bscale) - the LAST layer of the mapping network.  EPI_ACT_BLOCKED: the same values written as
-// the panel-blocked A operand of the NEXT layer (K' = N): the MFMA operands are swapped so that a lane holds ONE output row
-// and 16 output columns - four groups of four consecutive columns, i.e. four 16-byte k-quads of that row in the [k-quad][row][4]
-// unit of K-block (column / 32): 32 lanes write 512 contiguous bytes, no transpose, no `block_rows` pass between the layers.
-enum { EPI_PLAIN = 0, EPI_ACT = 1, EPI_ACT_BLOCKED = 2 };
-
-struct BlockedEpilogue {
-    const float *bias;      // [N] or nullptr
-    float wscale, bscale, slope, gain;
-    int act;
-    float *out_blocked;     // EPI_ACT_BLOCKED: [N / 32][npanA][8][128][4]
-};
-
-template <int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_blocked_nt_kernel(const float *__restrict__ A, int npanA,
-                                                                 const float *__restrict__ B, int npanB, int npanB_ld, int nkb,
+                                                                 const float *__restrict__ B, int npanB, int nkb,
                                                                  float *__restrict__ C, int64_t M, int N, int64_t ldc,
-                                                                 int64_t total, BlockedEpilogue ep) {
+                                                                 int64_t total) {
     __shared__ __attribute__((aligned(1024))) unsigned char ring[2 * kBStage];
     // block b runs on XCD b % 8: consecutive tiles of one XCD share their A panel (the N tiles of a row panel) and walk it
     // together; B (the weights) is small and L2-resident
@@ -72,7 +57,7 @@ __global__ __launch_bounds__(256, 2) void gemm_blocked_nt_kernel(const float *__
 
     const char *srcA = reinterpret_cast<const char *>(A) + I * (int64_t)kBUnit + wave * 4096 + lane * 16;
     const char *srcB = reinterpret_cast<const char *>(B) + (int64_t)J * kBUnit + wave * 4096 + lane * 16;
-    const int64_t strideA = (int64_t)npanA * kBUnit, strideB = (int64_t)npanB_ld * kBUnit;
+    const int64_t strideA = (int64_t)npanA * kBUnit, strideB = (int64_t)npanB * kBUnit;
     auto issue = [&](int s) {
         unsigned char *dst = ring + (s & 1) * kBStage + wave * 4096;
         const char *a = srcA + (int64_t)s * strideA;
@@ -97,13 +82,11 @@ __global__ __launch_bounds__(256, 2) void gemm_blocked_nt_kernel(const float *__
     GB_DSR128(pa1, aaddr, (g) * 4096 + 512);      \
     GB_DSR128(pb0, baddr, (g) * 4096);            \
     GB_DSR128(pb1, baddr, (g) * 4096 + 512);
-    // (acc0..3 = row sub-block 0/0/1/1 x column sub-block 0/1/0/1 in every mode; SW: operands swapped, lanes along rows)
-    constexpr bool SW = EPI == EPI_ACT_BLOCKED;
-#define GB_STEP(pa0, pa1, pb0, pb1, e)                                                                      \
-    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(SW ? pb0.e : pa0.e, SW ? pa0.e : pb0.e, acc0, 0, 0, 0);     \
-    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(SW ? pb1.e : pa0.e, SW ? pa0.e : pb1.e, acc1, 0, 0, 0);     \
-    acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(SW ? pb0.e : pa1.e, SW ? pa1.e : pb0.e, acc2, 0, 0, 0);     \
-    acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(SW ? pb1.e : pa1.e, SW ? pa1.e : pb1.e, acc3, 0, 0, 0);
+#define GB_STEP(pa0, pa1, pb0, pb1, e)                                             \
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(pa0.e, pb0.e, acc0, 0, 0, 0);      \
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(pa0.e, pb1.e, acc1, 0, 0, 0);      \
+    acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(pa1.e, pb0.e, acc2, 0, 0, 0);      \
+    acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(pa1.e, pb1.e, acc3, 0, 0, 0);
 #define GB_MMA(pa0, pa1, pb0, pb1) \
     GB_STEP(pa0, pa1, pb0, pb1, x) GB_STEP(pa0, pa1, pb0, pb1, y) GB_STEP(pa0, pa1, pb0, pb1, z) GB_STEP(pa0, pa1, pb0, pb1, w)
 
@@ -139,122 +122,18 @@ __global__ __launch_bounds__(256, 2) void gemm_blocked_nt_kernel(const float *__
 #undef GB_READ
 #undef GB_STEP
 #undef GB_MMA
-    if constexpr (EPI == EPI_ACT_BLOCKED) {
-        // lane = output row (wi * 64 + 32 R + l31 of panel I), registers = output columns 8 q + 4 half + (e & 3) of the
-        // 32-column sub-block (wj * 64 + 32 Cc): K-block J * 4 + wj * 2 + Cc of the next operand, k-quad 2 q + half
-        const int nsub = J * kBT + wj * 64 + 4 * half;            // + 32 Cc + 8 q: first of this lane's four columns
-        auto emit = [&](const f32x16 &acc, int R, int Cc) {
-            const int kb = J * 4 + wj * 2 + Cc;
-            float4 *unit = reinterpret_cast<float4 *>(ep.out_blocked) + ((int64_t)kb * npanA + I) * (int64_t)(kBT * 8);
-            const int row = wi * 64 + R * 32 + l31;
+    const int64_t row_base = I * kBT + wi * 64 + 4 * (lane >> 5);
+    const int col0 = J * kBT + wj * 64 + (lane & 31), col1 = col0 + 32;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                float4 bb = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (ep.bias) bb = *reinterpret_cast<const float4 *>(ep.bias + nsub + 32 * Cc + 8 * q);
-                float v[4] = {acc[4 * q + 0] * ep.wscale + bb.x * ep.bscale, acc[4 * q + 1] * ep.wscale + bb.y * ep.bscale,
-                              acc[4 * q + 2] * ep.wscale + bb.z * ep.bscale, acc[4 * q + 3] * ep.wscale + bb.w * ep.bscale};
-                if (ep.act) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) v[i] = ep.gain * (v[i] >= 0.f ? v[i] : v[i] * ep.slope);
-                }
-                unit[(2 * q + half) * kBT + row] = make_float4(v[0], v[1], v[2], v[3]);
-            }
-        };
-        emit(acc0, 0, 0);
-        emit(acc1, 0, 1);
-        emit(acc2, 1, 0);
-        emit(acc3, 1, 1);
-    } else {
-        const int64_t row_base = I * kBT + wi * 64 + 4 * (lane >> 5);
-        const int col0 = J * kBT + wj * 64 + (lane & 31), col1 = col0 + 32;
-        float bb0 = 0.f, bb1 = 0.f;
-        if constexpr (EPI == EPI_ACT) {
-            if (ep.bias) {
-                bb0 = col0 < N ? ep.bias[col0] * ep.bscale : 0.f;
-                bb1 = col1 < N ? ep.bias[col1] * ep.bscale : 0.f;
-            }
+    for (int e = 0; e < 16; ++e) {
+        const int64_t row = row_base + (e & 3) + 8 * (e >> 2);
+        if (row < M) {
+            if (col0 < N) C[row * ldc + col0] = acc0[e];
+            if (col1 < N) C[row * ldc + col1] = acc1[e];
         }
-        auto fin = [&](float v, float bb) {
-            if constexpr (EPI == EPI_ACT) {
-                v = v * ep.wscale + bb;
-                if (ep.act) v = ep.gain * (v >= 0.f ? v : v * ep.slope);
-            }
-            return v;
-        };
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int64_t row = row_base + (e & 3) + 8 * (e >> 2);
-            if (row < M) {
-                if (col0 < N) C[row * ldc + col0] = fin(acc0[e], bb0);
-                if (col1 < N) C[row * ldc + col1] = fin(acc1[e], bb1);
-            }
-            if (row + 32 < M) {
-                if (col0 < N) C[(row + 32) * ldc + col0] = fin(acc2[e], bb0);
-                if (col1 < N) C[(row + 32) * ldc + col1] = fin(acc3[e], bb1);
-            }
-        }
-    }
-}
-
-// ---- PixelNorm + blocking of the mapping network's input: z [rows, dim] row-major -> x = z rsqrt(mean(z^2) + eps) in the
-// panel-blocked layout (models/stylegan/model.py:138-143 in front of the first EqualLinear).  One workgroup per 128-row panel:
-// pass 1 sums the squares of its rows (thread = k-quad x row lane, reduced over the 8 lanes of a row), pass 2 re-reads the
-// panel (256 KB: L2), scales and transposes unit by unit as block_rows_kernel does.  Rows past `rows` become zero rows.
-__global__ __launch_bounds__(256) void pixelnorm_block_kernel(const float *__restrict__ src, int64_t rows, int dim, int64_t ld,
-                                                              float eps, int normalize, float *__restrict__ dst, int npan) {
-    __shared__ float4 tile[2][kBT * 9];
-    const int tid = threadIdx.x;
-    const int64_t P = blockIdx.x;
-    const int kq = tid & 7, rl = tid >> 3;
-    const int nkb = dim / kBK;
-    const float *rp[4];
-    bool rok[4];
-    float scale[4];
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        const int64_t row = P * kBT + rl + 32 * g;
-        rok[g] = row < rows;
-        rp[g] = src + (rok[g] ? row : 0) * ld + kq * 4;
-        scale[g] = 1.f;
-    }
-    if (normalize) {
-        float ss[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int kb = 0; kb < nkb; ++kb) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const float4 v = *reinterpret_cast<const float4 *>(rp[g] + kb * kBK);
-                ss[g] += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
-            }
-        }
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            float t = ss[g];
-            t += __shfl_xor(t, 1, 64);
-            t += __shfl_xor(t, 2, 64);
-            t += __shfl_xor(t, 4, 64);
-            scale[g] = 1.0f / sqrtf(t / (float)dim + eps);
-        }
-    }
-    for (int kb = 0; kb < nkb; ++kb) {
-        const int buf = kb & 1;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (rok[g]) {
-                v = *reinterpret_cast<const float4 *>(rp[g] + kb * kBK);
-                v.x *= scale[g];
-                v.y *= scale[g];
-                v.z *= scale[g];
-                v.w *= scale[g];
-            }
-            tile[buf][(rl + 32 * g) * 9 + kq] = v;
-        }
-        __syncthreads();
-        float4 *unit = reinterpret_cast<float4 *>(dst) + ((int64_t)kb * npan + P) * (int64_t)(kBT * 8);
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int idx = tid + 256 * g, row = idx & 127, q = idx >> 7;
-            unit[q * kBT + row] = tile[buf][row * 9 + q];
+        if (row + 32 < M) {
+            if (col0 < N) C[(row + 32) * ldc + col0] = acc2[e];
+            if (col1 < N) C[(row + 32) * ldc + col1] = acc3[e];
         }
     }
 }
@@ -328,61 +207,6 @@ __global__ __launch_bounds__(256) void block_rows_kernel(const float *__restrict
     }
 }
 
-// ---- the StyleGAN2 mapping network on the blocked GEMM ------------------------------------------------------------------------
-// (reference call sites models/wrappers.py:177,200; network models/stylegan/model.py:190-216.)  Per chunk of <= kMapChunkRows
-// rows: pixelnorm_block (z -> blocked x), then one launch per layer - bias / equalised-lr scales / sqrt(2) lrelu fused, every
-// layer but the last WRITING the blocked operand of the next one - and the last layer writing row-major w.  The weights of
-// all layers are blocked by one launch per call ([L * dim] rows: layer l = panels l * dim / 128 ...).  A chunk of 16 384 rows
-// is 512 tiles = one round of the chip's 512 workgroup slots; the old per-layer kernel (gs_linear.hip: linear_act_fast_kernel,
-// 160 x 128 tiles, one 10 000-row mini-batch per launch) stays the path for short calls.
-constexpr int64_t kMapChunkRows = 131072;
-
-int64_t mapping_blocked_workspace_bytes(int64_t rows, int dim, int layers) {
-    const int64_t chunk = rows < kMapChunkRows ? rows : kMapChunkRows;
-    return (int64_t)sizeof(float) * (2 * blocked_elems(chunk, dim) + blocked_elems((int64_t)layers * dim, dim));
-}
-
-int mapping_forward_blocked(const float *z, float *w, const float *weights, const float *bias, int layers, int dim, float wscale,
-                            float bscale, float slope, float gain, int pixelnorm, int64_t rows, void *workspace,
-                            int64_t workspace_bytes, hipStream_t stream) {
-    GS_REQUIRE(dim % kBT == 0 && layers >= 1, GS_EINVAL, "mapping (blocked): dim must be a multiple of 128");
-    GS_REQUIRE(workspace && workspace_bytes >= mapping_blocked_workspace_bytes(rows, dim, layers), GS_EINVAL,
-               "mapping (blocked): workspace smaller than gs_mapping_workspace_nbytes");
-    const int64_t chunk_max = rows < kMapChunkRows ? rows : kMapChunkRows;
-    float *act[2] = {static_cast<float *>(workspace), static_cast<float *>(workspace) + blocked_elems(chunk_max, dim)};
-    float *wblk = act[1] + blocked_elems(chunk_max, dim);
-    const int npanW = dim / kBT, nkb = dim / kBK;
-    const int64_t wrows = (int64_t)layers * dim;
-    GS_REQUIRE(wrows / kBT <= 65535, GS_EINVAL, "mapping (blocked): too many layers");
-    hipLaunchKernelGGL((block_rows_kernel<false>), dim3((unsigned)ceil_div(nkb, kBlockKB), (unsigned)(wrows / kBT)), dim3(256), 0,
-                       stream, weights, wrows, (int64_t)dim, (int64_t)dim, 0, 0, 0, wblk, (int)(wrows / kBT));
-    // chunks: as few as possible, of equal length (whole 128-row panels)
-    const int64_t nchunks = ceil_div(rows, kMapChunkRows);
-    const int64_t per = round_up(ceil_div(rows, nchunks), kBT);
-    for (int64_t r0 = 0; r0 < rows; r0 += per) {
-        const int64_t m = rows - r0 < per ? rows - r0 : per;
-        const int npanA = (int)ceil_div(m, kBT);
-        hipLaunchKernelGGL(pixelnorm_block_kernel, dim3((unsigned)npanA), dim3(256), 0, stream, z + r0 * dim, m, dim, (int64_t)dim,
-                           1e-8f, pixelnorm, act[0], npanA);
-        const int64_t total = (int64_t)npanA * npanW;
-        const unsigned grid = (unsigned)(((total + 7) / 8) * 8);
-        int cur = 0;
-        for (int l = 0; l < layers; ++l) {
-            BlockedEpilogue ep{bias ? bias + (int64_t)l * dim : nullptr, wscale, bscale, slope, gain, 1, act[cur ^ 1]};
-            const float *wl = wblk + (int64_t)l * npanW * (kBT * kBK);       // first panel of layer l (K-block 0)
-            if (l + 1 < layers)
-                hipLaunchKernelGGL((gemm_blocked_nt_kernel<EPI_ACT_BLOCKED>), dim3(grid), dim3(256), 0, stream, act[cur], npanA, wl,
-                                   npanW, layers * npanW, nkb, (float *)nullptr, m, dim, (int64_t)dim, total, ep);
-            else
-                hipLaunchKernelGGL((gemm_blocked_nt_kernel<EPI_ACT>), dim3(grid), dim3(256), 0, stream, act[cur], npanA, wl, npanW,
-                                   layers * npanW, nkb, w + r0 * dim, m, dim, (int64_t)dim, total, ep);
-            cur ^= 1;
-        }
-    }
-    GS_HIP_CHECK(hipGetLastError());
-    return GS_OK;
-}
-
 }  // namespace gs
 
 using namespace gs;
@@ -434,8 +258,8 @@ int gs_gemm_blocked_nt(const float *a_blocked, int64_t rows_a, const float *b_bl
     const int64_t total = npanA * npanB;
     GS_REQUIRE(total + 7 < 2147483647 && npanA < 2147483647 && nkb < 2147483647, GS_EINVAL, "gs_gemm_blocked_nt: grid too large");
     const unsigned grid = (unsigned)(((total + 7) / 8) * 8);
-    hipLaunchKernelGGL((gemm_blocked_nt_kernel<EPI_PLAIN>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a_blocked, (int)npanA,
-                       b_blocked, (int)npanB, (int)npanB, (int)nkb, c, rows_a, rows_b, ldc, total, BlockedEpilogue{});
+    hipLaunchKernelGGL(gemm_blocked_nt_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, a_blocked, (int)npanA, b_blocked,
+                       (int)npanB, (int)nkb, c, rows_a, rows_b, ldc, total);
     GS_HIP_CHECK(hipGetLastError());
     return GS_OK;
 }

@@ -479,6 +479,10 @@ static int launch_linear(const float *x, const float *W, const float *b, float *
                 best = R;
             }
         }
+        if (const char *forced = gs_knob("GS_LINEAR_R")) {         // (measurement build: tile height A/B)
+            const int r = atoi(forced);
+            if (r >= 2 && r <= 6) best = r;
+        }
         const unsigned grid = (unsigned)(ceil_div(M, (int64_t)32 * best) * ntn);
 #define GS_LAUNCH_FAST(RR)                                                                                         \
     hipLaunchKernelGGL((linear_act_fast_kernel<RR>), dim3(grid), dim3(512), 0, stream, x, W, b, y, M, N, K, (int64_t)K, \
@@ -507,21 +511,6 @@ static int project_splits(int64_t rows, int directions, int features) {
     if (s > cap) s = cap;
     if (s > 64) s = 64;
     return (int)(s < 1 ? 1 : s);
-}
-
-// blocked path of the mapping network (gs_gemm_blocked.hip)
-int64_t mapping_blocked_workspace_bytes(int64_t rows, int dim, int layers);
-int mapping_forward_blocked(const float *z, float *w, const float *weights, const float *bias, int layers, int dim, float wscale,
-                            float bscale, float slope, float gain, int pixelnorm, int64_t rows, void *workspace,
-                            int64_t workspace_bytes, hipStream_t stream);
-
-// Rows from which the blocked path pays: below, the 128-row panels of one call do not fill the 512 workgroup slots (10 000 rows:
-// 316 tiles - measured 82 us per layer against 51 us for the 160 x 128 tiling of linear_act_fast_kernel<5>).
-constexpr int64_t kMapBlockedMinRows = 24576;
-
-static bool mapping_uses_blocked(int64_t rows, int dim) {
-    static const bool off = gs_knob("GS_MAP_NO_BLOCKED") != nullptr;       // (measurement build: A/B against the per-layer kernels)
-    return !off && dim % 128 == 0 && rows >= kMapBlockedMinRows;
 }
 
 }  // namespace gs
@@ -610,33 +599,6 @@ int gs_mapping_forward(const float *z, float *w, float *scratch, const float *we
     }
     GS_HIP_CHECK(hipGetLastError());
     return GS_OK;
-}
-
-int gs_mapping_workspace_nbytes(int64_t rows, int dim, int layers, int64_t *nbytes) {
-    GS_REQUIRE(nbytes && rows >= 0 && dim >= 4 && layers >= 1, GS_EINVAL, "gs_mapping_workspace_nbytes: bad argument");
-    *nbytes = mapping_uses_blocked(rows, dim) ? mapping_blocked_workspace_bytes(rows, dim, layers)
-                                              : (int64_t)sizeof(float) * rows * dim;
-    return GS_OK;
-}
-
-int gs_mapping_forward_ws(const float *z, float *w, const float *weights, const float *bias, int layers, int dim, float wscale,
-                          float bscale, float slope, float gain, int pixelnorm, int64_t rows, void *workspace,
-                          int64_t workspace_bytes, void *stream_) {
-    GS_REQUIRE(z && w && weights, GS_EINVAL, "gs_mapping_forward_ws: NULL argument");
-    GS_REQUIRE(layers >= 1 && dim >= 4 && dim % 4 == 0 && rows >= 0, GS_EINVAL,
-               "gs_mapping_forward_ws: dim must be a positive multiple of 4");
-    if (rows == 0) return GS_OK;
-    GS_REQUIRE(workspace != nullptr, GS_EINVAL, "gs_mapping_forward_ws: NULL workspace");
-    GS_REQUIRE(((reinterpret_cast<uintptr_t>(z) | reinterpret_cast<uintptr_t>(w) | reinterpret_cast<uintptr_t>(workspace) |
-                 reinterpret_cast<uintptr_t>(weights)) & 15) == 0,
-               GS_EINVAL, "gs_mapping_forward_ws: buffers must be 16-byte aligned");
-    if (mapping_uses_blocked(rows, dim))
-        return mapping_forward_blocked(z, w, weights, bias, layers, dim, wscale, bscale, slope, gain, pixelnorm, rows, workspace,
-                                       workspace_bytes, (hipStream_t)stream_);
-    GS_REQUIRE(workspace_bytes >= (int64_t)sizeof(float) * rows * dim, GS_EINVAL,
-               "gs_mapping_forward_ws: workspace smaller than gs_mapping_workspace_nbytes");
-    return gs_mapping_forward(z, w, static_cast<float *>(workspace), weights, bias, layers, dim, wscale, bscale, slope, gain,
-                              pixelnorm, rows, stream_);
 }
 
 }  // extern "C"

@@ -59,9 +59,10 @@ _mapping_ws = {}
 
 
 def mapping_forward(z, weights, bias=None, lr_mul=0.01, slope=0.2, gain=math.sqrt(2.0), pixelnorm=True, out=None):
-    """StyleGAN2 mapping network ``style(z)``: ``weights [L, dim, dim]``, ``bias [L, dim]``.  Row-wise: any number of
-    mini-batches may go through one call (long calls run on the panel-blocked GEMM, ``gs_mapping_forward_ws``); ``out``
-    may be a row slice of a larger array (the resident latents)."""
+    """StyleGAN2 mapping network ``style(z)``: ``weights [L, dim, dim]``, ``bias [L, dim]``.  Row-wise - every output row is a
+    function of its input row alone, bit for bit whatever the call length - so callers push many mini-batches through one
+    call: at 80 000 rows the per-layer kernel runs at 0.76 of the f32-MFMA peak (two workgroups per CU), at one 10 000-row
+    mini-batch at 0.62 (252 tiles on 256 CUs).  ``out`` may be a row slice of a larger array (the resident latents)."""
     import torch
     lib = _lib.load()
     _need_cuda(z, weights, bias, out)
@@ -72,18 +73,16 @@ def mapping_forward(z, weights, bias=None, lr_mul=0.01, slope=0.2, gain=math.sqr
     if bias is not None:
         bias = bias.to(torch.float32).contiguous()
     w = out if out is not None else torch.empty_like(z)
-    assert w.dtype == torch.float32 and w.shape == z.shape and w.is_contiguous()
-    nb = C.c_int64(0)
-    _lib.check(lib.gs_mapping_workspace_nbytes(z.shape[0], dim, L, C.byref(nb)))
-    # one workspace per (device, stream), grown on demand: consecutive calls on a stream are ordered, so they may share it
+    assert w.dtype == torch.float32 and w.shape == z.shape and w.is_contiguous() and w.data_ptr() != z.data_ptr()
+    # ping-pong partner of `w`: one scratch per (device, stream), grown on demand - consecutive calls on a stream are ordered
     key = (z.device, torch.cuda.current_stream(z.device).cuda_stream)
     ws = _mapping_ws.get(key)
-    if ws is None or ws.numel() < nb.value:
-        ws = torch.empty(max(nb.value, 16), dtype=torch.uint8, device=z.device)
+    if ws is None or ws.numel() < z.numel():
+        ws = torch.empty(max(z.numel(), 4), dtype=torch.float32, device=z.device)
         _mapping_ws[key] = ws
-    _lib.check(lib.gs_mapping_forward_ws(_p(z), _p(w), _p(weights), _p(bias), L, dim, lr_mul / math.sqrt(dim), lr_mul,
-                                         slope, gain, 1 if pixelnorm else 0, z.shape[0], _p(ws), ws.numel(),
-                                         _lib.current_stream_ptr()))
+    _lib.check(lib.gs_mapping_forward(_p(z), _p(w), _p(ws), _p(weights), _p(bias), L, dim,
+                                      lr_mul / math.sqrt(dim), lr_mul, slope, gain, 1 if pixelnorm else 0,
+                                      z.shape[0], _lib.current_stream_ptr()))
     return w
 
 

@@ -301,17 +301,6 @@ int gs_mapping_forward(const float *z, float *w, float *scratch, const float *we
                        const float *bias, int layers, int dim, float wscale, float bscale,
                        float slope, float gain, int pixelnorm, int64_t rows, void *stream);
 
-/* The same map with a caller-provided workspace of gs_mapping_workspace_nbytes(rows, dim, layers) bytes.
- * Calls of >= 24 576 rows with dim % 128 == 0 run on the panel-blocked GEMM (csrc/gs_gemm_blocked.hip):
- * PixelNorm writes the blocked operand, every layer's epilogue (bias, equalised-lr scales, sqrt(2) lrelu)
- * writes the blocked operand of the next, the last one row-major w; shorter calls take the per-layer
- * kernels of gs_mapping_forward.  Each output row depends on its input row alone, so callers may push any
- * number of mini-batches through one call (decomposition.py:232-236 pre-samples n / B of them).        */
-int gs_mapping_workspace_nbytes(int64_t rows, int dim, int layers, int64_t *nbytes);
-int gs_mapping_forward_ws(const float *z, float *w, const float *weights, const float *bias, int layers,
-                          int dim, float wscale, float bscale, float slope, float gain, int pixelnorm,
-                          int64_t rows, void *workspace, int64_t workspace_bytes, void *stream);
-
 /* y[rows, out] = x[rows, in] @ W[out, in]^T + b  (torch.nn.functional.linear); the BigGAN
  * `generator.gen_z` layer (models/biggan/.../model.py:211-212, wrappers.py:636).          */
 int gs_linear_forward(const float *x, const float *W, const float *b, float *y,
