@@ -71,6 +71,8 @@ SIGNATURES = {
     "gs_block_rows": (_int, [_vp, _i64, _i64, _i64, _vp, _vp]),
     "gs_im2col3x3_blocked": (_int, [_vp, _i64, _int, _int, _int, _vp, _vp]),
     "gs_gemm_blocked_nt": (_int, [_vp, _i64, _vp, _int, _i64, _vp, _i64, _vp]),
+    "gs_modconv3x3_patches": (_int, [_vp, _i64, _int, _int, _int, _vp, _int, _vp, _vp]),
+    "gs_gemm_blocked_nt_styled": (_int, [_vp, _i64, _vp, _int, _i64, _vp, _i64, _int, _vp, _vp, _f32, _vp, _f32, _f32, _int, _vp]),
 }
 
 _lib = None

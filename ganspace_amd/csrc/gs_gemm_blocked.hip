@@ -38,10 +38,25 @@ __host__ __device__ inline int64_t blocked_elems(int64_t rows, int64_t K) {
 #define GB_DSR128(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
 #define GB_DSWAIT4(a, b, c, e) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(e))
 
+// Fused epilogue of a StyleGAN2 `StyledConv` (ModulatedConv2d demodulation + NoiseInjection + FusedLeakyReLU, the layer
+// sequence `StyleGAN2.partial_forward` walks, reference models/wrappers.py:221-255): with rows = output pixels (b, y, x) in
+// groups of `group_rows` = H W per sample and columns = output channels,
+//   c = gain * lrelu(acc * group_colscale[row / group_rows][col] + row_add_weight * row_add[row % group_rows] + bias[col])
+// - four elementwise passes over the activation (each a read + a write of 262 MB at cfg5's 16 x 16 layer) folded into the
+// GEMM's store.
+struct ConvEpilogue {
+    const float *group_colscale;   // [M / group_rows, N] demodulation d[b, o], or nullptr
+    const float *row_add;          // [group_rows] noise image, or nullptr
+    const float *bias;             // [N], or nullptr
+    float row_add_weight, slope, gain;
+    int group_rows, act;
+};
+
+template <bool EPI>
 __global__ __launch_bounds__(256, 2) void gemm_blocked_nt_kernel(const float *__restrict__ A, int npanA,
                                                                  const float *__restrict__ B, int npanB, int nkb,
                                                                  float *__restrict__ C, int64_t M, int N, int64_t ldc,
-                                                                 int64_t total) {
+                                                                 int64_t total, ConvEpilogue ep) {
     __shared__ __attribute__((aligned(1024))) unsigned char ring[2 * kBStage];
     // block b runs on XCD b % 8: consecutive tiles of one XCD share their A panel (the N tiles of a row panel) and walk it
     // together; B (the weights) is small and L2-resident
@@ -124,16 +139,33 @@ __global__ __launch_bounds__(256, 2) void gemm_blocked_nt_kernel(const float *__
 #undef GB_MMA
     const int64_t row_base = I * kBT + wi * 64 + 4 * (lane >> 5);
     const int col0 = J * kBT + wj * 64 + (lane & 31), col1 = col0 + 32;
+    float bias0 = 0.f, bias1 = 0.f;
+    if constexpr (EPI) {
+        if (ep.bias) {
+            bias0 = col0 < N ? ep.bias[col0] : 0.f;
+            bias1 = col1 < N ? ep.bias[col1] : 0.f;
+        }
+    }
+    auto fin = [&](float v, int64_t row, int col, float bias) {
+        if constexpr (EPI) {
+            const int64_t grp = row / ep.group_rows;
+            if (ep.group_colscale) v *= ep.group_colscale[grp * N + col];
+            if (ep.row_add) v += ep.row_add_weight * ep.row_add[row - grp * ep.group_rows];
+            v += bias;
+            if (ep.act) v = ep.gain * (v >= 0.f ? v : v * ep.slope);
+        }
+        return v;
+    };
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
         const int64_t row = row_base + (e & 3) + 8 * (e >> 2);
         if (row < M) {
-            if (col0 < N) C[row * ldc + col0] = acc0[e];
-            if (col1 < N) C[row * ldc + col1] = acc1[e];
+            if (col0 < N) C[row * ldc + col0] = fin(acc0[e], row, col0, bias0);
+            if (col1 < N) C[row * ldc + col1] = fin(acc1[e], row, col1, bias1);
         }
         if (row + 32 < M) {
-            if (col0 < N) C[(row + 32) * ldc + col0] = acc2[e];
-            if (col1 < N) C[(row + 32) * ldc + col1] = acc3[e];
+            if (col0 < N) C[(row + 32) * ldc + col0] = fin(acc2[e], row + 32, col0, bias0);
+            if (col1 < N) C[(row + 32) * ldc + col1] = fin(acc3[e], row + 32, col1, bias1);
         }
     }
 }
@@ -207,6 +239,92 @@ __global__ __launch_bounds__(256) void block_rows_kernel(const float *__restrict
     }
 }
 
+// ---- 3 x 3 patches of a StyleGAN2 modulated convolution, fused (ModulatedConv2d, reference call path models/wrappers.py:221-255):
+// the input x [B, h, w, Cc] (NHWC) is scaled per (sample, channel) by the style s[b, c] and - UP - bilinearly upsampled by 2
+// (F.interpolate(scale_factor=2, mode="bilinear", align_corners=False): source index 0.5 (Y + 0.5) - 0.5 clamped at 0, i.e.
+// weights 0.25 / 0.75) WHILE the patches are gathered: the scaled copy of x (read + write) and the upsampled tensor (a write of
+// four times x and its read-back) never exist.  Output grid H x W = (2h x 2w if UP else h x w); layout and zero padding as
+// block_rows_kernel<true>.
+template <bool UP>
+__global__ __launch_bounds__(256) void patch_fused_kernel(const float *__restrict__ src, const float *__restrict__ chan_scale,
+                                                          int64_t rows, int H, int W, int Cc, float *__restrict__ dst, int npan) {
+    __shared__ float4 tile[2][kBT * 9];
+    const int tid = threadIdx.x;
+    const int64_t P = blockIdx.y;
+    const int kq = tid & 7, rl = tid >> 3;
+    const int64_t K = 9ll * Cc, nkb = K / kBK;
+    const int64_t kb_begin = (int64_t)blockIdx.x * kBlockKB;
+    const int h = UP ? H / 2 : H, w = UP ? W / 2 : W;
+    int64_t bimg[4];           // element offset of sample b's image;  bsc: of its scale row
+    int64_t bsc[4];
+    int py[4], px[4];
+    bool rok[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int64_t row = P * kBT + rl + 32 * g;
+        rok[g] = row < rows;
+        const int64_t rc = rok[g] ? row : 0;
+        const int64_t hw = (int64_t)H * W;
+        const int64_t b = rc / hw;
+        const int rem = (int)(rc - b * hw);
+        py[g] = rem / W;
+        px[g] = rem - py[g] * W;
+        bimg[g] = b * (int64_t)h * w * Cc;
+        bsc[g] = b * (int64_t)Cc;
+    }
+    for (int it = 0; it < kBlockKB; ++it) {
+        const int64_t kb = kb_begin + it;
+        if (kb >= nkb) break;                     // (uniform)
+        const int64_t j = kb * kBK + kq * 4;
+        const int buf = it & 1;
+        const int tap = (int)(j / Cc);            // (kh, kw) of this K-block
+        const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+        const int c = (int)(j - (int64_t)tap * Cc);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            const int Y = py[g] + dy, X = px[g] + dx;
+            if (rok[g] && (unsigned)Y < (unsigned)H && (unsigned)X < (unsigned)W) {
+                const float *img = src + bimg[g] + c;
+                if (UP) {
+                    // at::native upsample_bilinear2d, align_corners = false, scale 0.5
+                    float sy = 0.5f * ((float)Y + 0.5f) - 0.5f, sx = 0.5f * ((float)X + 0.5f) - 0.5f;
+                    sy = sy < 0.f ? 0.f : sy;
+                    sx = sx < 0.f ? 0.f : sx;
+                    const int y0 = (int)sy, x0 = (int)sx;
+                    const int yp = y0 < h - 1 ? 1 : 0, xp = x0 < w - 1 ? 1 : 0;
+                    const float h1 = sy - (float)y0, h0 = 1.f - h1, w1 = sx - (float)x0, w0 = 1.f - w1;
+                    const float4 v00 = *reinterpret_cast<const float4 *>(img + ((int64_t)y0 * w + x0) * Cc);
+                    const float4 v01 = *reinterpret_cast<const float4 *>(img + ((int64_t)y0 * w + x0 + xp) * Cc);
+                    const float4 v10 = *reinterpret_cast<const float4 *>(img + ((int64_t)(y0 + yp) * w + x0) * Cc);
+                    const float4 v11 = *reinterpret_cast<const float4 *>(img + ((int64_t)(y0 + yp) * w + x0 + xp) * Cc);
+                    v.x = h0 * (w0 * v00.x + w1 * v01.x) + h1 * (w0 * v10.x + w1 * v11.x);
+                    v.y = h0 * (w0 * v00.y + w1 * v01.y) + h1 * (w0 * v10.y + w1 * v11.y);
+                    v.z = h0 * (w0 * v00.z + w1 * v01.z) + h1 * (w0 * v10.z + w1 * v11.z);
+                    v.w = h0 * (w0 * v00.w + w1 * v01.w) + h1 * (w0 * v10.w + w1 * v11.w);
+                } else {
+                    v = *reinterpret_cast<const float4 *>(img + ((int64_t)Y * w + X) * Cc);
+                }
+                if (chan_scale) {
+                    const float4 sc = *reinterpret_cast<const float4 *>(chan_scale + bsc[g] + c);
+                    v.x *= sc.x;
+                    v.y *= sc.y;
+                    v.z *= sc.z;
+                    v.w *= sc.w;
+                }
+            }
+            tile[buf][(rl + 32 * g) * 9 + kq] = v;
+        }
+        __syncthreads();
+        float4 *unit = reinterpret_cast<float4 *>(dst) + (kb * npan + P) * (int64_t)(kBT * 8);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int idx = tid + 256 * g, row = idx & 127, q = idx >> 7;
+            unit[q * kBT + row] = tile[buf][row * 9 + q];
+        }
+    }
+}
+
 }  // namespace gs
 
 using namespace gs;
@@ -258,8 +376,49 @@ int gs_gemm_blocked_nt(const float *a_blocked, int64_t rows_a, const float *b_bl
     const int64_t total = npanA * npanB;
     GS_REQUIRE(total + 7 < 2147483647 && npanA < 2147483647 && nkb < 2147483647, GS_EINVAL, "gs_gemm_blocked_nt: grid too large");
     const unsigned grid = (unsigned)(((total + 7) / 8) * 8);
-    hipLaunchKernelGGL(gemm_blocked_nt_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, a_blocked, (int)npanA, b_blocked,
-                       (int)npanB, (int)nkb, c, rows_a, rows_b, ldc, total);
+    hipLaunchKernelGGL((gemm_blocked_nt_kernel<false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a_blocked, (int)npanA,
+                       b_blocked, (int)npanB, (int)nkb, c, rows_a, rows_b, ldc, total, ConvEpilogue{});
+    GS_HIP_CHECK(hipGetLastError());
+    return GS_OK;
+}
+
+int gs_modconv3x3_patches(const float *x_nhwc, int64_t batch, int height, int width, int channels, const float *chan_scale,
+                          int upsample, float *dst_blocked, void *stream) {
+    GS_REQUIRE(x_nhwc && dst_blocked && batch >= 1 && height >= 1 && width >= 1 && channels >= 32 && channels % 32 == 0,
+               GS_EINVAL, "gs_modconv3x3_patches: channels must be a positive multiple of 32");
+    GS_REQUIRE(((reinterpret_cast<uintptr_t>(x_nhwc) | reinterpret_cast<uintptr_t>(dst_blocked) |
+                 reinterpret_cast<uintptr_t>(chan_scale)) & 15) == 0,
+               GS_EINVAL, "gs_modconv3x3_patches: buffers must be 16-byte aligned");
+    const int H = upsample ? 2 * height : height, W = upsample ? 2 * width : width;
+    const int64_t rows = batch * H * W, K = 9ll * channels;
+    const int64_t npan = ceil_div(rows, kBT), nkb = K / kBK;
+    GS_REQUIRE(npan <= 65535, GS_EINVAL, "gs_modconv3x3_patches: more than 65535 row panels (8.3 M output pixels) per call");
+    const dim3 grid((unsigned)ceil_div(nkb, kBlockKB), (unsigned)npan);
+    if (upsample)
+        hipLaunchKernelGGL((patch_fused_kernel<true>), grid, dim3(256), 0, (hipStream_t)stream, x_nhwc, chan_scale, rows, H, W,
+                           channels, dst_blocked, (int)npan);
+    else
+        hipLaunchKernelGGL((patch_fused_kernel<false>), grid, dim3(256), 0, (hipStream_t)stream, x_nhwc, chan_scale, rows, H, W,
+                           channels, dst_blocked, (int)npan);
+    GS_HIP_CHECK(hipGetLastError());
+    return GS_OK;
+}
+
+int gs_gemm_blocked_nt_styled(const float *a_blocked, int64_t rows_a, const float *b_blocked, int rows_b, int64_t cols, float *c,
+                              int64_t ldc, int group_rows, const float *group_colscale, const float *row_add,
+                              float row_add_weight, const float *bias, float slope, float gain, int act, void *stream) {
+    GS_REQUIRE(a_blocked && b_blocked && c && rows_a >= 1 && rows_b >= 1 && cols >= 1 && ldc >= rows_b && group_rows >= 1,
+               GS_EINVAL, "gs_gemm_blocked_nt_styled: bad argument");
+    GS_REQUIRE(((reinterpret_cast<uintptr_t>(a_blocked) | reinterpret_cast<uintptr_t>(b_blocked)) & 15) == 0, GS_EINVAL,
+               "gs_gemm_blocked_nt_styled: operands must be 16-byte aligned");
+    const int64_t npanA = ceil_div(rows_a, kBT), npanB = ceil_div(rows_b, kBT), nkb = ceil_div(cols, kBK);
+    const int64_t total = npanA * npanB;
+    GS_REQUIRE(total + 7 < 2147483647 && npanA < 2147483647 && nkb < 2147483647, GS_EINVAL,
+               "gs_gemm_blocked_nt_styled: grid too large");
+    const unsigned grid = (unsigned)(((total + 7) / 8) * 8);
+    const ConvEpilogue ep{group_colscale, row_add, bias, row_add_weight, slope, gain, group_rows, act};
+    hipLaunchKernelGGL((gemm_blocked_nt_kernel<true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a_blocked, (int)npanA,
+                       b_blocked, (int)npanB, (int)nkb, c, rows_a, rows_b, ldc, total, ep);
     GS_HIP_CHECK(hipGetLastError());
     return GS_OK;
 }

@@ -145,6 +145,44 @@ def gemm_blocked_nt(a_blocked, rows_a, b_blocked, rows_b, cols):
     return out
 
 
+def modconv3x3_patches(x_nhwc, chan_scale=None, upsample=False):
+    """Blocked 3 x 3 patch matrix of ``upsample2x(x * chan_scale[:, None, None, :])`` (``chan_scale`` [B, C] or None; the
+    bilinear upsampling of ``F.interpolate(scale_factor=2, mode="bilinear", align_corners=False)``) without materialising the
+    scaled or the upsampled tensor.  Rows = the ``B * H' * W'`` output pixels, columns ``(kh, kw, c)``."""
+    import torch
+    lib = _lib.load()
+    _need_cuda(x_nhwc, chan_scale)
+    assert x_nhwc.dtype == torch.float32 and x_nhwc.dim() == 4 and x_nhwc.is_contiguous()
+    b, h, w, c = x_nhwc.shape
+    if chan_scale is not None:
+        chan_scale = chan_scale.to(torch.float32).contiguous()
+        assert chan_scale.shape == (b, c)
+    f = 2 if upsample else 1
+    dst = _blocked_empty(b * h * f * w * f, 9 * c, x_nhwc.device)
+    _lib.check(lib.gs_modconv3x3_patches(_p(x_nhwc), b, h, w, c, _p(chan_scale), 1 if upsample else 0, _p(dst),
+                                         _lib.current_stream_ptr()))
+    return dst
+
+
+def gemm_blocked_nt_styled(a_blocked, rows_a, b_blocked, rows_b, cols, group_rows, group_colscale=None, row_add=None,
+                           row_add_weight=0.0, bias=None, slope=0.2, gain=math.sqrt(2.0), act=True):
+    """:func:`gemm_blocked_nt` with the StyledConv epilogue fused into the store:
+    ``gain * lrelu(acc * group_colscale[row // group_rows, col] + row_add_weight * row_add[row % group_rows] + bias[col])``."""
+    import torch
+    lib = _lib.load()
+    _need_cuda(a_blocked, b_blocked, group_colscale, row_add, bias)
+    for t in (group_colscale, row_add, bias):
+        assert t is None or (t.dtype == torch.float32 and t.is_contiguous())
+    assert group_colscale is None or group_colscale.numel() == -(-rows_a // group_rows) * rows_b
+    assert row_add is None or row_add.numel() == group_rows
+    assert bias is None or bias.numel() == rows_b
+    out = torch.empty((rows_a, rows_b), dtype=torch.float32, device=a_blocked.device)
+    _lib.check(lib.gs_gemm_blocked_nt_styled(_p(a_blocked), rows_a, _p(b_blocked), rows_b, cols, _p(out), rows_b, int(group_rows),
+                                             _p(group_colscale), _p(row_add), float(row_add_weight), _p(bias), float(slope),
+                                             float(gain), 1 if act else 0, _lib.current_stream_ptr()))
+    return out
+
+
 _project_scratch = {}
 
 

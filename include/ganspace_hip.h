@@ -334,6 +334,25 @@ int gs_im2col3x3_blocked(const float *x_nhwc, int64_t batch, int height, int wid
 int gs_gemm_blocked_nt(const float *a_blocked, int64_t rows_a, const float *b_blocked, int rows_b,
                        int64_t cols, float *c, int64_t ldc, void *stream);
 
+/* One `StyledConv` of the StyleGAN2 synthesis prefix (`StyleGAN2.partial_forward`, models/wrappers.py:221-255, for a conv
+ * layer; published layer definition: ModulatedConv2d + NoiseInjection + FusedLeakyReLU) in two launches:
+ *   gs_modconv3x3_patches      the patches of gs_im2col3x3_blocked with the style modulation (x scaled per sample and input
+ *                              channel by chan_scale [batch, channels], may be NULL) and, with `upsample`, the bilinear x 2
+ *                              upsampling (F.interpolate(scale_factor=2, mode="bilinear", align_corners=False)) applied while
+ *                              gathering: x_nhwc is [batch, height, width, channels], the patch rows are the
+ *                              batch * (2 height) * (2 width) output pixels
+ *   gs_gemm_blocked_nt_styled  gs_gemm_blocked_nt with the epilogue
+ *                              c = gain * lrelu(acc * group_colscale[row / group_rows][col] + row_add_weight * row_add[row % group_rows]
+ *                                               + bias[col], slope)
+ *                              (demodulation d[b, o], noise image, bias, fused leaky ReLU; NULL pointers skip a term, act = 0
+ *                              the activation)                                                                              */
+int gs_modconv3x3_patches(const float *x_nhwc, int64_t batch, int height, int width, int channels,
+                          const float *chan_scale, int upsample, float *dst_blocked, void *stream);
+int gs_gemm_blocked_nt_styled(const float *a_blocked, int64_t rows_a, const float *b_blocked, int rows_b,
+                              int64_t cols, float *c, int64_t ldc, int group_rows,
+                              const float *group_colscale, const float *row_add, float row_add_weight,
+                              const float *bias, float slope, float gain, int act, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -586,6 +586,47 @@ def test_modulated_conv_blocked_path_equals_strided_path(dev, monkeypatch):
     assert (a.double() - ref).abs().max().item() < 2e-5 * ref.abs().max().item()
 
 
+@pytest.mark.parametrize("up,h,cin,cout,b", [(False, 8, 64, 96, 5), (True, 8, 64, 96, 5), (True, 4, 512, 512, 3),
+                                             (False, 4, 32, 40, 7), (True, 5, 32, 130, 2)])
+def test_styled_conv_fused_launches_equal_the_unfused_layer(dev, monkeypatch, up, h, cin, cout, b):
+    """``StyledConv`` on the device in two launches (``gs_modconv3x3_patches``: style modulation + bilinear x 2 upsampling
+    while the patches are gathered; ``gs_gemm_blocked_nt_styled``: demodulation + noise + bias + sqrt(2) lrelu in the GEMM's
+    store) against the layer as the published definition states it - per-sample weights, ``F.interpolate``, grouped
+    convolution, noise injection, fused leaky ReLU - in float64, and against this repository's unfused float32 path."""
+    import torch.nn.functional as F
+    from ganspace_amd.wrappers import StyledConv
+    torch.manual_seed(17 + h + cin)
+    m = StyledConv(cin, cout, 3, 48, upsample=up).to(dev)
+    with torch.no_grad():
+        m.noise_weight.fill_(0.37)
+        m.bias.copy_(0.2 * torch.randn_like(m.bias))
+    x = torch.randn(b, cin, h, h, device=dev)
+    style = torch.randn(b, 48, device=dev)
+    H = 2 * h if up else h
+    noise = torch.randn(1, 1, H, H, device=dev)
+    with torch.no_grad():
+        assert m.conv.fused_available(x)
+        got = m(x, style, noise=noise)
+        monkeypatch.setenv("GANSPACE_CONV_FUSED", "0")
+        assert not m.conv.fused_available(x)
+        unfused = m(x, style, noise=noise)
+        m64 = m.double()
+        ref = m64.conv.forward_grouped(x.double(), style.double())
+        ref = np.sqrt(2.0) * F.leaky_relu(ref + m64.noise_weight * noise.double() + m64.bias, 0.2)
+    assert got.shape == ref.shape == (b, cout, H, H)
+    scale = ref.abs().max().item()
+    assert (got.double() - ref).abs().max().item() < 2e-5 * scale
+    assert (got - unfused).abs().max().item() < 2e-5 * scale
+    with torch.no_grad():                                            # no noise, several sub-batches (staging cap)
+        from ganspace_amd import wrappers
+        monkeypatch.delenv("GANSPACE_CONV_FUSED")
+        monkeypatch.setattr(wrappers, "CONV_STAGING_BYTES", 2 * H * H * 9 * cin * 4)
+        m32 = m.float()
+        a = m32(x, style)
+        ref2 = np.sqrt(2.0) * F.leaky_relu(m64.double().conv.forward_grouped(x.double(), style.double()) + m.bias.double(), 0.2)
+    assert (a.double() - ref2).abs().max().item() < 2e-5 * ref2.abs().max().item()
+
+
 # ---- BASELINE-size properties (no oracle at this size: size-independent invariants) --------------
 
 def test_full_size_block_properties(dev):
