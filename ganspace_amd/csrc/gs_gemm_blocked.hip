@@ -50,6 +50,7 @@ struct ConvEpilogue {
     const float *bias;             // [N], or nullptr
     float row_add_weight, slope, gain;
     int group_rows, act;
+    int group_shift;               // log2(group_rows) when it is a power of two, else -1
 };
 
 template <bool EPI>
@@ -146,26 +147,58 @@ __global__ __launch_bounds__(256, 2) void gemm_blocked_nt_kernel(const float *__
             bias1 = col1 < N ? ep.bias[col1] : 0.f;
         }
     }
-    auto fin = [&](float v, int64_t row, int col, float bias) {
+    // Rows are dealt to a lane in runs of four consecutive, 4-aligned rows (e & 3): with group_rows % 4 == 0 - every
+    // StyleGAN2 resolution - a run lies inside one group, so the group index (a shift for power-of-two groups) and the two
+    // demodulation factors are fetched once per run, not once per element (the first version divided 64-bit per element:
+    // the convs.2 product lost 7 %)
+    auto group_of = [&](int64_t row) -> int64_t {
+        return ep.group_shift >= 0 ? (row >> ep.group_shift) : (int64_t)((uint64_t)row / (uint32_t)ep.group_rows);
+    };
+    auto fin = [&](float v, float d, float add, float bias) {
         if constexpr (EPI) {
-            const int64_t grp = row / ep.group_rows;
-            if (ep.group_colscale) v *= ep.group_colscale[grp * N + col];
-            if (ep.row_add) v += ep.row_add_weight * ep.row_add[row - grp * ep.group_rows];
-            v += bias;
+            v = v * d + add + bias;
             if (ep.act) v = ep.gain * (v >= 0.f ? v : v * ep.slope);
         }
         return v;
     };
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-        const int64_t row = row_base + (e & 3) + 8 * (e >> 2);
-        if (row < M) {
-            if (col0 < N) C[row * ldc + col0] = fin(acc0[e], row, col0, bias0);
-            if (col1 < N) C[row * ldc + col1] = fin(acc1[e], row, col1, bias1);
-        }
-        if (row + 32 < M) {
-            if (col0 < N) C[(row + 32) * ldc + col0] = fin(acc2[e], row + 32, col0, bias0);
-            if (col1 < N) C[(row + 32) * ldc + col1] = fin(acc3[e], row + 32, col1, bias1);
+    for (int q = 0; q < 4; ++q) {
+#pragma unroll
+        for (int hb = 0; hb < 2; ++hb) {                       // rows .. and rows + 32 ..
+            const int64_t run = row_base + 8 * q + 32 * hb;    // first row of the run
+            float d0 = 1.f, d1 = 1.f;
+            int64_t g0 = 0;
+            const bool uniform = !EPI || (ep.group_rows & 3) == 0;
+            if constexpr (EPI) {
+                if (uniform && run < M) {
+                    g0 = group_of(run);
+                    if (ep.group_colscale) {
+                        if (col0 < N) d0 = ep.group_colscale[g0 * N + col0];
+                        if (col1 < N) d1 = ep.group_colscale[g0 * N + col1];
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int64_t row = run + i;
+                const int e = 4 * q + i;
+                if (row >= M) continue;
+                float add = 0.f;
+                if constexpr (EPI) {
+                    int64_t g = g0;
+                    if (!uniform) {
+                        g = group_of(row);
+                        if (ep.group_colscale) {
+                            if (col0 < N) d0 = ep.group_colscale[g * N + col0];
+                            if (col1 < N) d1 = ep.group_colscale[g * N + col1];
+                        }
+                    }
+                    if (ep.row_add) add = ep.row_add_weight * ep.row_add[row - g * ep.group_rows];
+                }
+                const float a0 = hb ? acc2[e] : acc0[e], a1 = hb ? acc3[e] : acc1[e];
+                if (col0 < N) C[row * ldc + col0] = fin(a0, d0, add, bias0);
+                if (col1 < N) C[row * ldc + col1] = fin(a1, d1, add, bias1);
+            }
         }
     }
 }
@@ -416,7 +449,10 @@ int gs_gemm_blocked_nt_styled(const float *a_blocked, int64_t rows_a, const floa
     GS_REQUIRE(total + 7 < 2147483647 && npanA < 2147483647 && nkb < 2147483647, GS_EINVAL,
                "gs_gemm_blocked_nt_styled: grid too large");
     const unsigned grid = (unsigned)(((total + 7) / 8) * 8);
-    const ConvEpilogue ep{group_colscale, row_add, bias, row_add_weight, slope, gain, group_rows, act};
+    int shift = -1;
+    if ((group_rows & (group_rows - 1)) == 0)
+        for (shift = 0; (1 << shift) < group_rows; ++shift) {}
+    const ConvEpilogue ep{group_colscale, row_add, bias, row_add_weight, slope, gain, group_rows, act, shift};
     hipLaunchKernelGGL((gemm_blocked_nt_kernel<true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a_blocked, (int)npanA,
                        b_blocked, (int)npanB, (int)nkb, c, rows_a, rows_b, ldc, total, ep);
     GS_HIP_CHECK(hipGetLastError());

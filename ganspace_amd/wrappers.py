@@ -141,7 +141,33 @@ class ConstantInput(nn.Module):
         return self.input.repeat(latent.shape[0], 1, 1, 1)
 
 
-CONV_STAGING_BYTES = 1 << 30      # im2col staging per product of ModulatedConv2d._conv_hip
+CONV_STAGING_BYTES = None         # im2col staging per product of ModulatedConv2d (None: sized from the device, below)
+
+
+def _conv_staging_bytes(device):
+    """Patch-matrix bytes one convolution product may stage: a sixteenth of the device memory that is free at first use,
+    at most 4 GiB (cfg5's 500 samples at 16 x 16 x 4608 are 2.4 GB = 4000 tiles, 7.8 rounds of the chip; cut into 1 GiB
+    pieces the last, ragged product ran one 0.72-full round), at least 256 MiB.  ``CONV_STAGING_BYTES`` overrides."""
+    global _STAGING_AUTO
+    if CONV_STAGING_BYTES is not None:
+        return int(CONV_STAGING_BYTES)
+    if _STAGING_AUTO is None:
+        try:
+            free = torch.cuda.mem_get_info(device)[0]
+        except Exception:
+            free = 16 << 30
+        _STAGING_AUTO = int(min(4 << 30, max(256 << 20, free // 16)))
+    return _STAGING_AUTO
+
+
+_STAGING_AUTO = None
+
+
+def _sub_batches(b, per):
+    """``b`` samples in as few pieces of at most ``per`` as possible, of (nearly) equal length."""
+    n = -(-b // max(1, per))
+    size = -(-b // n)
+    return [(lo, min(lo + size, b)) for lo in range(0, b, size)]
 
 
 class ModulatedConv2d(nn.Module):
@@ -208,13 +234,12 @@ class ModulatedConv2d(nn.Module):
         kk = wm.shape[1]
         xn = x.permute(0, 2, 3, 1)                                                        # NHWC view
         blocked = k == 3 and c % 32 == 0 and os.environ.get("GANSPACE_CONV", "blocked") == "blocked"
-        # patches per product: <= 1 GiB of staging (cfg5's -b 500 at 16 x 16 is 2.4 GB: three products; a product of a few
-        # hundred MB already fills the chip for dozens of rounds, and the staging buffer sits next to the activations)
-        per = max(1, int(CONV_STAGING_BYTES // max(1, h * w * kk * 4)))
+        # patches per product: bounded staging (see _conv_staging_bytes), equal pieces
+        per = max(1, int(_conv_staging_bytes(x.device) // max(1, h * w * kk * 4)))
         wblk = self._weight_blocked() if blocked else None
         outs = []
-        for lo in range(0, b, per):
-            xb = xn[lo:lo + per]
+        for lo, hi in _sub_batches(b, per):
+            xb = xn[lo:hi]
             nb = xb.shape[0]
             if blocked:
                 cols = ops.im2col3x3_blocked(xb.contiguous())
@@ -256,12 +281,12 @@ class ModulatedConv2d(nn.Module):
         wblk = self._weight_blocked()
         kk = self._weight_matrix().shape[1]
         xn = x.permute(0, 2, 3, 1)                                                                # NHWC view
-        per = max(1, int(CONV_STAGING_BYTES // max(1, H * W * kk * 4)))
+        per = max(1, int(_conv_staging_bytes(x.device) // max(1, H * W * kk * 4)))
         row_add = None if (noise is None or noise_weight == 0.0) else noise.reshape(-1).contiguous()
         bias = None if bias is None else bias.reshape(-1).contiguous()
         outs = []
-        for lo in range(0, b, per):
-            xb = xn[lo:lo + per].contiguous()
+        for lo, hi in _sub_batches(b, per):
+            xb = xn[lo:hi].contiguous()
             nb = xb.shape[0]
             cols = ops.modconv3x3_patches(xb, s[lo:lo + nb], self.upsample)
             outs.append(ops.gemm_blocked_nt_styled(cols, nb * H * W, wblk, self.out_ch, kk, H * W,
