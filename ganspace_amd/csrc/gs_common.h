@@ -259,7 +259,6 @@ struct InvsubPending {
     bool active = false;
     int attempt = 0, P = 0, P0 = 0, j = 1, jj_last = 1, used = 0;
     bool pass2 = false, loewdin = false, identity_start = false;
-    bool precond = false;          // attempt 0 runs the preconditioned schedule (invsub_prepare_precond)
     double ln_gap = 0.0, blocks_seen = 0.0;
     const double *A = nullptr;
     int n = 0, k = 0;
@@ -295,19 +294,6 @@ struct SubspaceWorkspace {
     int inv_plan = 0;              // products before the Rayleigh quotient (0 = derive from the block count)
     double inv_ratio1 = 0.0;       // max / min pivot of R per product at the last orthonormalisation (~lambda_1 / lambda_k)
     int inv_last_products = 0;
-    // Preconditioned schedule of the invariant-subspace step (round 6).  The start basis Q0 is nearly invariant and
-    // B0 = Q0^T A_old Q0 is known BEFORE the block's matrix exists, so A^j Q0 B0^-j stays within (1 + c / t)^j of
-    // orthonormal: between groups of products ONE n x k x k product with B0^-j replaces a CholeskyQR step (Gram matrix +
-    // single-workgroup Cholesky + product).  Cpow = B0^-1 .. B0^-4 are prepared on `side`, beside the head of the block's
-    // chain, from the Cholesky factor of B0 (whose pivots also give the spectrum estimate the acceptance test needs).
-    double *Cpow = nullptr;        // [4][pp][pp]
-    double *Rb = nullptr;          // [pp][pp] R^-1, B0 = R^T R
-    double *rdiagB = nullptr;      // [pp] diag(R)
-    hipStream_t side = nullptr;
-    hipEvent_t ev_state = nullptr, ev_prep = nullptr;
-    bool precond_ready = false;    // Cpow was enqueued for the state the next step starts from (wait for ev_prep)
-    bool precond_ok = true;        // cleared for good when a preconditioned attempt misses (singular B0, clustered data)
-    int precond_k = 0, precond_miss = 0;
     double *Q = nullptr, *Y = nullptr, *Z = nullptr, *R = nullptr;  // [n][pp]  (= ring[0..3])
     // gs_topk.hip: every n x pp block of a solve is taken from a ring of slots that ONE memset has zeroed at the start
     // of the solve, so that the split-K products (atomic epilogue) do not need a zeroing launch each (18 products +
@@ -394,9 +380,6 @@ int invsub_iterate(SubspaceWorkspace &ws, const double *A, int n, int64_t lda, i
 int invsub_begin(SubspaceWorkspace &ws, const double *A, int n, int64_t lda, int k, double *Vk, int64_t ldv, double *Bk,
                  int64_t ldbk, double blocks_seen, hipStream_t stream, bool identity_start, int *started);
 int invsub_finish(SubspaceWorkspace &ws, hipStream_t stream, int *mults_out, int *converged);
-// Enqueue the preparation of the preconditioned schedule for the step that will start from (.., Bk): `state_stream` is
-// where Bk was last written; the work runs on the workspace's side stream.  No-op once precond_ok is false.
-int invsub_prepare_precond(SubspaceWorkspace &ws, const double *Bk, int64_t ldbk, int k, hipStream_t state_stream);
 
 // ---- small-side recurrence for d >> m: gs_smallside.hip -------------------------------------------
 struct SmallSide {

@@ -1013,14 +1013,6 @@ int gs_ipca_update(gs_ipca_t *h, const float *X, int64_t rows, int64_t ld, void 
     if (rc != GS_OK) return rc;
     stream = cs;
     const double n0 = (double)h->n_seen, m = (double)rows;
-    static const bool eager = gs_knob("GS_FAITHFUL_EAGER") != nullptr;
-    const bool carry = !eager && h->sws.Q != nullptr && h->k <= 128 && n0 >= 4.0 * m;
-    if (carry) {
-        // the state (Vk, Bk) this block starts from is final on `cs`: B0^-1 .. B0^-4 for the preconditioned schedule of
-        // its subspace step are prepared on the workspace's side stream, beside the head of the chain below
-        rc = invsub_prepare_precond(h->sws, h->Bk, h->k, h->k, cs);
-        if (rc != GS_OK) return rc;
-    }
     hipLaunchKernelGGL(faithful_stats_kernel, dim3((unsigned)ceil_div(d, 256)), dim3(256), 0, stream, h->S1,
                        h->shift, h->mean, h->vec, d, dp, n0, m);
     if (n0 > 0)   // T = Bk Vk
@@ -1034,6 +1026,7 @@ int gs_ipca_update(gs_ipca_t *h, const float *X, int64_t rows, int64_t ld, void 
     h->blocks += 1;
     // From the fifth block on the k leading eigenvalues of W sit (n0 / m + 1) times above the rest: carry the
     // invariant subspace by orthogonal iteration and leave the diagonalisation to whoever reads the components.
+    static const bool eager = gs_knob("GS_FAITHFUL_EAGER") != nullptr;
     bool carried = false;
     // the shift of the NEXT block's Gram launch (only needs the mean: ahead of the solver chain)
     hipLaunchKernelGGL(mean_to_shift_kernel, dim3((unsigned)ceil_div(dp, 256)), dim3(256), 0, stream, h->mean,
@@ -1042,7 +1035,7 @@ int gs_ipca_update(gs_ipca_t *h, const float *X, int64_t rows, int64_t ld, void 
         GS_HIP_CHECK(hipEventRecord(h->ev_asm, cs));
         h->asm_live = true;
     }
-    if (carry) {
+    if (!eager && h->sws.Q != nullptr && h->k <= 128 && n0 >= 4.0 * m) {
         // enqueue the step and return: the acceptance test and the emit run on the device, the verdict is read by the next
         // call on this handle (faithful_resolve), behind that call's Gram launch
         int started = 0;

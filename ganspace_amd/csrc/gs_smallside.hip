@@ -897,12 +897,6 @@ int smallside_update(SmallSide &ss, const float *X, int64_t rows, int64_t ldx, d
     const unsigned gd = (unsigned)ceil_div(d, 256);
     hipLaunchKernelGGL(ss_stats_kernel, dim3(gd), dim3(256), 0, stream, bs, mean, vec, d, n0, (double)m);
     hipLaunchKernelGGL(ss_m2_kernel, dim3(gd), dim3(256), 0, stream, ss.colsq, bs, vec, m2, d, n0, (double)m, ss.colsq + d);
-    // (the carried state's B0 = W W^T is the leading k x k block of this block's T: its inverse powers for the preconditioned
-    //  schedule of the subspace step are prepared on the solver's side stream while M is built and contracted)
-    if (ss.w_state && ss.sws.Q != nullptr && k <= 128 && k <= ss.sws.p_cap && n0 >= 4.0 * m) {
-        const int rcp = invsub_prepare_precond(ss.sws, ss.Bk, k, k, stream);
-        if (rcp != GS_OK) return rcp;
-    }
     // 2. M = [S V ; X - bm ; mc ; 0]
     const int npan = rp / kRT;
     hipLaunchKernelGGL(ss_build_kernel, dim3((unsigned)ceil_div(ceil_div(d, 32), kBuildKB), (unsigned)npan), dim3(256), 0,

@@ -523,13 +523,7 @@ void subspace_workspace_free(SubspaceWorkspace &ws) {
     if (ws.pin) (void)hipHostFree(ws.pin);
     ws.pin = nullptr;
     if (ws.inv_event) (void)hipEventDestroy(ws.inv_event);
-    if (ws.side) {
-        (void)hipStreamSynchronize(ws.side);
-        (void)hipStreamDestroy(ws.side);
-    }
-    if (ws.ev_state) (void)hipEventDestroy(ws.ev_state);
-    if (ws.ev_prep) (void)hipEventDestroy(ws.ev_prep);
-    double *ptrs[] = {ws.pool, ws.G, ws.H, ws.B, ws.U, ws.theta, ws.Rm, ws.Dinv, ws.td_scratch, ws.Cpow, ws.Rb, ws.rdiagB};
+    double *ptrs[] = {ws.pool, ws.G, ws.H, ws.B, ws.U, ws.theta, ws.Rm, ws.Dinv, ws.td_scratch};
     for (double *p : ptrs)
         if (p) (void)hipFree(p);
     eigh_workspace_free(ws.ews);

@@ -813,11 +813,7 @@ __global__ __launch_bounds__(1024) void invsub_loewdin2_kernel(double *__restric
 // from block to block; an error relative to lambda_1 would swamp the trailing components of a steep spectrum) - floored at
 // what float64 products resolve, 3e-14 theta_1.  R_ii ~ lambda_i^jj after jj products.
 __global__ __launch_bounds__(128) void invsub_judge_kernel(const double *__restrict__ theta, int pp, int k, int jj_last,
-                                                           double tol_rel, int loewdin, double *__restrict__ verdict,
-                                                           double cond_limit) {
-    // cond_limit (preconditioned schedule): the block the last CholeskyQR step saw must not have been worse conditioned than
-    // the schedule assumed - max / min pivot above the limit (a stale or singular preconditioner) fails the attempt instead
-    // of leaving a basis that is orthonormal only to cond^2 eps.
+                                                           double tol_rel, int loewdin, double *__restrict__ verdict) {
     __shared__ double s_th1[128], s_w2[128], s_rmax[128], s_rmin[128];
     __shared__ int s_bad[128];
     const int t = threadIdx.x;
@@ -851,7 +847,6 @@ __global__ __launch_bounds__(128) void invsub_judge_kernel(const double *__restr
         th1 = s_th1[0];
         bool sane = !s_bad[0] && th1 > 0.0;
         if (loewdin && !(theta[3 * pp + 14] <= 1.5e-4)) sane = false;     // the symmetric correction was not small: O(E^3) > 1e-12
-        if (sane && !(s_rmax[0] <= cond_limit * s_rmin[0])) sane = false;
         double rel = 1e300, ratio1 = 0.0, lamk = 0.0;
         if (sane) {
             const double ej = 1.0 / (double)jj_last;
@@ -889,12 +884,6 @@ int invsub_enqueue_attempt(SubspaceWorkspace &ws, hipStream_t stream) {
         }
         st.jj_last = jl;
     }
-    // Preconditioned schedule (attempt 0, known spectrum): groups of <= j products, each closed by ONE product with B0^-jj
-    // (invsub_prepare_precond) instead of a CholeskyQR step, then a last SINGLE product in front of the one CholeskyQR step -
-    // the rounding of a B0^-jj product (eps cond(B0)^jj, in arbitrary directions) must be damped by a product with A before
-    // the basis is final, and a lone product leaves cond = lambda_1 / lambda_k for that step.
-    const bool pc = st.precond && st.attempt == 0;
-    if (pc) st.jj_last = 1;
     const double e_est = ws.inv_ratio1 > 1.0 ? std::pow(ws.inv_ratio1, 2.0 * st.jj_last) * 1e-16 : 1.0;
     st.pass2 = e_est > 1e-12;
     // second-order symmetric correction while the expected |Q^T Q - I| leaves |E|^3 below 1e-12 (the kernel reports
@@ -918,10 +907,8 @@ int invsub_enqueue_attempt(SubspaceWorkspace &ws, hipStream_t stream) {
             }
         }
         int rem = P;
-        bool prep_joined = false;
         while (rem > 0) {
-            // (preconditioned: the last group is the lone product)
-            const int jj = pc ? (rem == 1 ? 1 : (j < rem - 1 ? j : rem - 1)) : (j < rem ? j : rem);
+            const int jj = j < rem ? j : rem;
             double *cur = st.Qc;
             for (int s2 = 0; s2 < jj; ++s2) {
                 bool clean = false;
@@ -936,22 +923,11 @@ int invsub_enqueue_attempt(SubspaceWorkspace &ws, hipStream_t stream) {
                 ++st.used;
             }
             double *o = ring_take(ws, nullptr);
-            if (pc && rem - jj > 0) {
-                if (!prep_joined && !gs_dry_run()) {
-                    GS_HIP_CHECK(hipStreamWaitEvent(stream, ws.ev_prep, 0));
-                    prep_joined = true;
-                }
-                gemm_f64(n, k, k, cur, ld, 1, ws.Cpow + (size_t)(jj - 1) * ws.pp * ws.pp, ws.pp, 1, o, ld, stream, 1.0, 0.0,
-                         none, false);
-            } else {
-                int rc = orth_fast(ws, cur, o, n, k, stream);   // R diagonal -> theta + 2 pp
-                if (rc != GS_OK) return rc;
-            }
+            int rc = orth_fast(ws, cur, o, n, k, stream);   // R diagonal -> theta + 2 pp
+            if (rc != GS_OK) return rc;
             st.Qc = o;
             rem -= jj;
         }
-        // (whoever prepared a preconditioner reads Bk on the side stream: the emit below must not overtake it)
-        if (ws.precond_ready && !prep_joined && !gs_dry_run()) GS_HIP_CHECK(hipStreamWaitEvent(stream, ws.ev_prep, 0));
         // a second pass when the first one cannot have left the basis orthonormal to ~1e-12 (cond^2 eps)
         if (st.pass2) {
             bool clean = false;
@@ -983,13 +959,13 @@ int invsub_enqueue_attempt(SubspaceWorkspace &ws, hipStream_t stream) {
         GS_LAUNCH(invsub_resid_kernel, dim3((unsigned)k), dim3(256), 0, stream, Yb, Zb, ld, st.Bm, ld, n, ws.theta + ws.pp,
                   ws.theta);
         GS_LAUNCH(invsub_judge_kernel, dim3(1), dim3(128), 0, stream, ws.theta, ws.pp, k, st.jj_last, 1e-9, st.loewdin ? 1 : 0,
-                  verdict, pc ? (st.pass2 ? 1e6 : 300.0) : 1e300);
+                  verdict);
         // optimistic: the new state leaves for the caller's arrays if the device-side test passed
         GS_LAUNCH(invsub_emit_kernel, dim3((unsigned)ceil_div((int)(st.ldv > k ? st.ldv : k), 256), (unsigned)k), dim3(256), 0,
                   stream, st.Qc, ld, n, k, st.Vk, st.ldv, st.Bm, ld, st.Bk, st.ldbk, verdict);
         return GS_OK;
     };
-    const int rcs = run_as_graph(ws.graphs, graph_key({3, st.attempt, P, j, (st.pass2 ? (st.loewdin ? 1 : 2) : 0) + (pc ? 4 : 0), st.identity_start,
+    const int rcs = run_as_graph(ws.graphs, graph_key({3, st.attempt, P, j, st.pass2 ? (st.loewdin ? 1 : 2) : 0, st.identity_start,
                                                        n, k, ws.ring_next, ws.h_next, st.lda, st.ldv, (int64_t)(intptr_t)st.A,
                                                        (int64_t)(intptr_t)st.Vk, (int64_t)(intptr_t)st.Qc}), stream, segment);
     if (rcs != GS_OK) return rcs;
@@ -999,43 +975,6 @@ int invsub_enqueue_attempt(SubspaceWorkspace &ws, hipStream_t stream) {
 }
 
 }  // namespace
-
-int invsub_prepare_precond(SubspaceWorkspace &ws, const double *Bk, int64_t ldbk, int k, hipStream_t state_stream) {
-    ws.precond_ready = false;
-    static const bool off = gs_knob("GS_INVSUB_NO_PRECOND") != nullptr;        // (measurement build: A/B)
-    if (off || !ws.precond_ok || k < 1 || k > kCholP || k > ws.p_cap || ws.inv_ratio1 <= 1.0) return GS_OK;
-    const size_t ppp = (size_t)ws.pp * ws.pp;
-    if (ws.side == nullptr) {
-        if (hipStreamCreateWithFlags(&ws.side, hipStreamNonBlocking) != hipSuccess ||
-            hipEventCreateWithFlags(&ws.ev_state, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&ws.ev_prep, hipEventDisableTiming) != hipSuccess ||
-            hipMalloc((void **)&ws.Cpow, sizeof(double) * 4 * ppp) != hipSuccess ||
-            hipMalloc((void **)&ws.Rb, sizeof(double) * ppp) != hipSuccess ||
-            hipMalloc((void **)&ws.rdiagB, sizeof(double) * ws.pp) != hipSuccess) {
-            (void)hipGetLastError();
-            ws.precond_ok = false;       // (no side stream / memory: the CholeskyQR schedule needs neither)
-            return GS_OK;
-        }
-    }
-    const int64_t ld = ws.pp;
-    GemmEpilogue none;
-    GS_HIP_CHECK(hipEventRecord(ws.ev_state, state_stream));
-    GS_HIP_CHECK(hipStreamWaitEvent(ws.side, ws.ev_state, 0));
-    // B0 = R^T R  ->  R^-1 (upper triangular; a dead pivot leaves a zero row and column: the attempt then fails its
-    // acceptance test and the schedule is switched off);  B0^-1 = R^-1 R^-T, then its powers
-    const int rc = chol_inv_launch(Bk, ldbk, k, ws.Rb, ld, ws.rdiagB, ws.side);
-    if (rc != GS_OK) return rc;
-    double *C1 = ws.Cpow, *C2 = ws.Cpow + ppp, *C3 = ws.Cpow + 2 * ppp, *C4 = ws.Cpow + 3 * ppp;
-    gemm_f64(k, k, k, ws.Rb, ld, 1, ws.Rb, 1, ld, C1, ld, ws.side, 1.0, 0.0, none, false);
-    gemm_f64(k, k, k, C1, ld, 1, C1, ld, 1, C2, ld, ws.side, 1.0, 0.0, none, false);
-    gemm_f64(k, k, k, C2, ld, 1, C1, ld, 1, C3, ld, ws.side, 1.0, 0.0, none, false);
-    gemm_f64(k, k, k, C2, ld, 1, C2, ld, 1, C4, ld, ws.side, 1.0, 0.0, none, false);
-    GS_HIP_CHECK(hipEventRecord(ws.ev_prep, ws.side));
-    GS_HIP_CHECK(hipGetLastError());
-    ws.precond_ready = true;
-    ws.precond_k = k;
-    return GS_OK;
-}
 
 // Schedule and attempt 0 of the invariant-subspace step, enqueued only.  *started = 0 (nothing enqueued): the schedule
 // would cost more than the Rayleigh-Ritz solver.  Otherwise invsub_finish must follow (any time later, before A, Vk or
@@ -1089,9 +1028,6 @@ int invsub_begin(SubspaceWorkspace &ws, const double *A, int n, int64_t lda, int
     st.P0 = P;
     st.j = j;
     st.attempt = 0;
-    // preconditioned schedule: a measured spectrum, a preconditioner prepared for THIS start state, and at least one group
-    // in front of the lone last product
-    st.precond = ws.precond_ok && ws.precond_ready && ws.precond_k == k && ws.inv_ratio1 > 1.0 && P >= 2;
     const int rc = invsub_enqueue_attempt(ws, stream);
     if (rc != GS_OK) return rc;
     st.active = true;
@@ -1111,18 +1047,6 @@ int invsub_finish(SubspaceWorkspace &ws, hipStream_t stream, int *mults_out, int
     for (;;) {
         GS_HIP_CHECK(hipEventSynchronize(ws.inv_event));
         const double accepted = ws.inv_host[0], rel = ws.inv_host[1], ratio1 = ws.inv_host[2], sane = ws.inv_host[5];
-        if (st.precond && st.attempt == 0) {
-            // a preconditioned attempt that is not sane (numerically singular B0, a block worse conditioned than the
-            // schedule assumed) or that misses the residual target three blocks in a row sends this workspace back to the
-            // CholeskyQR schedule for good; this block continues exactly as a missed attempt always did - more products from
-            // the current basis (retries never use the preconditioner), or the caller's Rayleigh-Ritz fall-back
-            if (accepted != 0.0) {
-                ws.precond_miss = 0;
-            } else if (sane == 0.0 || ++ws.precond_miss >= 3) {
-                ws.precond_ok = false;
-                if (debug) fprintf(stderr, "invsub: preconditioned schedule disabled (sane=%.0f rel=%.2e)\n", sane, rel);
-            }
-        }
         if (sane == 0.0) break;
         ws.inv_ratio1 = ratio1;
         if (debug)
@@ -1152,7 +1076,6 @@ int invsub_finish(SubspaceWorkspace &ws, hipStream_t stream, int *mults_out, int
         }
     }
     if (!*converged) ws.inv_plan = 0;
-    ws.precond_ready = false;        // (prepared for the state this step started from)
     ws.inv_last_products = st.used;
     if (mults_out) *mults_out = st.used;
     st.active = false;
