@@ -13,14 +13,19 @@
 #   py:<script>[:args...]                   python tools/<script> args (':'-separated)        -> <script>.log
 #   pyprof:<script>[:args...]               the same under rocprofv3 --kernel-trace --stats    -> <script>_kernel_stats.csv
 #   pmc:<counters '+'-joined>:<script>[:args...]   one rocprofv3 --pmc pass (never combined with other tracing domains)
+#   timeline                                rocprofv3 --kernel-trace of `bench.py --no-extras` -> job_timeline.md (tools/job_timeline.py)
+#   grampmc[:rows]                          FETCH_SIZE / WRITE_SIZE / SQ / LDS --pmc passes on tools/gram_probe.py (separate passes)
+#                                           -> rocprof_summary.md + gram_pmc_latest.json (tools/summarize_profiles.py)
 #   measure                                 export GANSPACE_HIP_LIB=lib_measure for the following steps
 set -u
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp && cd "$R"
 TAG=$1; shift
 O=gpurun_out/$TAG; mkdir -p "$O"
-stats() {   # <trace dir> <out csv>: copy the kernel-stats table of a rocprofv3 --stats run
+stats() {   # <trace dir> <out csv>: keep the kernel-stats table of a rocprofv3 --stats run, drop the raw trace (gpurun merges
+            # at most 64 MiB back: a kernel trace of the bench run alone is larger)
   f=$(find "$1" -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp "$f" "$2" && head -25 "$2"
+  rm -rf "$1"
 }
 for step in "$@"; do
   IFS=':' read -r kind a1 rest <<< "$step"
@@ -49,7 +54,22 @@ for step in "$@"; do
     pmc)
       IFS=':' read -r script args <<< "$rest"
       timeout 1500 rocprofv3 --pmc ${a1//+/ } --kernel-trace --output-format csv -d "$O/pmc_${a1%%+*}" -o p -- python tools/$script ${args//:/ } > /dev/null 2>&1
-      python tools/pmc_table.py "$O/pmc_${a1%%+*}" | tee "$O/pmc_${a1%%+*}.txt" ;;
+      python tools/pmc_table.py "$O/pmc_${a1%%+*}" | tee "$O/pmc_${a1%%+*}.txt"; rm -rf "$O/pmc_${a1%%+*}" ;;
+    timeline)
+      timeout 1500 rocprofv3 --kernel-trace --output-format csv -d "$O/timeline" -o t -- python bench.py --no-extras > "$O/timeline_bench.json" 2> /dev/null
+      python tools/job_timeline.py "$O/timeline" > "$O/job_timeline.md"; cat "$O/job_timeline.md"; rm -rf "$O/timeline" ;;
+    grampmc)
+      ROWS=${a1:-131072}; export GS_PROBE_ROWS=$ROWS
+      [ -f "$O/benchprof_kernel_stats.csv" ] && mkdir -p "$O/bench_trace" && cp "$O/benchprof_kernel_stats.csv" "$O/bench_trace/b_kernel_stats.csv"
+      for c in FETCH_SIZE WRITE_SIZE; do
+        timeout 900 rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$O/pmc_$c" -o p -- python tools/gram_probe.py $ROWS > /dev/null 2>&1
+      done
+      timeout 900 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d "$O/pmc_sq" -o p -- python tools/gram_probe.py $ROWS > /dev/null 2>&1
+      timeout 900 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU --kernel-trace --output-format csv -d "$O/pmc_lds" -o p -- python tools/gram_probe.py $ROWS > /dev/null 2>&1
+      cp profiles/gram_pmc_latest.json "$O/gram_pmc_before.json" 2>/dev/null
+      python tools/summarize_profiles.py "$O" "profiles/${TAG}_rocprof_summary.md" > "$O/rocprof_summary.md"
+      cp profiles/gram_pmc_latest.json "$O/gram_pmc_latest.json"; cat "$O/rocprof_summary.md"
+      rm -rf "$O"/pmc_FETCH_SIZE "$O"/pmc_WRITE_SIZE "$O"/pmc_sq "$O"/pmc_lds "$O"/bench_trace ;;
     measure) export GANSPACE_HIP_LIB="$R/ganspace_amd/lib_measure/libganspace_hip.so" ;;
     *) echo "unknown step $step" ;;
   esac
