@@ -415,13 +415,20 @@ template <int R>
 __global__ __launch_bounds__(512, 1) void linear_act_fast_kernel(
     const float *__restrict__ X, const float *__restrict__ Wt, const float *__restrict__ bias,
     float *__restrict__ Y, int64_t M, int N, int K, int64_t ldx, int64_t ldy, float wscale, float bscale,
-    float slope, float gain, int act) {
+    float slope, float gain, int act, int64_t total_tiles, int64_t xcd_per) {
     constexpr int TM = 32 * R;
     __shared__ __attribute__((aligned(16))) float lds[2][TM + kLT][kFP];  // [buffer][x rows | W rows][k]
     const int ntn = N / kLT;
-    const int bid = blockIdx.x;
-    const int64_t m0 = (int64_t)(bid / ntn) * TM;
-    const int n0 = (bid % ntn) * kLT;
+    // block b runs on XCD b % 8: tile v = (b % 8) * per + b / 8 gives every XCD a contiguous range of tiles, so the ntn column
+    // tiles of a row tile - the same x rows - are fetched through ONE L2 instead of up to ntn of them (`xcd` = 0: the plain
+    // order of rounds 1-5; a launch that is not longer than one round per XCD keeps it)
+    int64_t bid = blockIdx.x;
+    if (xcd_per > 0) {
+        bid = (int64_t)(blockIdx.x & 7) * xcd_per + (blockIdx.x >> 3);
+        if (bid >= total_tiles) return;
+    }
+    const int64_t m0 = (bid / ntn) * TM;
+    const int n0 = (int)(bid % ntn) * kLT;
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(X), 0,
                                                                         (unsigned)((uint64_t)M * ldx * 4u), 0x00020000);
@@ -483,10 +490,15 @@ static int launch_linear(const float *x, const float *W, const float *b, float *
             const int r = atoi(forced);
             if (r >= 2 && r <= 6) best = r;
         }
-        const unsigned grid = (unsigned)(ceil_div(M, (int64_t)32 * best) * ntn);
+        const int64_t total = ceil_div(M, (int64_t)32 * best) * ntn;
+        // XCD-contiguous tile order for launches of more than two rounds of the chip (measurement build: GS_LINEAR_XCD=0/1)
+        bool xcd = total > 1024;
+        if (const char *fx = gs_knob("GS_LINEAR_XCD")) xcd = fx[0] == '1';
+        const int64_t per = xcd ? ceil_div(total, 8) : 0;
+        const unsigned grid = (unsigned)(xcd ? per * 8 : total);
 #define GS_LAUNCH_FAST(RR)                                                                                         \
     hipLaunchKernelGGL((linear_act_fast_kernel<RR>), dim3(grid), dim3(512), 0, stream, x, W, b, y, M, N, K, (int64_t)K, \
-                       (int64_t)N, wscale, bscale, slope, gain, act)
+                       (int64_t)N, wscale, bscale, slope, gain, act, total, per)
         switch (best) {
             case 2: GS_LAUNCH_FAST(2); break;
             case 3: GS_LAUNCH_FAST(3); break;
