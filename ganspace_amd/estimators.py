@@ -304,6 +304,11 @@ class IPCAEstimator:
         self.transformer.fit(X)
 
     def fit_partial(self, X, resident=False):
+        """One block (reference estimators.py:68-76).  Contract for device tensors: the rows are READ ONLY and are read in
+        stream order before this call's work on the current stream ends - ``decomposition._fit_blocks`` relies on it when it
+        hands over slices of the hooked activation or of the resident latent array instead of a copy.  ``resident=True``
+        (rows that stay valid and unchanged until the results are read; the exact mode may then defer and merge their
+        contraction) must therefore never be combined with memory the caller is about to reuse."""
         try:
             self.transformer.partial_fit(X, resident=resident)
             return True

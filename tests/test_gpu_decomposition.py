@@ -84,6 +84,44 @@ def test_z_space_regression_path(dev, tmp_path):
     inst.close()
 
 
+def test_grouped_generator_calls_give_the_blocks_of_the_mini_batch_loop(dev, monkeypatch):
+    """``_fit_blocks`` pushes several mini-batches of a narrow layer through one ``partial_forward`` (cfg4: 8 x 10 000
+    rows, ``_forward_rows``) and hands the estimator slices of the hooked activation.  The blocks must be the ones the
+    reference's mini-batch loop builds (decomposition.py:245-261: block gi = rows gi .. gi + NB - 1 of the latents, the
+    tail mini-batch kept in part): with the faithful estimator - sequential in the blocks, every block its own solve - the
+    grouped loop and the one-mini-batch-per-call loop must agree bit for bit, ragged B / NB included."""
+    from ganspace_amd import decomposition as dec
+    from ganspace_amd.estimators import get_estimator
+    from ganspace_amd.wrappers import get_instrumented_model
+    inst = get_instrumented_model("StyleGAN2", "car", "style", dev)
+    model = inst.model
+    inst.retain_layer("style")
+    k, n, B = 12, 30_000, 768                      # NB = 2000: mini-batches of 768 straddle the block boundaries
+    plan = dec._Plan.make(n, B, k)
+    assert plan.NB == 2000 and plan.NB % plan.B != 0
+    torch.manual_seed(dec.SEED_SAMPLING)
+    np.random.seed(dec.SEED_SAMPLING)
+    latents, _ = dec._presample(model, plan, model.get_latent_shape(), dev)
+    results = []
+    for rows_per_call in (dec.FORWARD_ROWS, B):    # grouped (81 920-row cap: all 15 blocks in one call) / one mini-batch
+        monkeypatch.setattr(dec, "FORWARD_ROWS", rows_per_call)
+        est = get_estimator("ipca", k, 1.0)
+        last = dec._fit_blocks(est, inst, latents, plan, "style", 512, False, dev)
+        comp, stdev, ratio = est.get_components()
+        results.append((np.array(comp), np.array(stdev), np.array(est.transformer.mean_), last.clone()))
+        assert int(est.transformer.n_samples_seen_) == len(list(plan.block_starts)) * plan.NB
+    (c0, s0, m0, l0), (c1, s1, m1, l1) = results
+    np.testing.assert_array_equal(c0, c1)
+    np.testing.assert_array_equal(s0, s1)
+    np.testing.assert_array_equal(m0, m1)
+    assert torch.equal(l0, l1)                     # the rows the random-direction statistic reads (last block)
+    # ... and they are the mapping network's rows of latents[gi : gi + NB]
+    with torch.no_grad():
+        ref = model.model.style(latents[plan.block_starts[-1]:plan.block_starts[-1] + plan.NB])
+    assert torch.equal(ref, l0)
+    inst.close()
+
+
 def test_partial_forward_equals_forward_prefix(dev):
     """Spec of the reference's tests/partial_forward_test.py:112-121: the feature retained after
     ``partial_forward(z, layer)`` equals the one retained after a full ``forward(z)``."""
