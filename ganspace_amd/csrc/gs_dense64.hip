@@ -258,11 +258,18 @@ __device__ __forceinline__ void chol_leaf16(double *__restrict__ Hs, double *__r
     const int c = lane & 15;
     const bool aug = (lane & 16) != 0;
     double col[16];
+    // (unconditional LDS reads, selected afterwards: with the test around the read every element became its own exec-mask
+    //  region - read, wait, select - and the 16 reads took 1 400 clk, as long as six pivots; round 6)
+    {
+        double hv[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        double v = (r == c) ? 1.0 : 0.0;
-        if (!aug) v = (r <= c) ? Hs[(j0 + r) * kCiLd + j0 + c] : 0.0;
-        col[r] = v;
+        for (int r = 0; r < 16; ++r) hv[r] = Hs[(j0 + r) * kCiLd + j0 + c];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const double ident = (r == c) ? 1.0 : 0.0;
+            const double blk = (r <= c) ? hv[r] : 0.0;
+            col[r] = aug ? ident : blk;
+        }
     }
     const double ref = refd[j0 + c] * 1e-13;
     unsigned dead_mask = 0;
@@ -314,17 +321,35 @@ __device__ __forceinline__ void chol_leaf16(double *__restrict__ Hs, double *__r
     // pivots): lanes 0-15 store their whole column into the block - the sub-diagonal garbage is overwritten when the kernel
     // copies R_JJ^-T (Es) into the block's lower triangle after the next barrier -, lanes 16-31 store column c of R_JJ^-T
     // into Es (zeros above the diagonal and in dead rows / columns).
-    const bool dead_c = (dead_mask >> c) & 1u;
-    if (lane < 32) {
-        double *base = aug ? Es + c : Hs + j0 * kCiLd + j0 + c;
-        const int stride = aug ? 17 : kCiLd;
+    // (values selected first, without short-circuit evaluation - `dead_r` is wave-uniform and each `||` became a scalar
+    //  branch around its store: 30 exec-mask regions, 2 400 clk for 16 stores -, then ONE predicated region of plain stores)
+    double *base = aug ? Es + c : Hs + j0 * kCiLd + j0 + c;
+    const int stride = aug ? 17 : kCiLd;
+    double diag = 0.0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) diag = (r == c) ? col[r] : diag;
+    if (dead_mask == 0) {
+        // no dead pivot in this block (wave-uniform, the normal case): the identity half is lower triangular by
+        // construction (rows above the diagonal were never touched), so every lane stores its column as it is
+        if (lane < 32) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) base[r * stride] = col[r];
+            if (!aug) rd[j0 + c] = diag;
+        }
+    } else {
+        const bool dead_c = (dead_mask >> c) & 1u;
+        double out[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const bool dead_r = (dead_mask >> r) & 1u;
-            const bool zero = aug && (r < c || dead_r || dead_c);
-            base[r * stride] = zero ? 0.0 : col[r];
+            const bool zero = aug & ((r < c) | dead_r | dead_c);
+            out[r] = zero ? 0.0 : col[r];
         }
-        if (!aug) rd[j0 + c] = dead_c ? 0.0 : col[c];
+        if (lane < 32) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) base[r * stride] = out[r];
+            if (!aug) rd[j0 + c] = dead_c ? 0.0 : diag;
+        }
     }
     if (STAMP) stamps[3] = clock64();
 }
@@ -362,9 +387,9 @@ __global__ __launch_bounds__(512) void chol_inv_kernel(const double *__restrict_
 #pragma unroll
         for (int q = 0; q < 32; ++q) {
             const int i = i0 + 4 * q;
-            double v = (i <= j && j < p) ? hv[q] : 0.0;
-            v = (i == j && j >= p) ? 1.0 : v;
-            if (i < pend && j < pend) Hs[i * kCiLd + j] = v;
+            double v = ((i <= j) & (j < p)) ? hv[q] : 0.0;
+            v = ((i == j) & (j >= p)) ? 1.0 : v;
+            Hs[i * kCiLd + j] = v;              // (every (i, j) < 128 is a cell of the image: no predicate, no exec-mask region)
         }
     }
     __syncthreads();
@@ -478,10 +503,13 @@ __global__ __launch_bounds__(512) void chol_inv_kernel(const double *__restrict_
     // ---- R^-1 = (R^-T)^T ----
     {
         const int j = tid & 127, i0 = tid >> 7;
+        const int nq = (p + 3) >> 2;                      // rows i0 + 4 q < p
 #pragma unroll 4
-        for (int q = 0; q < 32; ++q) {
+        for (int q = 0; q < nq; ++q) {
             const int i = i0 + 4 * q;
-            if (i < p && j < p) Rinv[(int64_t)i * ldr + j] = (i < j) ? Hs[j * kCiLd + i] : (i == j ? ed[i] : 0.0);
+            const double up = Hs[j * kCiLd + i], dg = ed[i];          // (unconditional LDS reads, selected afterwards)
+            const double v = (i < j) ? up : (i == j ? dg : 0.0);
+            if ((i < p) & (j < p)) Rinv[(int64_t)i * ldr + j] = v;
         }
     }
     if (tid < p) rdiag[tid] = rd[tid];
