@@ -103,6 +103,12 @@ class BaseModel(AbstractBaseClass, nn.Module):
     def named_modules(self, *args, **kwargs):
         return self.model.named_modules(*args, **kwargs)
 
+    def cheap_prefix(self, layer_name):
+        """True when ``partial_forward(x, layer_name)`` evaluates nothing wider than the hooked activation itself, so that
+        the discovery loop may push several mini-batches through one call (``decomposition._forward_rows``).  Not part of
+        the reference surface; the default keeps the configured mini-batch."""
+        return False
+
 
 # =================================================================================================
 # synthetic StyleGAN2 generator
@@ -466,6 +472,10 @@ class StyleGAN2(BaseModel):
 
     def get_max_latents(self):
         return self.model.n_latent
+
+    def cheap_prefix(self, layer_name):
+        # partial_forward returns right behind the mapping network for every layer whose name contains 'style'
+        return "style" in layer_name
 
     def set_output_class(self, new_class):
         if self.outclass != new_class:

@@ -281,6 +281,16 @@ def test_forward_rows_groups_narrow_layers_only():
     for B, d in [(1, 4), (20, 8192), (333, 37), (4096, 2048)]:
         r = fr(B, d)
         assert r >= B and r % B == 0
+    # a model has to vouch for the layer: BigGAN's 128-wide `embeddings` hook sits in front of the 32 768-wide gen_z that
+    # partial_forward evaluates too - 80 000 rows of it would be a 10 GB temporary
+    from types import SimpleNamespace
+    from ganspace_amd.wrappers import BaseModel, StyleGAN2
+    assert fr(2000, 128, SimpleNamespace(cheap_prefix=lambda name: False), "embeddings") == 2000
+    assert fr(2000, 128, SimpleNamespace(), "embeddings") == 2000
+    assert fr(10_000, 512, SimpleNamespace(cheap_prefix=lambda name: "style" in name), "style") == 80_000
+    assert BaseModel.cheap_prefix(None, "anything") is False
+    assert StyleGAN2.cheap_prefix(None, "style") and StyleGAN2.cheap_prefix(None, "strided_style")
+    assert not StyleGAN2.cheap_prefix(None, "convs.2")
 
 
 @pytest.mark.parametrize("k,demod,up", [(3, True, False), (3, True, True), (1, False, False)])
