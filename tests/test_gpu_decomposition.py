@@ -88,8 +88,10 @@ def test_grouped_generator_calls_give_the_blocks_of_the_mini_batch_loop(dev, mon
     """``_fit_blocks`` pushes several mini-batches of a narrow layer through one ``partial_forward`` (cfg4: 8 x 10 000
     rows, ``_forward_rows``) and hands the estimator slices of the hooked activation.  The blocks must be the ones the
     reference's mini-batch loop builds (decomposition.py:245-261: block gi = rows gi .. gi + NB - 1 of the latents, the
-    tail mini-batch kept in part): with the faithful estimator - sequential in the blocks, every block its own solve - the
-    grouped loop and the one-mini-batch-per-call loop must agree bit for bit, ragged B / NB included."""
+    tail mini-batch kept in part): the last block's rows must be bit-identical between the grouped loop and the
+    one-mini-batch-per-call loop (ragged B / NB included), and the faithful estimator - sequential in the blocks, every
+    block its own solve - must end in the same state up to the order of its float64 atomic additions (split-K products:
+    components to the last float32 bit or one beside it)."""
     from ganspace_amd import decomposition as dec
     from ganspace_amd.estimators import get_estimator
     from ganspace_amd.wrappers import get_instrumented_model
@@ -111,10 +113,11 @@ def test_grouped_generator_calls_give_the_blocks_of_the_mini_batch_loop(dev, mon
         results.append((np.array(comp), np.array(stdev), np.array(est.transformer.mean_), last.clone()))
         assert int(est.transformer.n_samples_seen_) == len(list(plan.block_starts)) * plan.NB
     (c0, s0, m0, l0), (c1, s1, m1, l1) = results
-    np.testing.assert_array_equal(c0, c1)
-    np.testing.assert_array_equal(s0, s1)
-    np.testing.assert_array_equal(m0, m1)
-    assert torch.equal(l0, l1)                     # the rows the random-direction statistic reads (last block)
+    assert torch.equal(l0, l1)                     # the rows the random-direction statistic reads (last block): bit for bit
+    np.testing.assert_allclose(c0, c1, rtol=0, atol=2e-8)
+    assert O.signed_cosines(c0, c1).min() > 1 - 1e-12
+    np.testing.assert_allclose(s0, s1, rtol=1e-9)
+    np.testing.assert_allclose(m0, m1, rtol=0, atol=1e-12 * max(1.0, float(np.abs(m1).max())))
     # ... and they are the mapping network's rows of latents[gi : gi + NB]
     with torch.no_grad():
         ref = model.model.style(latents[plan.block_starts[-1]:plan.block_starts[-1] + plan.NB])
