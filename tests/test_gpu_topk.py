@@ -165,7 +165,11 @@ def test_eigh_topk_white_noise_falls_back(dev):
                                          (512, 96, 96, False, False), (2081, 80, 2081, False, False),
                                          (80, 80, 2081, True, False), (80, 512, 80, False, False),
                                          (33, 17, 5, False, True), (1, 1, 1, False, False), (100, 260, 37, True, True),
-                                         (2100, 2100, 64, False, True), (130, 131, 4100, True, False)])
+                                         (2100, 2100, 64, False, True), (130, 131, 4100, True, False),
+                                         # tall-skinny products (the small side's T Q shape class): ragged rows / columns / K,
+                                         # transposed operands
+                                         (2050, 37, 1030, True, True), (2081, 128, 2081, False, False),
+                                         (4100, 17, 1100, False, True), (2049, 113, 1025, True, False)])
 def test_gemm_f64_mfma_matches_numpy(dev, M, N, K, ta, tb):
     """The f64 matrix-pipe product (`mm64_kernel`, v_mfma_f64_16x16x4_f64) of the solver chains, every operand layout
     (strided views: no transposed copies), ragged shapes, both tile arrangements and the split-K path."""
