@@ -269,11 +269,13 @@ struct InvsubPending {
 struct SubspaceWorkspace {
     int n_cap = 0, p_cap = 0, pp = 0;
     InvsubPending inv;
-    double *inv_host = nullptr;    // [8] pinned: verdict of the attempt in flight (invsub_judge_kernel)
+    double *inv_host = nullptr;    // [8] pinned: verdict of the attempt in flight (invsub_resid_judge_kernel)
+    double *inv_host_dev = nullptr;   // the same slot as the device sees it (the kernel writes the verdict there itself)
     hipEvent_t inv_event = nullptr;
     // projection step of eigh_topk_cheb: tridiagonalisation + bisection (gs_tridiag.hip) unless that solver reported
     // clustered Ritz values on this workspace - then one-sided Jacobi from there on
     double *td_scratch = nullptr;  // [(128 + 3) * 128] reflectors, diagonal, off-diagonal, taus
+    double *pin_dev = nullptr;     // device view of `pin`: the kernels that produce those values write them there themselves
     double *pin = nullptr;         // [p_cap + 32] PINNED host scratch: what the solver reads back between its segments
                                    // (a copy into pageable memory is a staged, synchronous transfer: ~40 us each)
     bool rr_force_jacobi = false;

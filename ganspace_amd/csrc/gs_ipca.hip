@@ -122,26 +122,36 @@ __global__ void exact_assemble_kernel(const double *__restrict__ G, const double
 // vec[0..dp)   bm' = S1/m          (block mean relative to the shift)
 // vec[dp..2dp) mc  = sqrt(n0/n1*m) * (mean_old - bm)
 // vec[2dp..)   delta = bm - mean_old
-__global__ void faithful_stats_kernel(const double *__restrict__ S1, const float *__restrict__ shift,
+// The shift of the NEXT block's Gram launch - the new running mean in float32 - is written here as well (round 6: one
+// launch less per block; it was `mean_to_shift_kernel` behind the assembly): nothing else in the block's chain reads `shift`
+// (the assembly works from vec), and the next Gram launch waits for ev_asm, which is recorded behind the assembly as before.
+__global__ void faithful_stats_kernel(const double *__restrict__ S1, float *__restrict__ shift,
                                       double *__restrict__ mean, double *__restrict__ vec, int d, int dp,
                                       double n0, double m) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= d) return;
+    if (i >= dp) return;
+    if (i >= d) {
+        shift[i] = 0.f;
+        return;
+    }
     const double n1 = n0 + m;
     const double bmp = S1[i] / m;
     const double bm = (double)shift[i] + bmp;
     vec[i] = bmp;
+    double mu_new;
     if (n0 > 0) {
         const double mu = mean[i];
         const double delta = bm - mu;
         vec[dp + i] = sqrt(n0 / n1 * m) * (mu - bm);
         vec[2 * dp + i] = delta;
-        mean[i] = mu + delta * (m / n1);
+        mu_new = mu + delta * (m / n1);
     } else {
         vec[dp + i] = 0;
         vec[2 * dp + i] = 0;
-        mean[i] = bm;
+        mu_new = bm;
     }
+    mean[i] = mu_new;
+    shift[i] = (float)mu_new;
 }
 
 // T = Bk Vk (k x dp); the old-state term Vk^T Bk Vk is evaluated as sum_t T[t][lo] Vk[t][hi] with lo <= hi so that W
@@ -1013,7 +1023,7 @@ int gs_ipca_update(gs_ipca_t *h, const float *X, int64_t rows, int64_t ld, void 
     if (rc != GS_OK) return rc;
     stream = cs;
     const double n0 = (double)h->n_seen, m = (double)rows;
-    hipLaunchKernelGGL(faithful_stats_kernel, dim3((unsigned)ceil_div(d, 256)), dim3(256), 0, stream, h->S1,
+    hipLaunchKernelGGL(faithful_stats_kernel, dim3((unsigned)ceil_div(dp, 256)), dim3(256), 0, stream, h->S1,
                        h->shift, h->mean, h->vec, d, dp, n0, m);
     if (n0 > 0)   // T = Bk Vk
         gemm_f64(h->k, dp, h->k, h->Bk, h->k, 1, h->Vk, dp, 1, h->T, dp, stream, 1.0, 0.0, GemmEpilogue(), false);
@@ -1028,9 +1038,7 @@ int gs_ipca_update(gs_ipca_t *h, const float *X, int64_t rows, int64_t ld, void 
     // invariant subspace by orthogonal iteration and leave the diagonalisation to whoever reads the components.
     static const bool eager = gs_knob("GS_FAITHFUL_EAGER") != nullptr;
     bool carried = false;
-    // the shift of the NEXT block's Gram launch (only needs the mean: ahead of the solver chain)
-    hipLaunchKernelGGL(mean_to_shift_kernel, dim3((unsigned)ceil_div(dp, 256)), dim3(256), 0, stream, h->mean,
-                       h->shift, d, dp);
+    // (the shift of the NEXT block's Gram launch was written by faithful_stats_kernel)
     if (cs != user) {
         GS_HIP_CHECK(hipEventRecord(h->ev_asm, cs));
         h->asm_live = true;

@@ -505,6 +505,13 @@ int subspace_workspace_alloc(SubspaceWorkspace &ws, int n, int p) {
         (void)hipGetLastError();
         ws.pin = nullptr;              // (the readers fall back to pageable buffers)
     }
+    if (ws.pin != nullptr) {
+        void *dv = nullptr;
+        if (hipHostGetDevicePointer(&dv, ws.pin, 0) == hipSuccess) ws.pin_dev = static_cast<double *>(dv);
+        else (void)hipGetLastError();
+    }
+    // (ticket counters of the last-block kernels live in theta's tail: 3 pp + 24, + 25)
+    if (rc == GS_OK && hipMemset(ws.theta + 3 * (size_t)ws.pp + 24, 0, sizeof(double) * 2) != hipSuccess) rc = GS_EHIP;
     if (rc == GS_OK && hipMemset(ws.Rm, 0, sizeof(double) * ppp) != hipSuccess) rc = GS_EHIP;
     if (rc == GS_OK) rc = eigh_workspace_alloc(ws.ews, ws.pp + 2);
     if (rc == GS_OK) rc = topk_prepare_kernels();

@@ -511,7 +511,8 @@ __global__ __launch_bounds__(64 * LP) void jacobi_lds_kernel(const double *__res
 // With dead pivots (the basis already spans the numerical range of A) or a degenerate edge the coefficients
 // fall back to plain scaled products {1/lambda_1, 0, 0}.
 __global__ __launch_bounds__(64) void cheb_setup_kernel(const double *__restrict__ rdiag, int p, int k, int j,
-                                                        double *__restrict__ stats, double *__restrict__ coef) {
+                                                        double *__restrict__ stats, double *__restrict__ coef,
+                                                        double *__restrict__ stats_host) {
     const int lane = threadIdx.x;
     double mx = 0.0, mn = 1e300, last = 0.0;
     int dead = 0, last_idx = -1;
@@ -552,6 +553,12 @@ __global__ __launch_bounds__(64) void cheb_setup_kernel(const double *__restrict
         stats[5] = (double)dead;
         stats[6] = lam1;
         stats[7] = b;
+        if (stats_host) {       // (round 6: the planning step reads them from pinned memory - no copy behind this kernel)
+            const double hv[8] = {r1, rk, last, mx, mn, (double)dead, lam1, b};
+#pragma unroll
+            for (int i = 0; i < 8; ++i) stats_host[i] = hv[i];
+            __threadfence_system();
+        }
         const bool cheb = (dead == 0) && (b > 1e-12 * lam1) && (lam1 > 0.0);
         if (cheb) {
             coef[0] = 2.0 / b;
@@ -572,11 +579,16 @@ __global__ __launch_bounds__(64) void cheb_setup_kernel(const double *__restrict
     }
 }
 
-// resid[i] = || YU_i - theta_i Z_i ||^2 for i < k
+// resid[i] = || YU_i - theta_i Z_i ||^2 for i < k.  Round 6: the block that arrives last at the ticket counter copies what
+// the host decides on - the k residuals, theta_1, the projection step's two status words - into the workspace's pinned
+// buffer (`pub`, device view; layout host[0 .. k) | host[k] | two ints at host + k + 2): three 8 .. 640-byte device-to-host
+// copies per attempt were three dependent operations of the solve's tail.
 __global__ __launch_bounds__(256) void topk_resid_kernel(const double *__restrict__ YU, const double *__restrict__ Zv,
                                                          int64_t ld, const double *__restrict__ theta, int n, int k,
-                                                         double *__restrict__ resid) {
+                                                         double *__restrict__ resid, double *__restrict__ pub,
+                                                         const int *__restrict__ jinfo, unsigned *__restrict__ ticket) {
     __shared__ double scr[256];
+    __shared__ unsigned s_last;
     const int i = blockIdx.x;
     double s = 0;
     const double th = theta[i];
@@ -591,6 +603,23 @@ __global__ __launch_bounds__(256) void topk_resid_kernel(const double *__restric
         __syncthreads();
     }
     if (threadIdx.x == 0) resid[i] = scr[0];
+    if (pub == nullptr) return;
+    if (threadIdx.x == 0) {
+        __threadfence();
+        s_last = atomicAdd(ticket, 1u);
+    }
+    __syncthreads();
+    if (s_last != (unsigned)(k - 1)) return;
+    __threadfence();
+    for (int e = threadIdx.x; e < k; e += 256) pub[e] = resid[e];
+    if (threadIdx.x == 0) {
+        pub[k] = theta[0];
+        int *jp = reinterpret_cast<int *>(pub + k + 2);
+        jp[0] = jinfo[0];
+        jp[1] = jinfo[1];
+        *ticket = 0u;
+    }
+    __threadfence_system();
 }
 
 __global__ void topk_emit_kernel(const double *__restrict__ V, int64_t ld, const double *__restrict__ theta, int n,
@@ -865,6 +894,91 @@ __global__ __launch_bounds__(128) void invsub_judge_kernel(const double *__restr
     }
 }
 
+// invsub_resid_kernel + invsub_judge_kernel in ONE launch (round 6: two dependent launches less per block - the separate
+// verdict kernel and the 64-byte device-to-host copy behind it): block c computes the squared residual of column c, the
+// block that arrives last at the ticket counter (release / acquire through agent-scope fences) evaluates the acceptance
+// test over all columns and writes the verdict to device memory (the emit kernel's predicate) AND straight into the
+// handle's pinned host slot (`verdict_host`, device-visible: the host reads it behind the event of the next launch).
+__global__ __launch_bounds__(256) void invsub_resid_judge_kernel(const double *__restrict__ Y, const double *__restrict__ Z,
+                                                                 int64_t ld, const double *__restrict__ B, int64_t ldb, int n,
+                                                                 double *__restrict__ theta, int pp, int k, int jj_last,
+                                                                 double tol_rel, int loewdin, double *__restrict__ verdict,
+                                                                 double *__restrict__ verdict_host,
+                                                                 unsigned *__restrict__ ticket) {
+    __shared__ double scr[256], s_th1[256], s_w2[256], s_rmax[256], s_rmin[256];
+    __shared__ int s_bad[256];
+    __shared__ unsigned s_last;
+    const int c = blockIdx.x, t = threadIdx.x;
+    double s = 0;
+    for (int r = t; r < n; r += 256) {
+        const double v = Y[(int64_t)r * ld + c] - Z[(int64_t)r * ld + c];
+        s += v * v;
+    }
+    scr[t] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (t < o) scr[t] += scr[t + o];
+        __syncthreads();
+    }
+    if (t == 0) {
+        theta[pp + c] = scr[0];
+        theta[c] = B[(int64_t)c * ldb + c];
+        __threadfence();                                       // (release: the two stores before the ticket)
+        s_last = atomicAdd(ticket, 1u);
+    }
+    __syncthreads();
+    if (s_last != (unsigned)(k - 1)) return;
+    __threadfence();                                           // (acquire: every other block's stores are visible)
+    double th1 = 0.0, w2 = 0.0, rmax = 0.0, rmin = 1e300;
+    int bad = 0;
+    for (int i = t; i < k; i += 256) {
+        const double bd = theta[i], rs = theta[pp + i], rd = theta[2 * pp + i];
+        if (!(rs == rs) || !(rd > 0.0)) bad = 1;          // NaN, or a dead pivot (rank lost)
+        th1 = bd > th1 ? bd : th1;
+        w2 = rs > w2 ? rs : w2;
+        rmax = rd > rmax ? rd : rmax;
+        rmin = rd < rmin ? rd : rmin;
+    }
+    s_th1[t] = th1;
+    s_w2[t] = w2;
+    s_rmax[t] = rmax;
+    s_rmin[t] = rmin;
+    s_bad[t] = bad;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (t < o) {
+            s_th1[t] = fmax(s_th1[t], s_th1[t + o]);
+            s_w2[t] = fmax(s_w2[t], s_w2[t + o]);
+            s_rmax[t] = fmax(s_rmax[t], s_rmax[t + o]);
+            s_rmin[t] = fmin(s_rmin[t], s_rmin[t + o]);
+            s_bad[t] |= s_bad[t + o];
+        }
+        __syncthreads();
+    }
+    if (t == 0) {
+        th1 = s_th1[0];
+        bool sane = !s_bad[0] && th1 > 0.0;
+        if (loewdin && !(theta[3 * pp + 14] <= 1.5e-4)) sane = false;     // the symmetric correction was not small: O(E^3) > 1e-12
+        double rel = 1e300, ratio1 = 0.0, lamk = 0.0;
+        if (sane) {
+            const double ej = 1.0 / (double)jj_last;
+            lamk = pow(s_rmin[0], ej);
+            ratio1 = pow(s_rmax[0] / s_rmin[0], ej);
+            double target = tol_rel * lamk;
+            if (target < 3e-14 * th1) target = 3e-14 * th1;
+            rel = sqrt(s_w2[0]) / target;
+        }
+        const double out[8] = {(sane && rel <= 1.0) ? 1.0 : 0.0, rel, ratio1, lamk, th1, sane ? 1.0 : 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            verdict[i] = out[i];
+            if (verdict_host) verdict_host[i] = out[i];
+        }
+        *ticket = 0u;                                          // (the next step's blocks start counting from zero)
+        __threadfence_system();
+    }
+}
+
 namespace {
 
 // one attempt of the iteration, enqueued: products / CholeskyQR steps / Rayleigh quotient / residuals / device-side
@@ -956,10 +1070,10 @@ int invsub_enqueue_attempt(SubspaceWorkspace &ws, hipStream_t stream) {
         ++st.used;
         gemm_f64(k, k, n, st.Qc, 1, ld, Yb, ld, 1, st.Bm, ld, stream, 1.0, 0.0, none, true, cleanb);     // B = Q^T Y
         gemm_f64(n, k, k, st.Qc, ld, 1, st.Bm, ld, 1, Zb, ld, stream, 1.0, 0.0, none, false);            // Z = Q B
-        GS_LAUNCH(invsub_resid_kernel, dim3((unsigned)k), dim3(256), 0, stream, Yb, Zb, ld, st.Bm, ld, n, ws.theta + ws.pp,
-                  ws.theta);
-        GS_LAUNCH(invsub_judge_kernel, dim3(1), dim3(128), 0, stream, ws.theta, ws.pp, k, st.jj_last, 1e-9, st.loewdin ? 1 : 0,
-                  verdict);
+        // residuals + acceptance test in one launch; the verdict also lands in the pinned host slot (no copy behind it)
+        GS_LAUNCH(invsub_resid_judge_kernel, dim3((unsigned)k), dim3(256), 0, stream, Yb, Zb, ld, st.Bm, ld, n, ws.theta, ws.pp,
+                  k, st.jj_last, 1e-9, st.loewdin ? 1 : 0, verdict, ws.inv_host_dev,
+                  reinterpret_cast<unsigned *>(ws.theta + 3 * ws.pp + 24));
         // optimistic: the new state leaves for the caller's arrays if the device-side test passed
         GS_LAUNCH(invsub_emit_kernel, dim3((unsigned)ceil_div((int)(st.ldv > k ? st.ldv : k), 256), (unsigned)k), dim3(256), 0,
                   stream, st.Qc, ld, n, k, st.Vk, st.ldv, st.Bm, ld, st.Bk, st.ldbk, verdict);
@@ -969,7 +1083,8 @@ int invsub_enqueue_attempt(SubspaceWorkspace &ws, hipStream_t stream) {
                                                        n, k, ws.ring_next, ws.h_next, st.lda, st.ldv, (int64_t)(intptr_t)st.A,
                                                        (int64_t)(intptr_t)st.Vk, (int64_t)(intptr_t)st.Qc}), stream, segment);
     if (rcs != GS_OK) return rcs;
-    GS_HIP_CHECK(hipMemcpyAsync(ws.inv_host, verdict, sizeof(double) * 8, hipMemcpyDeviceToHost, stream));
+    if (ws.inv_host_dev == nullptr)       // (no device view of the pinned slot: the copy of rounds 4-5)
+        GS_HIP_CHECK(hipMemcpyAsync(ws.inv_host, verdict, sizeof(double) * 8, hipMemcpyDeviceToHost, stream));
     GS_HIP_CHECK(hipEventRecord(ws.inv_event, stream));
     return GS_OK;
 }
@@ -1010,6 +1125,11 @@ int invsub_begin(SubspaceWorkspace &ws, const double *A, int n, int64_t lda, int
     if (ws.inv_host == nullptr) {
         GS_HIP_CHECK(hipHostMalloc((void **)&ws.inv_host, sizeof(double) * 8, hipHostMallocDefault));
         GS_HIP_CHECK(hipEventCreateWithFlags(&ws.inv_event, hipEventDisableTiming));
+        void *dv = nullptr;
+        if (hipHostGetDevicePointer(&dv, ws.inv_host, 0) == hipSuccess) ws.inv_host_dev = static_cast<double *>(dv);
+        else (void)hipGetLastError();
+        // the ticket counter of invsub_resid_judge_kernel lives in the statistics tail of theta
+        GS_HIP_CHECK(hipMemsetAsync(ws.theta + 3 * ws.pp + 24, 0, sizeof(double), stream));
     }
     InvsubPending &st = ws.inv;
     st = InvsubPending();
@@ -1151,7 +1271,8 @@ int eigh_topk_cheb(SubspaceWorkspace &ws, const double *A, int n, int64_t lda, i
             if (rc != GS_OK) return rc;
             Qc = o;
         }
-        GS_LAUNCH(cheb_setup_kernel, dim3(1), dim3(64), 0, stream, ws.theta + 2 * ws.pp, p, k, 1, stats, coef);
+        GS_LAUNCH(cheb_setup_kernel, dim3(1), dim3(64), 0, stream, ws.theta + 2 * ws.pp, p, k, 1, stats, coef,
+                  ws.pin_dev ? ws.pin_dev + ws.p_cap + 16 : (double *)nullptr);
         return GS_OK;
     };
     {
@@ -1171,9 +1292,13 @@ int eigh_topk_cheb(SubspaceWorkspace &ws, const double *A, int n, int64_t lda, i
     const bool reuse_cold = !warm && ws.cold_plan_valid && ws.cold_plan_p == p;
     auto plan_from_stats = [&](bool *no_gap) -> int {
         *no_gap = false;
-        GS_HIP_CHECK(hipMemcpyAsync(host, stats, sizeof(double) * 8, hipMemcpyDeviceToHost, stream));
+        const double *hs = host;
+        if (ws.pin_dev != nullptr)
+            hs = ws.pin + ws.p_cap + 16;          // (written by cheb_setup_kernel itself)
+        else
+            GS_HIP_CHECK(hipMemcpyAsync(host, stats, sizeof(double) * 8, hipMemcpyDeviceToHost, stream));
         GS_HIP_CHECK(hipStreamSynchronize(stream));
-        const double rk = host[1], ndead = host[5], lam1 = host[6], b = host[7];
+        const double rk = hs[1], ndead = hs[5], lam1 = hs[6], b = hs[7];
         if (ndead > 0.0 || !(b > 1e-12 * lam1)) {
             deg = 1;            // plain products (cheb_setup chose them too): the basis spans the numerical range
             ncyc = 2;
@@ -1276,7 +1401,8 @@ int eigh_topk_cheb(SubspaceWorkspace &ws, const double *A, int n, int64_t lda, i
             gemm_f64(n, p, p, Qc, ld, 1, ws.U, ld, 1, Zb, ld, stream, 1.0, 0.0, none, false);    // Z = Q U
             gemm_f64(n, k, p, Yb, ld, 1, ws.U, ld, 1, Wb, ld, stream, 1.0, 0.0, none, false);    // (A Q) U_k
             GS_LAUNCH(topk_resid_kernel, dim3((unsigned)k), dim3(256), 0, stream, Wb, Zb, ld, ws.theta, n, k,
-                      ws.theta + ws.pp);
+                      ws.theta + ws.pp, ws.pin_dev, (const int *)jinfo,
+                      reinterpret_cast<unsigned *>(ws.theta + 3 * ws.pp + 25));
             // optimistic: the Ritz pairs leave for the caller's arrays before the host has looked at the residuals -
             // a failed attempt continues from Zb (not from Vk), a failed solve is redone by the caller's fall-back
             GS_LAUNCH(topk_emit_kernel, dim3((unsigned)ceil_div(n, 256), (unsigned)k), dim3(256), 0, stream, Zb, ld,
@@ -1292,10 +1418,12 @@ int eigh_topk_cheb(SubspaceWorkspace &ws, const double *A, int n, int64_t lda, i
                                                            (int64_t)(intptr_t)Qc, ws.epilogue ? 1 : 0,
                                                            ws.rr_force_jacobi ? 1 : 0}), stream, segment_b);
         if (rcb != GS_OK) return rcb;
-        GS_HIP_CHECK(hipMemcpyAsync(host, ws.theta + ws.pp, sizeof(double) * k, hipMemcpyDeviceToHost, stream));
-        GS_HIP_CHECK(hipMemcpyAsync(host + k, ws.theta, sizeof(double), hipMemcpyDeviceToHost, stream));
         int *jhost = reinterpret_cast<int *>(host + k + 2);
-        GS_HIP_CHECK(hipMemcpyAsync(jhost, jinfo, sizeof(int) * 2, hipMemcpyDeviceToHost, stream));
+        if (ws.pin_dev == nullptr) {          // (no device view of the pinned buffer: the three copies of rounds 4-5)
+            GS_HIP_CHECK(hipMemcpyAsync(host, ws.theta + ws.pp, sizeof(double) * k, hipMemcpyDeviceToHost, stream));
+            GS_HIP_CHECK(hipMemcpyAsync(host + k, ws.theta, sizeof(double), hipMemcpyDeviceToHost, stream));
+            GS_HIP_CHECK(hipMemcpyAsync(jhost, jinfo, sizeof(int) * 2, hipMemcpyDeviceToHost, stream));
+        }
         GS_HIP_CHECK(hipStreamSynchronize(stream));
         double worst = 0;
         bool finite = true;
