@@ -900,41 +900,19 @@ __global__ __launch_bounds__(128) void invsub_judge_kernel(const double *__restr
 // test over all columns and writes the verdict to device memory (the emit kernel's predicate) AND straight into the
 // handle's pinned host slot (`verdict_host`, device-visible: the host reads it behind the event of the next launch).
 __global__ __launch_bounds__(256) void invsub_resid_judge_kernel(const double *__restrict__ Y, const double *__restrict__ Z,
-                                                                 const double *__restrict__ Q,
                                                                  int64_t ld, const double *__restrict__ B, int64_t ldb, int n,
                                                                  double *__restrict__ theta, int pp, int k, int jj_last,
                                                                  double tol_rel, int loewdin, double *__restrict__ verdict,
                                                                  double *__restrict__ verdict_host,
                                                                  unsigned *__restrict__ ticket) {
-    __shared__ double scr[256], s_th1[256], s_w2[256], s_rmax[256], s_rmin[256], s_bc[128];
+    __shared__ double scr[256], s_th1[256], s_w2[256], s_rmax[256], s_rmin[256];
     __shared__ int s_bad[256];
     __shared__ unsigned s_last;
     const int c = blockIdx.x, t = threadIdx.x;
     double s = 0;
-    if (Q != nullptr) {
-        // Z = Q B is not formed (one more launch less, n <= 1024): column c of it is evaluated here - a 16-lane group per
-        // row, lanes along the k columns of Q (coalesced), B[:, c] in LDS, the row's dot product summed over the group
-        for (int j = t; j < k; j += 256) s_bc[j] = B[(int64_t)j * ldb + c];
-        __syncthreads();
-        const int gl = t & 15, grp = t >> 4;
-        for (int r = grp; r < n; r += 16) {
-            const double *qr = Q + (int64_t)r * ld;
-            double z = 0.0;
-            for (int j = gl; j < k; j += 16) z += qr[j] * s_bc[j];
-            z += __shfl_xor(z, 1);
-            z += __shfl_xor(z, 2);
-            z += __shfl_xor(z, 4);
-            z += __shfl_xor(z, 8);
-            if (gl == 0) {
-                const double v = Y[(int64_t)r * ld + c] - z;
-                s += v * v;
-            }
-        }
-    } else {
-        for (int r = t; r < n; r += 256) {
-            const double v = Y[(int64_t)r * ld + c] - Z[(int64_t)r * ld + c];
-            s += v * v;
-        }
+    for (int r = t; r < n; r += 256) {
+        const double v = Y[(int64_t)r * ld + c] - Z[(int64_t)r * ld + c];
+        s += v * v;
     }
     scr[t] = s;
     __syncthreads();
@@ -1091,13 +1069,9 @@ int invsub_enqueue_attempt(SubspaceWorkspace &ws, hipStream_t stream) {
         gemm_f64(n, k, n, st.A, st.lda, 1, st.Qc, ld, 1, Yb, ld, stream, 1.0, 0.0, none, true, cleany);     // Y = A Q
         ++st.used;
         gemm_f64(k, k, n, st.Qc, 1, ld, Yb, ld, 1, st.Bm, ld, stream, 1.0, 0.0, none, true, cleanb);     // B = Q^T Y
-        // Z = Q B: formed for tall blocks (small side: every residual block would stream the whole Q through L2), evaluated
-        // column by column inside the residual kernel otherwise
-        const bool fuse_z = n <= 1024 && k <= 128;
-        if (!fuse_z) gemm_f64(n, k, k, st.Qc, ld, 1, st.Bm, ld, 1, Zb, ld, stream, 1.0, 0.0, none, false);
+        gemm_f64(n, k, k, st.Qc, ld, 1, st.Bm, ld, 1, Zb, ld, stream, 1.0, 0.0, none, false);            // Z = Q B
         // residuals + acceptance test in one launch; the verdict also lands in the pinned host slot (no copy behind it)
-        GS_LAUNCH(invsub_resid_judge_kernel, dim3((unsigned)k), dim3(256), 0, stream, Yb, Zb,
-                  fuse_z ? (const double *)st.Qc : (const double *)nullptr, ld, st.Bm, ld, n, ws.theta, ws.pp,
+        GS_LAUNCH(invsub_resid_judge_kernel, dim3((unsigned)k), dim3(256), 0, stream, Yb, Zb, ld, st.Bm, ld, n, ws.theta, ws.pp,
                   k, st.jj_last, 1e-9, st.loewdin ? 1 : 0, verdict, ws.inv_host_dev,
                   reinterpret_cast<unsigned *>(ws.theta + 3 * ws.pp + 24));
         // optimistic: the new state leaves for the caller's arrays if the device-side test passed
