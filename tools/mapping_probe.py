@@ -1,5 +1,5 @@
-"""Time the mapping network (8 x [rows x 512 x 512] f32-MFMA layers) per call length - the per-layer kernels below 24 576 rows,
-the panel-blocked path (gs_gemm_blocked.hip) from there on - and the gen_z-shaped Linear, on the device.
+"""Time the mapping network (8 x [rows x 512 x 512] f32-MFMA layers, one `linear_act_fast_kernel` launch per layer) per call
+length, and the gen_z-shaped Linear, on the device.
     python tools/mapping_probe.py [rows ...]"""
 import os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
