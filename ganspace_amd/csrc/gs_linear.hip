@@ -411,6 +411,145 @@ __device__ __forceinline__ void linear_fast_body(float (*lds)[32 * R + kLT][kFP]
     }
 }
 
+// The same K loop run as ONE software pipeline over all the output tiles of a workgroup (`linear_act_persist_kernel`, one
+// workgroup per CU): while the last K stage of a tile is in the MFMAs, the first stage of the workgroup's next tile is
+// already being fetched, and the finished tile is stored behind that stage's LDS writes - the per-tile start-up (a dispatch,
+// a cold fetch of 320 rows, the bias) and the drain are paid once per launch instead of once per tile.  Per output element the
+// arithmetic is the fma chain of `linear_fast_body` in the same order: results are bit-identical.
+template <int R, int RF>
+__device__ __forceinline__ void linear_persist_body(float (*lds)[32 * R + kLT][kFP], const float *__restrict__ bias,
+                                                    float *__restrict__ Y, int64_t M, int K, int64_t ldy, float wscale,
+                                                    float bscale, float slope, float gain, int act, int ntn,
+                                                    int64_t t_first, int64_t t_end, int t_step, int f0, int cw,
+                                                    const __amdgpu_buffer_rsrc_t &rx, const __amdgpu_buffer_rsrc_t &rw,
+                                                    int64_t ldx) {
+    constexpr int TM = 32 * R;
+    constexpr int PA = (TM + 63) / 64;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int k4 = tid & 7, r8 = tid >> 3;
+    const unsigned voffx = (unsigned)((r8 * ldx + k4 * 4) * 4), voffw = (unsigned)((r8 * K + k4 * 4) * 4);
+
+    u32x4 ra[PA], rb[2];
+    auto fetch = [&](int64_t m0, int n0, int k0) {
+#pragma unroll
+        for (int i = 0; i < PA; ++i)
+            if (TM % 64 == 0 || i + 1 < PA || r8 < TM % 64)
+                ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, voffx, (unsigned)(((m0 + 64 * i) * ldx + k0) * 4), 0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            rb[i] = __builtin_amdgcn_raw_buffer_load_b128(rw, voffw, (unsigned)((((int64_t)n0 + 64 * i) * K + k0) * 4), 0);
+    };
+    auto put = [&](float *dst, u32x4 v) {
+        asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));
+        uint2 *p = reinterpret_cast<uint2 *>(dst);
+        p[0] = make_uint2(v.x, v.y);
+        p[1] = make_uint2(v.z, v.w);
+    };
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < PA; ++i)
+            if (TM % 64 == 0 || i + 1 < PA || r8 < TM % 64) put(&lds[buf][r8 + 64 * i][k4 * 4], ra[i]);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) put(&lds[buf][TM + r8 + 64 * i][k4 * 4], rb[i]);
+    };
+
+    f32x16 acc[RF > 0 ? RF : 1];
+#pragma unroll
+    for (int r = 0; r < (RF > 0 ? RF : 1); ++r) acc[r] = f32x16{0};
+    const int nst = K / kLK;
+    const int frag = ((lane & 31) * kFP + (lane >> 5)) * 4;
+    constexpr int kFrag = 32 * kFP * 4;
+
+    int64_t t = t_first;
+    if (t >= t_end) return;                      // (uniform over the workgroup)
+    int64_t m0 = (t / ntn) * TM;
+    int n0 = (int)(t % ntn) * kLT;
+    fetch(m0, n0, 0);
+    stash(0);
+    __syncthreads();
+    int buf = 0;
+    while (true) {
+        const int64_t tn = t + t_step;
+        const bool more = tn < t_end;
+        const int64_t m1 = more ? (tn / ntn) * TM : 0;
+        const int n1 = more ? (int)(tn % ntn) * kLT : 0;
+        float bb = 0.f;
+        if constexpr (RF > 0) bb = bias ? bias[n0 + cw * 32 + (lane & 31)] * bscale : 0.f;
+        for (int s = 0; s < nst; ++s) {
+            const bool last = s + 1 == nst;
+            const bool nxt = !last || more;
+            if (nxt) fetch(last ? m1 : m0, last ? n1 : n0, last ? 0 : (s + 1) * kLK);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (RF > 0) {
+                const unsigned aaddr = (unsigned)(uintptr_t)&lds[buf][32 * f0][0] + frag;
+                const unsigned baddr = (unsigned)(uintptr_t)&lds[buf][TM + cw * 32][0] + frag;
+                float a[RF], p[RF];
+                const float b0 = lds_rd<0>(baddr);
+                ReadFrags<RF, 0, kFrag>::run(aaddr, a);
+                const float pb = lds_rd<8>(baddr);
+                ReadFrags<RF, 8, kFrag>::run(aaddr, p);
+                LinPipe<RF, 0, kLK / 2>::run(aaddr, baddr, a, b0, p, pb, acc);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (nxt) stash(buf ^ 1);
+            if (last) {
+                if constexpr (RF > 0) {
+                    const int col = n0 + cw * 32 + (lane & 31);
+                    const int64_t row_base = m0 + 32 * f0 + 4 * (lane >> 5);
+#pragma unroll
+                    for (int r = 0; r < RF; ++r) {
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) {
+                            const int64_t row = row_base + 32 * r + (i & 3) + 8 * (i >> 2);
+                            if (row < M) {
+                                float v = acc[r][i] * wscale + bb;
+                                if (act) v = gain * (v >= 0.f ? v : v * slope);
+                                Y[row * ldy + col] = v;
+                            }
+                        }
+                        acc[r] = f32x16{0};
+                    }
+                }
+            }
+            __syncthreads();
+            buf ^= 1;
+        }
+        if (!more) break;
+        t = tn;
+        m0 = m1;
+        n0 = n1;
+    }
+}
+
+// One workgroup per CU (grid = 8 XCDs x `wg_per_xcd`); workgroup b (XCD b % 8) walks the tiles
+// (b % 8) * xcd_per + b / 8 + j * wg_per_xcd of its XCD's contiguous tile range: at any moment the CUs of an XCD hold
+// neighbouring tiles, i.e. the ntn column tiles of the same x rows, fetched through one L2.
+template <int R>
+__global__ __launch_bounds__(512, 1) void linear_act_persist_kernel(
+    const float *__restrict__ X, const float *__restrict__ Wt, const float *__restrict__ bias,
+    float *__restrict__ Y, int64_t M, int N, int K, int64_t ldx, int64_t ldy, float wscale, float bscale,
+    float slope, float gain, int act, int64_t total_tiles, int64_t xcd_per, int wg_per_xcd) {
+    constexpr int TM = 32 * R;
+    __shared__ __attribute__((aligned(16))) float lds[2][TM + kLT][kFP];
+    const int ntn = N / kLT;
+    const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+    const int64_t t_first = (int64_t)xcd * xcd_per + local;
+    int64_t t_end = (int64_t)(xcd + 1) * xcd_per;
+    if (t_end > total_tiles) t_end = total_tiles;
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(X), 0,
+                                                                        (unsigned)((uint64_t)M * ldx * 4u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(Wt), 0,
+                                                                        (unsigned)((uint64_t)N * K * 4u), 0x00020000);
+    constexpr int RA = (R + 1) / 2, RB = R / 2;
+    if (wave < 4)
+        linear_persist_body<R, RA>(lds, bias, Y, M, K, ldy, wscale, bscale, slope, gain, act, ntn, t_first, t_end,
+                                   wg_per_xcd, 0, wave, rx, rw, ldx);
+    else
+        linear_persist_body<R, RB>(lds, bias, Y, M, K, ldy, wscale, bscale, slope, gain, act, ntn, t_first, t_end,
+                                   wg_per_xcd, RA, wave - 4, rx, rw, ldx);
+}
+
 template <int R>
 __global__ __launch_bounds__(512, 1) void linear_act_fast_kernel(
     const float *__restrict__ X, const float *__restrict__ Wt, const float *__restrict__ bias,
@@ -496,6 +635,26 @@ static int launch_linear(const float *x, const float *W, const float *b, float *
         if (const char *fx = gs_knob("GS_LINEAR_XCD")) xcd = fx[0] == '1';
         const int64_t per = xcd ? ceil_div(total, 8) : 0;
         const unsigned grid = (unsigned)(xcd ? per * 8 : total);
+        // launches of more than four rounds of the chip: one workgroup per CU walks its tiles as one pipeline
+        bool persist = total > 1024;
+        if (const char *fp = gs_knob("GS_LINEAR_PERSIST")) persist = fp[0] == '1';
+        if (persist) {
+            const int64_t pper = ceil_div(total, 8);
+            const int wgx = (int)(pper < 32 ? pper : 32);
+#define GS_LAUNCH_PERSIST(RR)                                                                                      \
+    hipLaunchKernelGGL((linear_act_persist_kernel<RR>), dim3((unsigned)(8 * wgx)), dim3(512), 0, stream, x, W, b, y, M, N, K, \
+                       (int64_t)K, (int64_t)N, wscale, bscale, slope, gain, act, total, pper, wgx)
+            switch (best) {
+                case 2: GS_LAUNCH_PERSIST(2); break;
+                case 3: GS_LAUNCH_PERSIST(3); break;
+                case 4: GS_LAUNCH_PERSIST(4); break;
+                case 5: GS_LAUNCH_PERSIST(5); break;
+                default: GS_LAUNCH_PERSIST(6); break;
+            }
+#undef GS_LAUNCH_PERSIST
+            GS_HIP_CHECK(hipGetLastError());
+            return GS_OK;
+        }
 #define GS_LAUNCH_FAST(RR)                                                                                         \
     hipLaunchKernelGGL((linear_act_fast_kernel<RR>), dim3(grid), dim3(512), 0, stream, x, W, b, y, M, N, K, (int64_t)K, \
                        (int64_t)N, wscale, bscale, slope, gain, act, total, per)
