@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256, 2) void linear_act_kernel(
     const float bb0 = (bias && col0 < N) ? bias[col0] * bscale : 0.f;
     const float bb1 = (bias && col1 < N) ? bias[col1] * bscale : 0.f;
     auto fin = [&](float v, float bb) {
-        v = v * wscale + bb;
+        v = __fmaf_rn(v, wscale, bb);
         if (act) v = gain * (v >= 0.f ? v : v * slope);
         return v;
     };
@@ -403,7 +403,7 @@ __device__ __forceinline__ void linear_fast_body(float (*lds)[32 * R + kLT][kFP]
             for (int i = 0; i < 16; ++i) {
                 const int64_t row = row_base + 32 * r + (i & 3) + 8 * (i >> 2);
                 if (row < M) {
-                    float v = acc[r][i] * wscale + bb;
+                    float v = __fmaf_rn(acc[r][i], wscale, bb);   // (one rounding, in every kernel of this file)
                     if (act) v = gain * (v >= 0.f ? v : v * slope);
                     Y[row * ldy + col] = v;
                 }
@@ -418,10 +418,10 @@ __device__ __forceinline__ void linear_fast_body(float (*lds)[32 * R + kLT][kFP]
 // arithmetic is the fma chain of `linear_fast_body` in the same order: results are bit-identical.
 template <int R, int RF>
 __device__ __forceinline__ void linear_persist_body(float (*lds)[32 * R + kLT][kFP], const float *__restrict__ bias,
-                                                    float *__restrict__ Y, int64_t M, int K, int64_t ldy, float wscale,
-                                                    float bscale, float slope, float gain, int act, int ntn,
-                                                    int64_t t_first, int64_t t_end, int t_step, int f0, int cw,
-                                                    const __amdgpu_buffer_rsrc_t &rx, const __amdgpu_buffer_rsrc_t &rw,
+                                                    int K, int64_t ldy, float wscale, float bscale, float slope,
+                                                    float gain, int act, unsigned ntn, unsigned t_first, unsigned t_end,
+                                                    unsigned t_step, int f0, int cw, const __amdgpu_buffer_rsrc_t &rx,
+                                                    const __amdgpu_buffer_rsrc_t &rw, const __amdgpu_buffer_rsrc_t &ry,
                                                     int64_t ldx) {
     constexpr int TM = 32 * R;
     constexpr int PA = (TM + 63) / 64;
@@ -460,25 +460,31 @@ __device__ __forceinline__ void linear_persist_body(float (*lds)[32 * R + kLT][k
     const int frag = ((lane & 31) * kFP + (lane >> 5)) * 4;
     constexpr int kFrag = 32 * kFP * 4;
 
-    int64_t t = t_first;
+    unsigned t = t_first;
     if (t >= t_end) return;                      // (uniform over the workgroup)
-    int64_t m0 = (t / ntn) * TM;
+    int64_t m0 = (int64_t)(t / ntn) * TM;
     int n0 = (int)(t % ntn) * kLT;
     fetch(m0, n0, 0);
     stash(0);
     __syncthreads();
     int buf = 0;
+    // row offsets of this lane's 16 values of a fragment are 4 (lane >> 5) + (i & 3) + 8 (i >> 2); rows past M fall outside
+    // the buffer resource of y and are dropped by the hardware: no branches around the stores
+    const unsigned ystore = (unsigned)(((32 * f0 + 4 * (lane >> 5)) * ldy + cw * 32 + (lane & 31)) * 4);
+    float braw = 0.f;                            // (set once per tile, in its last stage: no write at the top of a tile,
+                                                 //  where the stores of the tile before are still in flight)
     while (true) {
-        const int64_t tn = t + t_step;
+        const unsigned tn = t + t_step;
         const bool more = tn < t_end;
-        const int64_t m1 = more ? (tn / ntn) * TM : 0;
+        const int64_t m1 = more ? (int64_t)(tn / ntn) * TM : 0;
         const int n1 = more ? (int)(tn % ntn) * kLT : 0;
-        float bb = 0.f;
-        if constexpr (RF > 0) bb = bias ? bias[n0 + cw * 32 + (lane & 31)] * bscale : 0.f;
         for (int s = 0; s < nst; ++s) {
             const bool last = s + 1 == nst;
             const bool nxt = !last || more;
             if (nxt) fetch(last ? m1 : m0, last ? n1 : n0, last ? 0 : (s + 1) * kLK);
+            // the bias of THIS tile, needed behind the last barrier: issued here, with the loads the stage waits for anyway
+            if constexpr (RF > 0)
+                if (last && bias) braw = bias[n0 + cw * 32 + (lane & 31)];
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (RF > 0) {
                 const unsigned aaddr = (unsigned)(uintptr_t)&lds[buf][32 * f0][0] + frag;
@@ -492,27 +498,27 @@ __device__ __forceinline__ void linear_persist_body(float (*lds)[32 * R + kLT][k
             }
             __builtin_amdgcn_sched_barrier(0);
             if (nxt) stash(buf ^ 1);
+            __syncthreads();
+            buf ^= 1;
+            // the finished tile goes out behind the barrier, i.e. behind the LDS writes of the next tile's first stage
             if (last) {
                 if constexpr (RF > 0) {
-                    const int col = n0 + cw * 32 + (lane & 31);
-                    const int64_t row_base = m0 + 32 * f0 + 4 * (lane >> 5);
+                    const float bb = __fmul_rn(braw, bscale);
+                    const unsigned tile_off = (unsigned)((m0 * ldy + n0) * 4);
 #pragma unroll
                     for (int r = 0; r < RF; ++r) {
 #pragma unroll
                         for (int i = 0; i < 16; ++i) {
-                            const int64_t row = row_base + 32 * r + (i & 3) + 8 * (i >> 2);
-                            if (row < M) {
-                                float v = acc[r][i] * wscale + bb;
-                                if (act) v = gain * (v >= 0.f ? v : v * slope);
-                                Y[row * ldy + col] = v;
-                            }
+                            float v = __fmaf_rn(acc[r][i], wscale, bb);   // (one rounding, in every kernel of this file)
+                            if (act) v = gain * (v >= 0.f ? v : v * slope);
+                            __builtin_amdgcn_raw_buffer_store_b32(
+                                __builtin_bit_cast(unsigned, v), ry,
+                                ystore + (unsigned)((32 * r + (i & 3) + 8 * (i >> 2)) * ldy * 4), tile_off, 0);
                         }
                         acc[r] = f32x16{0};
                     }
                 }
             }
-            __syncthreads();
-            buf ^= 1;
         }
         if (!more) break;
         t = tn;
@@ -521,33 +527,35 @@ __device__ __forceinline__ void linear_persist_body(float (*lds)[32 * R + kLT][k
     }
 }
 
-// One workgroup per CU (grid = 8 XCDs x `wg_per_xcd`); workgroup b (XCD b % 8) walks the tiles
+// One or two workgroups per CU (grid = 8 XCDs x `wg_per_xcd`); workgroup b (XCD b % 8) walks the tiles
 // (b % 8) * xcd_per + b / 8 + j * wg_per_xcd of its XCD's contiguous tile range: at any moment the CUs of an XCD hold
 // neighbouring tiles, i.e. the ntn column tiles of the same x rows, fetched through one L2.
 template <int R>
-__global__ __launch_bounds__(512, 1) void linear_act_persist_kernel(
+__global__ __launch_bounds__(512, (R <= 4 ? 4 : 2)) void linear_act_persist_kernel(
     const float *__restrict__ X, const float *__restrict__ Wt, const float *__restrict__ bias,
     float *__restrict__ Y, int64_t M, int N, int K, int64_t ldx, int64_t ldy, float wscale, float bscale,
     float slope, float gain, int act, int64_t total_tiles, int64_t xcd_per, int wg_per_xcd) {
     constexpr int TM = 32 * R;
     __shared__ __attribute__((aligned(16))) float lds[2][TM + kLT][kFP];
-    const int ntn = N / kLT;
+    const unsigned ntn = (unsigned)(N / kLT);
     const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
-    const int64_t t_first = (int64_t)xcd * xcd_per + local;
-    int64_t t_end = (int64_t)(xcd + 1) * xcd_per;
-    if (t_end > total_tiles) t_end = total_tiles;
+    const unsigned t_first = (unsigned)(xcd * xcd_per + local);
+    int64_t t_end64 = (int64_t)(xcd + 1) * xcd_per;
+    if (t_end64 > total_tiles) t_end64 = total_tiles;
+    const unsigned t_end = (unsigned)t_end64;
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(X), 0,
                                                                         (unsigned)((uint64_t)M * ldx * 4u), 0x00020000);
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(Wt), 0,
                                                                         (unsigned)((uint64_t)N * K * 4u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(Y, 0, (unsigned)((uint64_t)M * ldy * 4u), 0x00020000);
     constexpr int RA = (R + 1) / 2, RB = R / 2;
     if (wave < 4)
-        linear_persist_body<R, RA>(lds, bias, Y, M, K, ldy, wscale, bscale, slope, gain, act, ntn, t_first, t_end,
-                                   wg_per_xcd, 0, wave, rx, rw, ldx);
+        linear_persist_body<R, RA>(lds, bias, K, ldy, wscale, bscale, slope, gain, act, ntn, t_first, t_end,
+                                   (unsigned)wg_per_xcd, 0, wave, rx, rw, ry, ldx);
     else
-        linear_persist_body<R, RB>(lds, bias, Y, M, K, ldy, wscale, bscale, slope, gain, act, ntn, t_first, t_end,
-                                   wg_per_xcd, RA, wave - 4, rx, rw, ldx);
+        linear_persist_body<R, RB>(lds, bias, K, ldy, wscale, bscale, slope, gain, act, ntn, t_first, t_end,
+                                   (unsigned)wg_per_xcd, RA, wave - 4, rx, rw, ry, ldx);
 }
 
 template <int R>
@@ -635,23 +643,16 @@ static int launch_linear(const float *x, const float *W, const float *b, float *
         if (const char *fx = gs_knob("GS_LINEAR_XCD")) xcd = fx[0] == '1';
         const int64_t per = xcd ? ceil_div(total, 8) : 0;
         const unsigned grid = (unsigned)(xcd ? per * 8 : total);
-        // launches of more than four rounds of the chip: one workgroup per CU walks its tiles as one pipeline
-        bool persist = total > 1024;
-        if (const char *fp = gs_knob("GS_LINEAR_PERSIST")) persist = fp[0] == '1';
+        // launches of more than two rounds of 128-row tiles: two workgroups per CU walk their tiles as one pipeline each
+        // (R = 4: the tile height whose registers and LDS let two of them share a CU)
+        const int64_t total4 = ceil_div(M, (int64_t)128) * ntn;
+        bool persist = total4 > 1024 && (uint64_t)M * N * 4u < 0xFFFFFFFFull;     // (y through a buffer resource)
+        if (const char *fp = gs_knob("GS_LINEAR_PERSIST")) persist = persist && fp[0] == '1';
         if (persist) {
-            const int64_t pper = ceil_div(total, 8);
-            const int wgx = (int)(pper < 32 ? pper : 32);
-#define GS_LAUNCH_PERSIST(RR)                                                                                      \
-    hipLaunchKernelGGL((linear_act_persist_kernel<RR>), dim3((unsigned)(8 * wgx)), dim3(512), 0, stream, x, W, b, y, M, N, K, \
-                       (int64_t)K, (int64_t)N, wscale, bscale, slope, gain, act, total, pper, wgx)
-            switch (best) {
-                case 2: GS_LAUNCH_PERSIST(2); break;
-                case 3: GS_LAUNCH_PERSIST(3); break;
-                case 4: GS_LAUNCH_PERSIST(4); break;
-                case 5: GS_LAUNCH_PERSIST(5); break;
-                default: GS_LAUNCH_PERSIST(6); break;
-            }
-#undef GS_LAUNCH_PERSIST
+            const int64_t pper = ceil_div(total4, 8);
+            const int wgx = 64;                                   // workgroups per XCD (32 CUs)
+            hipLaunchKernelGGL((linear_act_persist_kernel<4>), dim3((unsigned)(8 * wgx)), dim3(512), 0, stream, x, W, b, y, M, N,
+                               K, (int64_t)K, (int64_t)N, wscale, bscale, slope, gain, act, total4, pper, wgx);
             GS_HIP_CHECK(hipGetLastError());
             return GS_OK;
         }
