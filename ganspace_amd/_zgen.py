@@ -162,9 +162,10 @@ def device_generation_enabled(device) -> bool:
 
 ZGEN_STAGING_BYTES = 12 << 30     # device staging of one gs_zgen_device launch (device_groups), and never more than a
 ZGEN_STAGING_FRACTION = 4         # quarter of the free device memory
-# streams per launch: one workgroup (four waves, 182 VGPRs) per stream, two workgroups fit a CU - measured per launch of
-# 10 000 x 512 normals (tools/zgen_group_probe.py): 256 streams 22.9 ms, 512 30.5 ms, 1024 58.6 ms, 2048 113.5 ms
-ZGEN_GROUP = 1024
+# streams per launch: one workgroup (four waves, 54 VGPRs, 20 KB of LDS) per stream, up to eight workgroups per CU - measured
+# per launch of 10 000 x 512 normals (tools/zgen_group_probe.py): 256 streams 21.4 ms, 512 26.0 ms, 1024 38.4 ms, 2048 66.5 ms
+# (rounds 5-6, 182 VGPRs, two workgroups per CU: 22.9 / 30.5 / 58.6 / 113.5 ms)
+ZGEN_GROUP = 2048
 
 
 def device_groups(kind: str, seeds, n: int, dim: int, device, truncation: float = 1.0, group: int = None, out=None):
@@ -172,7 +173,7 @@ def device_groups(kind: str, seeds, n: int, dim: int, device, truncation: float 
     ``RandomState(seeds[lo + j]).standard_normal(n * dim)`` (``kind="stylegan"``) or BigGAN's
     ``truncation * truncnorm.rvs(-2, 2, size=(n, dim), random_state=RandomState(seed))`` - generated on the device, one
     workgroup (four waves) per seed, up to ``group`` seeds per launch.  A launch of up to 256 streams lasts as long as ONE
-    stream (22 ms for 10 000 x 512 normals), twice as many take a third longer (two workgroups per CU): the groups are
+    stream (21 ms for 10 000 x 512 normals), 2 048 streams three times as long (up to eight workgroups per CU): the groups are
     as long as memory allows - ``out`` (``[len(seeds), n, dim]``, e.g. the resident latent array of a Z-space job: no staging
     at all) or a staging buffer of at most ``ZGEN_STAGING_BYTES`` / a quarter of the free device memory.  (Round 6 first
     capped the staging at 1 GiB: cfg4's 801 streams became 16 launches instead of 4, 0.35 s instead of 0.09 s.)  Nothing

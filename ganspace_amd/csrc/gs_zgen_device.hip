@@ -3,17 +3,19 @@
 // The reference draws one seed per mini-batch and fills the batch from RandomState(seed).standard_normal(n * dim)
 // (models/wrappers.py:167-174; BigGAN: truncnorm.rvs through RandomState(seed).uniform, biggan/.../utils.py:21-33).  A
 // stream is serial per seed, but the batches are independent: one workgroup of FOUR WAVES per seed walks its stream
-// here (one wave per seed in the first version: 46 ms per launch, the float64 log / sqrt / divide of three candidates
-// per lane; one candidate per thread now), all seeds of a launch side by side.  The host generator (gs_zgen.hip) needs 64 threads, a 1.4 GB pinned ring (0.14 s of page locking
-// that does not parallelise - profiles/r05_probes.md) and a PCIe copy per batch: 0.24 s of cfg2's pre-sampling against
-// 0.004 s of fitting.  Here nothing leaves the device.
+// here, all seeds of a launch side by side (54 VGPRs and 20 KB of LDS for the normals: up to eight streams per CU).  The
+// host generator (gs_zgen.hip) needs 64 threads, a 1.4 GB pinned ring (0.14 s of page locking that does not parallelise -
+// profiles/r05_probes.md) and a PCIe copy per batch: 0.24 s of cfg2's pre-sampling against 0.004 s of fitting.  Here
+// nothing leaves the device.
 //
 // Per block of N = 624 draws (the whole MT19937 state):
-//   * the state update in its three data-parallel phases - i < 227 reads old words only, 227 <= i < 454 reads the NEW
-//     word i - 227, 454 <= i < 623 likewise, word 623 last: every old word is read up front, five barriers per block;
+//   * the state update in ONE data-parallel phase: the recurrence is XOR-linear, so every new word is written as a function
+//     of old words alone (mt_new_word) into the other of two state buffers - one barrier per block, where the textbook
+//     three-phase update cost five (rounds 5-6: 22.9 ms per stream of 5.12 M normals);
 //   * normals: a candidate of the polar method takes exactly four draws and 624 = 4 x 156, so thread t < 156 examines
-//     candidate t; the accepted ones are ranked by ballot / popcount (per-wave counts through LDS) in stream order and write their pair
-//     (f x2, then the "cached" f x1: legacy_gauss, numpy/random/src/legacy/legacy-distributions.c) at position p + 2 rank;
+//     candidate t between the same two barriers; the accepted ones are ranked by ballot / popcount (per-wave counts through
+//     LDS) in stream order and parked in LDS; once per four blocks the float64 log / divide / sqrt run on full waves and the
+//     pairs (f x2, then the "cached" f x1: legacy_gauss, numpy/random/src/legacy/legacy-distributions.c) are written;
 //   * truncated normals: 312 uniforms per block (two draws each), one inverse CDF per value.
 // Same operations on the same operands as the host generator (gs_zgen_math.h); what differs is the implementation of
 // log / exp / log1p / expm1 behind them (device libm instead of glibc): the float64 intermediates agree to <= 1 ulp, the
@@ -25,64 +27,82 @@ namespace gs {
 
 constexpr int kMtN = 624, kMtM = 397;
 
-__device__ __forceinline__ uint32_t mt_mix(uint32_t ki, uint32_t ki1, uint32_t km) {
-    const uint32_t y = (ki & 0x80000000u) | (ki1 & 0x7fffffffu);
-    return km ^ (y >> 1) ^ ((0u - (y & 1u)) & 0x9908b0dfu);
+__device__ __forceinline__ uint32_t mt_g(uint32_t a, uint32_t b) {
+    const uint32_t y = (a & 0x80000000u) | (b & 0x7fffffffu);
+    return (y >> 1) ^ ((0u - (y & 1u)) & 0x9908b0dfu);
 }
 
 constexpr int kZT = 256;      // threads per stream: four waves
+constexpr int kZG = 4;        // blocks of 624 draws per group of candidates (kind 0)
 
-// the next 624 draws: key[] (LDS) is advanced in place, untempered.  Thread t owns words t, t + 256, t + 512.  Every OLD
-// word a thread needs (its own, their right neighbours, and word i + 397 for i < 227) is read before the first barrier;
-// the three phases then only wait for the NEW word i - 227 of the phase before: five barriers per block.
-__device__ __forceinline__ void mt_next_block(uint32_t *key, int tid) {
-    const int i0 = tid, i1 = tid + kZT, i2 = tid + 2 * kZT;
-    const uint32_t o0 = key[i0], n0 = key[i0 + 1];                                   // i0 <= 255
-    const uint32_t o1 = key[i1], n1 = key[i1 + 1];                                   // 256 <= i1 <= 511
-    const uint32_t o2 = i2 < kMtN ? key[i2] : 0u, n2 = i2 < kMtN ? key[i2 + 1 < kMtN ? i2 + 1 : 0] : 0u;   // 512 <= i2 <= 623(+)
-    const uint32_t m0 = i0 < 227 ? key[i0 + kMtM] : 0u;                              // old word i + 397 (phase A)
-    __syncthreads();
-    // phase A: i in [0, 227)
-    if (i0 < 227) key[i0] = mt_mix(o0, n0, m0);
-    __syncthreads();
-    // phase B: i in [227, 454): words 227..255 are "i0" words, 256..453 "i1" words
-    if (i0 >= 227) key[i0] = mt_mix(o0, n0, key[i0 - 227]);
-    if (i1 < 454) key[i1] = mt_mix(o1, n1, key[i1 - 227]);
-    __syncthreads();
-    // phase C: i in [454, 623): 454..511 "i1" words, 512..622 "i2" words
-    if (i1 >= 454) key[i1] = mt_mix(o1, n1, key[i1 - 227]);
-    if (i2 < 623) key[i2] = mt_mix(o2, n2, key[i2 - 227]);
-    __syncthreads();
-    // word 623: the NEW word 0 is its right neighbour (n2 of that thread holds the old one: unused)
-    if (i2 == 623) key[623] = mt_mix(o2, key[0], key[kMtM - 1]);
-    __syncthreads();
+// Word i of the NEXT block of 624 draws as a function of the CURRENT block k[] alone.  The textbook update
+//   new[i] = (i < 227 ? old[i + 397] : new[i - 227]) ^ g(old[i], old[i + 1])          (word 623: g(old[623], new[0]))
+// runs in three dependent phases (rounds 5-6 paid five barriers per block for them).  The mix is XOR-linear, so the new
+// words on the right-hand side can be substituted until only old words are left:
+//   i in [0, 227):    old[i + 397] ^ G(i)
+//   i in [227, 454):  old[i + 170] ^ G(i - 227) ^ G(i)
+//   i in [454, 623):  old[i - 57]  ^ G(i - 454) ^ G(i - 227) ^ G(i)                    G(i) = g(old[i], old[i + 1])
+//   i = 623:          new[396] ^ g(old[623], new[0])
+// - every word of the block in ONE phase, written to the other of two state buffers: one barrier per block.
+__device__ __forceinline__ uint32_t mt_new_word(const uint32_t *k, int i) {
+    if (i < 227) return k[i + 397] ^ mt_g(k[i], k[i + 1]);
+    if (i < 454) return k[i + 170] ^ mt_g(k[i - 227], k[i - 226]) ^ mt_g(k[i], k[i + 1]);
+    if (i < 623) return k[i - 57] ^ mt_g(k[i - 454], k[i - 453]) ^ mt_g(k[i - 227], k[i - 226]) ^ mt_g(k[i], k[i + 1]);
+    const uint32_t n0 = k[397] ^ mt_g(k[0], k[1]);
+    const uint32_t n396 = k[566] ^ mt_g(k[169], k[170]) ^ mt_g(k[396], k[397]);
+    return n396 ^ mt_g(k[623], n0);
 }
 
-// kind 0: standard normals; kind 1: scale * truncnorm(-2, 2) (log_cdf_a / log_mass as in gs_zgen_start_truncnorm)
-__global__ __launch_bounds__(kZT) void zgen_device_kernel(const uint32_t *__restrict__ seeds, int64_t count,
-                                                          float *__restrict__ out, int64_t stride, int kind,
-                                                          double log_cdf_a, double log_mass, float scale) {
-    __shared__ __attribute__((aligned(16))) uint32_t key[kMtN];
-    __shared__ int wcount[2][kZT / 64];        // accepted candidates per wave (two sets: no barrier between blocks for it)
+// thread t of T writes words t, t + T, ... of the next block (untempered) into `next`
+template <int T>
+__device__ __forceinline__ void mt_write_next(const uint32_t *cur, uint32_t *next, int tid) {
+    constexpr int kW = (kMtN + T - 1) / T;
+    uint32_t v[kW];
+#pragma unroll
+    for (int j = 0; j < kW; ++j) v[j] = tid + j * T < kMtN ? mt_new_word(cur, tid + j * T) : 0u;
+#pragma unroll
+    for (int j = 0; j < kW; ++j)
+        if (tid + j * T < kMtN) next[tid + j * T] = v[j];
+}
+
+__device__ __forceinline__ void mt_seed(uint32_t *key, uint32_t s) {      // init_genrand: a serial recurrence, once per stream
+    for (int i = 0; i < kMtN; ++i) {
+        key[i] = s;
+        s = 1812433253u * (s ^ (s >> 30)) + (uint32_t)i + 1u;
+    }
+}
+
+// standard normals (legacy_gauss, numpy/random/src/legacy/legacy-distributions.c): a candidate of the polar method takes
+// exactly four draws and 624 = 4 x 156, so thread t < 156 examines candidate t of a block.
+template <int T>
+__global__ __launch_bounds__(T) void zgen_normal_kernel(const uint32_t *__restrict__ seeds, int64_t count,
+                                                        float *__restrict__ out, int64_t stride, int grp) {
+    __shared__ __attribute__((aligned(16))) uint32_t key[2][kMtN];
+    __shared__ double cx1[kZG * kMtN / 4], cx2[kZG * kMtN / 4], cr2[kZG * kMtN / 4];   // accepted candidates of a group
+    __shared__ int wcount[2][T / 64];        // accepted candidates per wave (two sets: one barrier per block serves both)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float *dst = out + (int64_t)blockIdx.x * stride;
-    if (tid == 0) {           // init_genrand: a serial recurrence, 624 steps once per stream
-        uint32_t s = seeds[blockIdx.x];
-        for (int i = 0; i < kMtN; ++i) {
-            key[i] = s;
-            s = 1812433253u * (s ^ (s >> 30)) + (uint32_t)i + 1u;
-        }
-    }
+    if (tid == 0) mt_seed(key[0], seeds[blockIdx.x]);
     __syncthreads();
+    mt_write_next<T>(key[0], key[1], tid);        // the first block of draws (the seeded state itself is never drawn from)
+    __syncthreads();
+    int cur = 1, par = 0;
     int64_t p = 0;
-    int par = 0;
     while (p < count) {
-        mt_next_block(key, tid);
-        if (kind == 0) {
-            // one candidate per thread (156 of the 256 have one)
-            const int j = tid;
-            const bool valid = j < kMtN / 4;
-            const uint4 w = *reinterpret_cast<const uint4 *>(key + 4 * (valid ? j : 0));
+        // `grp` blocks of the stream at a time.  Per block, between two barriers: examine the candidates of the current
+        // block, count the accepted ones per wave, AND write the next block; behind the barrier: rank the accepted ones in
+        // stream order (ballot / popcount + the per-wave counts) and park them in LDS.  The float64 log / divide / sqrt of
+        // legacy_gauss then run once per group on FULL waves (~490 accepted candidates of four blocks = 1.9 passes of 256
+        // threads; a pass per block left half of the lanes of its slowest wave idle).  A group ends early once it holds the
+        // pairs the stream still needs.  (Measured and dropped: sixteen waves per stream, 24.6 ms per stream against 22.5;
+        // per-wave LDS regions so that nothing behind the barrier waits for the other waves' counts, 29.7 ms - the search
+        // for a pair's region in the float64 pass costs more than the round trip it saves.)
+        const int64_t pairs_left = (count - p + 1) / 2;
+        int filled = 0;
+        for (int g = 0; g < grp && filled < pairs_left; ++g) {
+            const uint32_t *k = key[cur];
+            const bool valid = tid < kMtN / 4;
+            const uint4 w = *reinterpret_cast<const uint4 *>(k + 4 * (valid ? tid : 0));
             const double x1 = 2.0 * zmath::double53(zmath::temper(w.x), zmath::temper(w.y)) - 1.0;
             const double x2 = 2.0 * zmath::double53(zmath::temper(w.z), zmath::temper(w.w)) - 1.0;
             double r2;
@@ -92,50 +112,81 @@ __global__ __launch_bounds__(kZT) void zgen_device_kernel(const uint32_t *__rest
             }
             const bool acc = valid && r2 < 1.0 && r2 != 0.0;
             const unsigned long long mask = __ballot(acc);
-            if (lane == 0) wcount[par][wave] = __popcll(mask);
+            if (lane == 0 && wave < (kMtN / 4 + 63) / 64) wcount[par][wave] = __popcll(mask);
+            mt_write_next<T>(k, key[cur ^ 1], tid);
             __syncthreads();
+            cur ^= 1;
             int base = 0, total = 0;
+            constexpr int kCW = (kMtN / 4 + 63) / 64 < T / 64 ? (kMtN / 4 + 63) / 64 : T / 64;   // waves that hold candidates
 #pragma unroll
-            for (int v = 0; v < kZT / 64; ++v) {
+            for (int v = 0; v < kCW; ++v) {
                 const int c = wcount[par][v];
                 base += v < wave ? c : 0;
                 total += c;
             }
             par ^= 1;
-            const int rank = base + __popcll(mask & ((1ull << lane) - 1ull));
-            int64_t n = total;
-            const int64_t pairs_left = (count - p + 1) / 2;
-            if (n > pairs_left) n = pairs_left;
-            const bool half = 2 * n > count - p;       // odd count: the last pair gives only its first value
-            const int64_t whole = half ? n - 1 : n;
-            if (acc && rank < n) {
-                const double f = zmath::gauss_factor(r2);
-                float *q = dst + p + 2 * (int64_t)rank;
-                double a, b;
-                {
-#pragma clang fp contract(off)
-                    a = f * x2;
-                    b = f * x1;
-                }
-                q[0] = (float)a;
-                if (rank < whole) q[1] = (float)b;
+            if (acc) {
+                const int slot = filled + base + __popcll(mask & ((1ull << lane) - 1ull));
+                cx1[slot] = x1;
+                cx2[slot] = x2;
+                cr2[slot] = r2;
             }
-            p += 2 * whole + (half ? 1 : 0);
-        } else {
-            const int64_t n = count - p < kMtN / 2 ? count - p : kMtN / 2;
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const int j = tid + kZT * t;
-                if (j < n) {
-                    const uint2 w = *reinterpret_cast<const uint2 *>(key + 2 * j);
-                    const double u = zmath::double53(zmath::temper(w.x), zmath::temper(w.y));
-                    dst[p + j] = scale * (float)zmath::truncnorm_ppf_left(u, log_cdf_a, log_mass);
-                }
-            }
-            p += n;
+            filled += total;
         }
-        // (no barrier here: the next block's first write to key[] sits behind its own first barrier, i.e. behind every
-        //  thread's reads of this block's words)
+        __syncthreads();
+        int64_t n = filled;
+        if (n > pairs_left) n = pairs_left;
+        const bool half = 2 * n > count - p;       // odd count: the last pair gives only its first value
+        const int64_t whole = half ? n - 1 : n;
+        for (int idx = tid; idx < n; idx += T) {
+            const double f = zmath::gauss_factor(cr2[idx]);
+            double a, b;
+            {
+#pragma clang fp contract(off)
+                a = f * cx2[idx];                  // f x2 first, then the "cached" f x1
+                b = f * cx1[idx];
+            }
+            float *q = dst + p + 2 * (int64_t)idx;
+            if (idx < whole && (reinterpret_cast<uintptr_t>(q) & 7) == 0) {
+                *reinterpret_cast<float2 *>(q) = make_float2((float)a, (float)b);
+            } else {
+                q[0] = (float)a;
+                if (idx < whole) q[1] = (float)b;
+            }
+        }
+        p += 2 * whole + (half ? 1 : 0);
+        // (the next group parks its first candidates behind a barrier, i.e. behind every thread's reads here)
+    }
+}
+
+// scale * truncnorm(-2, 2): 312 uniforms per block (two draws each), one inverse CDF per value (log_cdf_a / log_mass as in
+// gs_zgen_start_truncnorm)
+__global__ __launch_bounds__(kZT) void zgen_truncnorm_kernel(const uint32_t *__restrict__ seeds, int64_t count,
+                                                             float *__restrict__ out, int64_t stride, double log_cdf_a,
+                                                             double log_mass, float scale) {
+    __shared__ __attribute__((aligned(16))) uint32_t key[2][kMtN];
+    const int tid = threadIdx.x;
+    float *dst = out + (int64_t)blockIdx.x * stride;
+    if (tid == 0) mt_seed(key[0], seeds[blockIdx.x]);
+    __syncthreads();
+    mt_write_next<kZT>(key[0], key[1], tid);
+    __syncthreads();
+    int cur = 1;
+    for (int64_t p = 0; p < count; p += kMtN / 2) {
+        const uint32_t *k = key[cur];
+        const int64_t n = count - p < kMtN / 2 ? count - p : kMtN / 2;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int j = tid + kZT * t;
+            if (j < n) {
+                const uint2 w = *reinterpret_cast<const uint2 *>(k + 2 * j);
+                const double u = zmath::double53(zmath::temper(w.x), zmath::temper(w.y));
+                dst[p + j] = scale * (float)zmath::truncnorm_ppf_left(u, log_cdf_a, log_mass);
+            }
+        }
+        mt_write_next<kZT>(k, key[cur ^ 1], tid);
+        __syncthreads();
+        cur ^= 1;
     }
 }
 
@@ -153,8 +204,17 @@ int gs_zgen_device(const uint32_t *seeds_dev, int64_t n_seeds, int64_t count, fl
                "gs_zgen_device: kind must be 0 (normals) or 1 (truncated normals, negative log-probabilities)");
     GS_REQUIRE(n_seeds < 2147483647, GS_EINVAL, "gs_zgen_device: too many seeds for one launch");
     if (n_seeds == 0 || count == 0) return GS_OK;
-    hipLaunchKernelGGL(zgen_device_kernel, dim3((unsigned)n_seeds), dim3(kZT), 0, (hipStream_t)stream, seeds_dev, count, out_dev,
-                       stride, kind, log_cdf_a, log_mass, scale);
+    int grp = kZG;
+    if (const char *g = gs_knob("GS_ZGEN_GROUP_BLOCKS")) {      // (measurement build: 1 = a pass of log / sqrt per block, as in round 5)
+        const int v = atoi(g);
+        if (v >= 1 && v <= kZG) grp = v;
+    }
+    if (kind == 0)
+        hipLaunchKernelGGL(zgen_normal_kernel<kZT>, dim3((unsigned)n_seeds), dim3(kZT), 0, (hipStream_t)stream, seeds_dev, count,
+                           out_dev, stride, grp);
+    else
+        hipLaunchKernelGGL(zgen_truncnorm_kernel, dim3((unsigned)n_seeds), dim3(kZT), 0, (hipStream_t)stream, seeds_dev, count,
+                           out_dev, stride, log_cdf_a, log_mass, scale);
     GS_HIP_CHECK(hipGetLastError());
     return GS_OK;
 }

@@ -450,7 +450,14 @@ class StyleGAN2(BaseModel):
     def sample_latent(self, n_samples=1, seed=None, truncation=None):
         if seed is None:
             seed = np.random.randint(np.iinfo(np.int32).max)  # use (reproducible) global rand state
+        if n_samples * 512 >= self.DEVICE_SAMPLE_VALUES and _zgen.device_generation_enabled(self.device):
+            # a long stream (the 5 000 fresh latents behind ``lat_stdev``, decomposition.py:326-329: 2.56 M normals, 60 ms of
+            # NumPy's serial legacy_gauss on the host) comes from the device generator, like the pre-sampled ones
+            (_, z), = _zgen.device_batches("stylegan", [seed], n_samples, 512, self.device)
+            return self.latent_from_z(z)
         return self.latent_from_z(_zgen.stylegan_z(seed, n_samples, 512))
+
+    DEVICE_SAMPLE_VALUES = 1 << 18      # shorter streams (interactive use: one latent) stay on NumPy's generator, bit for bit
 
     # host z -> primary latent on the device (W when w_primary); lets the driver generate z batches in
     # parallel worker processes while keeping the reference's seeding protocol bit for bit

@@ -35,7 +35,7 @@ def _check_rows(got, want):
     assert (d > 0).mean() <= 1e-5, int((d > 0).sum())
 
 
-@pytest.mark.parametrize("n,dim", [(37, 64), (3, 5), (1, 1), (1, 2), (61, 4), (1000, 512)])
+@pytest.mark.parametrize("n,dim", [(37, 64), (3, 5), (1, 1), (1, 2), (61, 4), (1000, 512), (4001, 129)])
 def test_device_normals_match_numpy_randomstate(dev, n, dim):
     from ganspace_amd import _zgen
     seeds = [0, 1, 12345, 2 ** 31 - 2, 987654321]
@@ -89,3 +89,20 @@ def test_presample_device_and_host_generators_agree(dev, monkeypatch):
     rel = np.abs(a - b).max(axis=1) / np.abs(b).max()
     assert (rel > 1e-5).mean() <= 1e-3 and rel.max() < 1e-3, (rel.max(), (rel > 1e-5).mean())
     inst.close()
+
+
+def test_long_sample_latent_streams_come_from_the_device_generator(dev, monkeypatch):
+    """``StyleGAN2.sample_latent`` (models/wrappers.py:167-174) with a long stream - the 5 000 fresh latents behind
+    ``lat_stdev`` - takes the device generator: same stream as NumPy's (isolated float32 values one ulp apart), and the host
+    generator is not called; a short one (one latent) stays on NumPy, bit for bit."""
+    from ganspace_amd import _zgen
+    from ganspace_amd.wrappers import StyleGAN2
+    model = StyleGAN2(dev, "car")                       # Z space: latent_from_z is the identity
+    n = model.DEVICE_SAMPLE_VALUES // 512 + 3
+    want = np.random.RandomState(77).standard_normal(n * 512).astype(np.float32).reshape(n, 512)
+    short = model.sample_latent(4, seed=77).cpu().numpy()
+    np.testing.assert_array_equal(short, np.random.RandomState(77).standard_normal(4 * 512).astype(np.float32).reshape(4, 512))
+    monkeypatch.setattr(_zgen, "stylegan_z", lambda *a, **k: pytest.fail("host generator called for a long stream"))
+    got = model.sample_latent(n, seed=77)
+    assert got.is_cuda and got.shape == (n, 512)
+    _check_rows(got.cpu().numpy(), want)

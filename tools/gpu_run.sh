@@ -12,6 +12,7 @@
 #   e2eprof:<job>[:n[:batch]]               the same under rocprofv3 --kernel-trace --stats    -> e2eprof_<job>_kernel_stats.csv
 #   py:<script>[:args...]                   python tools/<script> args (':'-separated)        -> <script>.log
 #   pyprof:<script>[:args...]               the same under rocprofv3 --kernel-trace --stats    -> <script>_kernel_stats.csv
+#   apiprof:<script>[:args...]              rocprofv3 --hip-trace --kernel-trace --stats       -> <script>_hip_api_stats.csv
 #   pmc:<counters '+'-joined>:<script>[:args...]   one rocprofv3 --pmc pass (never combined with other tracing domains)
 #   timeline                                rocprofv3 --kernel-trace of `bench.py --no-extras` -> job_timeline.md (tools/job_timeline.py)
 #   grampmc[:rows]                          FETCH_SIZE / WRITE_SIZE / SQ / LDS --pmc passes on tools/gram_probe.py (separate passes)
@@ -51,6 +52,23 @@ for step in "$@"; do
     pyprof)
       timeout 1500 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof_${a1%.py}" -o p -- python tools/$a1 ${rest//:/ } > "$O/${a1%.py}.log" 2>&1
       tail -20 "$O/${a1%.py}.log"; stats "$O/prof_${a1%.py}" "$O/${a1%.py}_kernel_stats.csv" ;;
+    apiprof)   # HIP API time per call name (where host-side milliseconds of a short job go): <script>_hip_api_stats.csv
+      timeout 1500 rocprofv3 --hip-trace --kernel-trace --stats --output-format csv -d "$O/api_${a1%.py}" -o p -- python tools/$a1 ${rest//:/ } > "$O/${a1%.py}.log" 2>&1
+      tail -8 "$O/${a1%.py}.log"
+      f=$(find "$O/api_${a1%.py}" -name '*hip_api_stats.csv' | head -1); [ -n "$f" ] && cp "$f" "$O/${a1%.py}_hip_api_stats.csv" && head -16 "$f"
+      # one timeline: every kernel and the HIP calls that took more than 0.1 ms, in time order (ms since the first call)
+      f=$(find "$O/api_${a1%.py}" -name '*hip_api_trace.csv' | head -1); g=$(find "$O/api_${a1%.py}" -name '*kernel_trace.csv' | head -1)
+      [ -n "$f" ] && [ -n "$g" ] && python - "$f" "$g" > "$O/${a1%.py}_hip_api_slow_calls.txt" <<'PYEOF'
+import csv, sys
+api = list(csv.DictReader(open(sys.argv[1]))); ker = list(csv.DictReader(open(sys.argv[2])))
+t0 = min(int(r["Start_Timestamp"]) for r in api)
+ev = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"]), "API    " + r["Function"]) for r in api
+      if int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) > 100_000]
+ev += [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"]), "kernel " + r["Kernel_Name"][:60]) for r in ker]
+for s, d, n in sorted(ev): print(f"{(s - t0) / 1e6:10.3f} ms  {d / 1e3:9.1f} us  {n}")
+PYEOF
+      tail -60 "$O/${a1%.py}_hip_api_slow_calls.txt"
+      stats "$O/api_${a1%.py}" "$O/${a1%.py}_kernel_stats.csv" > /dev/null ;;
     pmc)
       IFS=':' read -r script args <<< "$rest"
       timeout 1500 rocprofv3 --pmc ${a1//+/ } --kernel-trace --output-format csv -d "$O/pmc_${a1%%+*}" -o p -- python tools/$script ${args//:/ } > /dev/null 2>&1

@@ -8,8 +8,14 @@ lib = _lib.load()
 dev = torch.device("cuda", 0)
 n, dim = 10000, 512
 count = n * dim
-for kind, cnt in ((0, count), (1, 2000 * 128)):
-    for nseeds in (64, 128, 256, 384, 512, 768, 1024, 1536, 2048):
+# measurement build (GANSPACE_HIP_LIB=.../lib_measure/...): GS_ZGEN_GROUP_BLOCKS = blocks of 624 draws per pass of log / sqrt
+measure = "lib_measure" in os.environ.get("GANSPACE_HIP_LIB", "")
+variants = ["4", "2", "1"] if measure else [None]
+for kind, cnt, grp in [(0, count, g) for g in variants] + [(1, 2000 * 128, None)]:
+    if grp is not None:
+        os.environ["GS_ZGEN_GROUP_BLOCKS"] = grp
+        print(f"--- GS_ZGEN_GROUP_BLOCKS={grp}")
+    for nseeds in (101, 256, 512, 801, 1024, 2048):
         if nseeds * cnt * 4 > 60e9:
             continue
         seeds = torch.from_numpy(np.random.RandomState(1).randint(0, 2**31 - 1, size=nseeds).astype(np.int32)).to(dev)
