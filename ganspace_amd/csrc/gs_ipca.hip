@@ -785,7 +785,10 @@ int gs_ipca_create(int64_t d, int k, int mode, int precision, int device, gs_ipc
     h->prec = precision;
     h->device = device;
     h->n2 = (int)d;
-    if (hipStreamCreateWithFlags(&h->aux, hipStreamNonBlocking) != hipSuccess ||
+    // the private stream carries the faithful block chain (and the opt-in graph replays); an exact or small-side handle never
+    // leaves the caller's stream, and the first streams of a process cost 6-7 ms each (HSA queue set-up; tools/create_probe.py)
+    const bool wants_stream = mode == GS_MODE_FAITHFUL || gs_knob("GS_USE_GRAPHS") != nullptr;
+    if ((wants_stream && hipStreamCreateWithFlags(&h->aux, hipStreamNonBlocking) != hipSuccess) ||
         hipEventCreateWithFlags(&h->ev_in, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_out, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_gram, hipEventDisableTiming) != hipSuccess ||
