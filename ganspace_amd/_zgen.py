@@ -168,6 +168,47 @@ ZGEN_STAGING_FRACTION = 4         # quarter of the free device memory
 ZGEN_GROUP = 2048
 
 
+# One stream on many workgroups (gs_zgen_device_segmented): MT19937 jump-ahead polynomials for offsets of i * 2 048 blocks of
+# 624 draws (tools/make_mt_jump.py wrote the file and checked every polynomial against NumPy).  A launch of few, long streams
+# - cfg2: 101 streams of 5.12 M normals, 21 ms on 101 of the 256 CUs whatever else is idle - is cut into segments that run
+# side by side; launches of more than SEGMENT_MAX_STREAMS streams fill the chip as they are.
+JUMP_BLOCK_LEN = 2048
+SEGMENT_MAX_STREAMS = 512
+VALUES_PER_BLOCK = 2 * 156 * np.pi / 4        # 156 candidates of the polar method per block, accepted with probability pi / 4
+_JUMP_POLYS = {}
+
+
+def plan_segments(count: int) -> int:
+    """Segments of JUMP_BLOCK_LEN blocks that hold ``count`` normals of one stream with 0.4 % + 2 blocks to spare (the number
+    of accepted candidates of B blocks has a standard deviation of sqrt(26 B) pairs: 6 blocks' worth for the 20 900 blocks
+    of a 10 000 x 512 mini-batch); 1 = not worth cutting, 0 = longer than the polynomial file reaches."""
+    blocks = int(np.ceil(count / VALUES_PER_BLOCK * 1.004)) + 2
+    segments = -(-blocks // JUMP_BLOCK_LEN)
+    return segments if segments <= jump_polys_host().shape[0] + 1 else 0
+
+
+def jump_polys_host() -> np.ndarray:
+    if "host" not in _JUMP_POLYS:
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", f"mt19937_jump_L{JUMP_BLOCK_LEN}.npz")
+        with np.load(path) as f:
+            assert int(f["block_len"]) == JUMP_BLOCK_LEN
+            _JUMP_POLYS["host"] = np.ascontiguousarray(f["polys"], dtype=np.uint32)
+    return _JUMP_POLYS["host"]
+
+
+def _jump_polys_device(device):
+    import torch
+    key = str(torch.device(device))
+    if key not in _JUMP_POLYS:
+        _JUMP_POLYS[key] = torch.from_numpy(jump_polys_host().view(np.int32)).to(device)
+    return _JUMP_POLYS[key]
+
+
+def segmented_generation_enabled() -> bool:
+    """``GANSPACE_ZGEN_SEGMENTS=0`` keeps every stream on one workgroup (A/B timing)."""
+    return os.environ.get("GANSPACE_ZGEN_SEGMENTS", "1") != "0"
+
+
 def device_groups(kind: str, seeds, n: int, dim: int, device, truncation: float = 1.0, group: int = None, out=None):
     """Yield ``(lo, z)`` for ``seeds`` in order, ``z`` a ``[m, n, dim]`` float32 DEVICE tensor whose slice ``z[j]`` holds
     ``RandomState(seeds[lo + j]).standard_normal(n * dim)`` (``kind="stylegan"``) or BigGAN's
@@ -205,11 +246,31 @@ def device_groups(kind: str, seeds, n: int, dim: int, device, truncation: float 
         assert out.dtype == torch.float32 and out.is_contiguous() and out.numel() == len(seeds) * count and out.is_cuda
         out = out.view(len(seeds), int(n), int(dim))
     stream = _lib.current_stream_ptr()
+    segments = plan_segments(count) if (knd == 0 and segmented_generation_enabled()) else 1
     for lo in range(0, len(seeds), group):
         m = min(group, len(seeds) - lo)
         buf = out[lo:lo + m] if out is not None else torch.empty((m, int(n), int(dim)), dtype=torch.float32, device=device)
-        _lib.check(lib.gs_zgen_device(C.c_void_p(seeds_dev.data_ptr() + 4 * lo), m, count, C.c_void_p(buf.data_ptr()), count,
-                                      knd, la, lm, scale, stream))
+        done = False
+        if segments >= 2 and m <= SEGMENT_MAX_STREAMS:
+            nbytes = C.c_int64(0)
+            _lib.check(lib.gs_zgen_segmented_nbytes(m, segments, JUMP_BLOCK_LEN, C.cast(C.byref(nbytes), C.c_void_p)))
+            try:
+                room = torch.cuda.mem_get_info(device)[0] // 2
+            except Exception:
+                room = nbytes.value
+            if nbytes.value <= room:
+                scratch = torch.empty(nbytes.value, dtype=torch.uint8, device=device)
+                short = C.c_int(0)
+                _lib.check(lib.gs_zgen_device_segmented(C.c_void_p(seeds_dev.data_ptr() + 4 * lo), m, count,
+                                                        C.c_void_p(buf.data_ptr()), count,
+                                                        C.c_void_p(_jump_polys_device(device).data_ptr()), JUMP_BLOCK_LEN,
+                                                        segments, C.c_void_p(scratch.data_ptr()), nbytes.value,
+                                                        C.cast(C.byref(short), C.c_void_p), stream))
+                done = short.value == 0          # a stream short of accepted candidates (a 7-sigma event): serial path below
+                del scratch
+        if not done:
+            _lib.check(lib.gs_zgen_device(C.c_void_p(seeds_dev.data_ptr() + 4 * lo), m, count, C.c_void_p(buf.data_ptr()),
+                                          count, knd, la, lm, scale, stream))
         yield lo, buf
 
 

@@ -74,21 +74,34 @@ __device__ __forceinline__ void mt_seed(uint32_t *key, uint32_t s) {      // ini
 
 // standard normals (legacy_gauss, numpy/random/src/legacy/legacy-distributions.c): a candidate of the polar method takes
 // exactly four draws and 624 = 4 x 156, so thread t < 156 examines candidate t of a block.
-template <int T>
+// SEG: the stream is cut into `segs` segments of `seg_blocks` blocks (see mt_jump_kernel below); workgroup b walks segment
+// b % segs of stream b / segs from the state block the jump kernel left in `states` (segment 0: from the seed), writes the
+// pairs of ALL its blocks to its own slice of `out` (stride = slice length) and their number to counts[b]; where a pair
+// belongs in the stream is only known once the segments before it are counted (zgen_compact_kernel).
+template <int T, bool SEG>
 __global__ __launch_bounds__(T) void zgen_normal_kernel(const uint32_t *__restrict__ seeds, int64_t count,
-                                                        float *__restrict__ out, int64_t stride, int grp) {
+                                                        float *__restrict__ out, int64_t stride, int grp,
+                                                        const uint32_t *__restrict__ states, int segs, int seg_blocks,
+                                                        int *__restrict__ counts) {
     __shared__ __attribute__((aligned(16))) uint32_t key[2][kMtN];
     __shared__ double cx1[kZG * kMtN / 4], cx2[kZG * kMtN / 4], cr2[kZG * kMtN / 4];   // accepted candidates of a group
     __shared__ int wcount[2][T / 64];        // accepted candidates per wave (two sets: one barrier per block serves both)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float *dst = out + (int64_t)blockIdx.x * stride;
-    if (tid == 0) mt_seed(key[0], seeds[blockIdx.x]);
+    const int seg = SEG ? (int)(blockIdx.x % (unsigned)segs) : 0;
+    if (SEG && seg > 0) {
+        const uint32_t *st = states + (int64_t)blockIdx.x * kMtN;
+        for (int i = tid; i < kMtN; i += T) key[1][i] = st[i];
+    } else {
+        if (tid == 0) mt_seed(key[0], seeds[SEG ? blockIdx.x / (unsigned)segs : blockIdx.x]);
+        __syncthreads();
+        mt_write_next<T>(key[0], key[1], tid);    // the first block of draws (the seeded state itself is never drawn from)
+    }
     __syncthreads();
-    mt_write_next<T>(key[0], key[1], tid);        // the first block of draws (the seeded state itself is never drawn from)
-    __syncthreads();
+    int blocks_left = SEG ? seg_blocks : 0;
     int cur = 1, par = 0;
     int64_t p = 0;
-    while (p < count) {
+    while (SEG ? blocks_left > 0 : p < count) {
         // `grp` blocks of the stream at a time.  Per block, between two barriers: examine the candidates of the current
         // block, count the accepted ones per wave, AND write the next block; behind the barrier: rank the accepted ones in
         // stream order (ballot / popcount + the per-wave counts) and park them in LDS.  The float64 log / divide / sqrt of
@@ -97,9 +110,11 @@ __global__ __launch_bounds__(T) void zgen_normal_kernel(const uint32_t *__restri
         // pairs the stream still needs.  (Measured and dropped: sixteen waves per stream, 24.6 ms per stream against 22.5;
         // per-wave LDS regions so that nothing behind the barrier waits for the other waves' counts, 29.7 ms - the search
         // for a pair's region in the float64 pass costs more than the round trip it saves.)
-        const int64_t pairs_left = (count - p + 1) / 2;
+        const int64_t pairs_left = SEG ? (int64_t)1 << 40 : (count - p + 1) / 2;
+        const int gmax = SEG && blocks_left < grp ? blocks_left : grp;
+        if (SEG) blocks_left -= gmax;
         int filled = 0;
-        for (int g = 0; g < grp && filled < pairs_left; ++g) {
+        for (int g = 0; g < gmax && filled < pairs_left; ++g) {
             const uint32_t *k = key[cur];
             const bool valid = tid < kMtN / 4;
             const uint4 w = *reinterpret_cast<const uint4 *>(k + 4 * (valid ? tid : 0));
@@ -136,7 +151,7 @@ __global__ __launch_bounds__(T) void zgen_normal_kernel(const uint32_t *__restri
         __syncthreads();
         int64_t n = filled;
         if (n > pairs_left) n = pairs_left;
-        const bool half = 2 * n > count - p;       // odd count: the last pair gives only its first value
+        const bool half = !SEG && 2 * n > count - p;       // odd count: the last pair gives only its first value
         const int64_t whole = half ? n - 1 : n;
         for (int idx = tid; idx < n; idx += T) {
             const double f = zmath::gauss_factor(cr2[idx]);
@@ -156,6 +171,93 @@ __global__ __launch_bounds__(T) void zgen_normal_kernel(const uint32_t *__restri
         }
         p += 2 * whole + (half ? 1 : 0);
         // (the next group parks its first candidates behind a barrier, i.e. behind every thread's reads here)
+    }
+    if (SEG && tid == 0) counts[blockIdx.x] = (int)p;
+}
+
+// ---- one stream on many workgroups -------------------------------------------------------------------------------------
+// A stream is serial: 20 900 dependent blocks of ~1 us for the 5.12 M normals of one mini-batch, whatever the number of
+// streams in the launch - 21 ms for the 101 streams of cfg2 on 101 of 256 CUs.  MT19937 is F2-linear, so the state after
+// J draws is a fixed XOR-combination of the first 19937 + 624 state words of the stream: with c(x) = x^J mod phi(x) (phi:
+// the characteristic polynomial of the word recurrence; tools/make_mt_jump.py derives it from the generator and checks every
+// c against NumPy),  w[J + n] = XOR over the set bits k of c of w[k + n].  The polynomials depend on J only: the data file
+// holds c for J = i * L * 624, i = 1 .. 63, L = 2 048 blocks.  Per (stream, segment i >= 1) one workgroup builds the first 33
+// blocks of the stream in LDS (82 KB) and XORs ~10 000 windows of 624 words: ~0.1 ms, against the 2 ms the segment then runs.
+constexpr int kJumpBlocks = (19937 + kMtN + kMtN - 1) / kMtN;      // 33 blocks hold every window
+constexpr int kJT = 1024;
+
+__global__ __launch_bounds__(kJT) void mt_jump_kernel(const uint32_t *__restrict__ seeds, const uint32_t *__restrict__ polys,
+                                                      int segs, uint32_t *__restrict__ states) {
+    __shared__ uint32_t seeded[kMtN];
+    __shared__ uint32_t w[(kJumpBlocks + 1) * kMtN];          // 33 blocks of the stream, then 624 zeros
+    const int tid = threadIdx.x;
+    const unsigned stream = blockIdx.x / (unsigned)(segs - 1), seg = 1 + blockIdx.x % (unsigned)(segs - 1);
+    if (tid == 0) mt_seed(seeded, seeds[stream]);
+    if (tid < kMtN) w[kJumpBlocks * kMtN + tid] = 0u;
+    __syncthreads();
+    mt_write_next<kJT>(seeded, w, tid);
+    __syncthreads();
+    for (int b = 1; b < kJumpBlocks; ++b) {
+        mt_write_next<kJT>(w + (b - 1) * kMtN, w + b * kMtN, tid);
+        __syncthreads();
+    }
+    const uint32_t *c = polys + (int64_t)(seg - 1) * kMtN;
+    uint32_t r = 0;
+    const int n = tid < kMtN ? tid : 0;
+    const int lane = tid & 63;
+    if (tid < kMtN + 64 - kMtN % 64) {            // (the waves that hold a word of the state)
+        for (int w0 = 0; w0 < kMtN; w0 += 64) {
+            // 64 words of the polynomial per wave register (lane l holds word w0 + l), handed out with v_readlane: the walk
+            // over the set bits is scalar code with no memory access of its own.  Eight windows per step - positions past
+            // the last set bit of a word point at the block of zeros behind w - so that eight LDS reads are in flight.
+            const uint32_t cv = w0 + lane < kMtN ? c[w0 + lane] : 0u;
+            const int wn = kMtN - w0 < 64 ? kMtN - w0 : 64;
+            for (int j = 0; j < wn; ++j) {
+                uint32_t bits = __builtin_amdgcn_readlane(cv, j);
+                const int base = (w0 + j) * 32;
+                while (bits) {
+                    int k[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        k[u] = bits ? base + __builtin_ctz(bits) : kJumpBlocks * kMtN;
+                        bits &= bits - 1;
+                    }
+                    uint32_t v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) v[u] = w[k[u] + n];
+                    r ^= ((v[0] ^ v[1]) ^ (v[2] ^ v[3])) ^ ((v[4] ^ v[5]) ^ (v[6] ^ v[7]));
+                }
+            }
+        }
+    }
+    if (tid < kMtN) states[((int64_t)stream * segs + seg) * kMtN + tid] = r;
+}
+
+// the pairs of segment `seg` of stream `s` go behind those of its earlier segments; the stream ends at `count` values (an odd
+// count cuts the last pair in two, as legacy_gauss's cached second value would have been left unused).  A stream whose
+// segments together hold fewer than `count` values raises *shortfall (the caller regenerates it serially; with the 0.4 %
+// of spare blocks the caller plans, that is a 7-sigma event).
+__global__ __launch_bounds__(256) void zgen_compact_kernel(const float *__restrict__ staging, int64_t cap,
+                                                           const int *__restrict__ counts, int segs, int64_t count,
+                                                           float *__restrict__ out, int64_t stride, int *shortfall) {
+    const unsigned s = blockIdx.z, seg = blockIdx.y;
+    int64_t off = 0;
+    for (unsigned j = 0; j < seg; ++j) off += counts[(int64_t)s * segs + j];
+    const int64_t avail = counts[(int64_t)s * segs + seg];
+    int64_t n = count - off;
+    if (n > avail) n = avail;
+    if (seg + 1 == (unsigned)segs && blockIdx.x == 0 && threadIdx.x == 0 && off + avail < count) atomicOr(shortfall, 1);
+    if (n <= 0) return;
+    const float *src = staging + ((int64_t)s * segs + seg) * cap;
+    float *dst = out + (int64_t)s * stride + off;
+    const int64_t step = (int64_t)gridDim.x * 256;
+    if ((reinterpret_cast<uintptr_t>(dst) & 15) == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0) {
+        const int64_t n4 = n / 4;
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += step)
+            reinterpret_cast<float4 *>(dst)[i] = reinterpret_cast<const float4 *>(src)[i];
+        for (int64_t i = 4 * n4 + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += step) dst[i] = src[i];
+    } else {
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += step) dst[i] = src[i];
     }
 }
 
@@ -210,12 +312,53 @@ int gs_zgen_device(const uint32_t *seeds_dev, int64_t n_seeds, int64_t count, fl
         if (v >= 1 && v <= kZG) grp = v;
     }
     if (kind == 0)
-        hipLaunchKernelGGL(zgen_normal_kernel<kZT>, dim3((unsigned)n_seeds), dim3(kZT), 0, (hipStream_t)stream, seeds_dev, count,
-                           out_dev, stride, grp);
+        hipLaunchKernelGGL((zgen_normal_kernel<kZT, false>), dim3((unsigned)n_seeds), dim3(kZT), 0, (hipStream_t)stream, seeds_dev,
+                           count, out_dev, stride, grp, (const uint32_t *)nullptr, 1, 0, (int *)nullptr);
     else
         hipLaunchKernelGGL(zgen_truncnorm_kernel, dim3((unsigned)n_seeds), dim3(kZT), 0, (hipStream_t)stream, seeds_dev, count,
                            out_dev, stride, log_cdf_a, log_mass, scale);
     GS_HIP_CHECK(hipGetLastError());
+    return GS_OK;
+}
+
+static int64_t seg_cap(int block_len) { return (int64_t)block_len * (kMtN / 2); }      // every candidate accepted: 312 values per block
+
+int gs_zgen_segmented_nbytes(int64_t n_seeds, int segments, int block_len, int64_t *nbytes) {
+    GS_REQUIRE(nbytes && n_seeds >= 0 && segments >= 2 && block_len >= 1, GS_EINVAL, "gs_zgen_segmented_nbytes: bad argument");
+    const int64_t units = n_seeds * segments;
+    *nbytes = round_up(units * kMtN * 4, 256) + round_up(units * 4 + 4, 256) + units * seg_cap(block_len) * 4;
+    return GS_OK;
+}
+
+int gs_zgen_device_segmented(const uint32_t *seeds_dev, int64_t n_seeds, int64_t count, float *out_dev, int64_t stride,
+                             const uint32_t *polys_dev, int block_len, int segments, void *scratch, int64_t scratch_bytes,
+                             int *shortfall_host, void *stream_) {
+    GS_REQUIRE(seeds_dev && out_dev && polys_dev && scratch && shortfall_host && n_seeds >= 0 && count >= 0 && stride >= count,
+               GS_EINVAL, "gs_zgen_device_segmented: bad argument");
+    GS_REQUIRE(segments >= 2 && block_len >= 1 && n_seeds * segments < 2147483647 && n_seeds < 65536, GS_EINVAL,
+               "gs_zgen_device_segmented: segments >= 2, fewer than 65 536 streams per call");
+    int64_t need = 0;
+    (void)gs_zgen_segmented_nbytes(n_seeds, segments, block_len, &need);
+    GS_REQUIRE(scratch_bytes >= need, GS_EINVAL, "gs_zgen_device_segmented: scratch smaller than gs_zgen_segmented_nbytes");
+    *shortfall_host = 0;
+    if (n_seeds == 0 || count == 0) return GS_OK;
+    hipStream_t stream = (hipStream_t)stream_;
+    const int64_t units = n_seeds * segments, cap = seg_cap(block_len);
+    char *base = static_cast<char *>(scratch);
+    uint32_t *states = reinterpret_cast<uint32_t *>(base);
+    int *counts = reinterpret_cast<int *>(base + round_up(units * kMtN * 4, 256));
+    int *flag = counts + units;
+    float *staging = reinterpret_cast<float *>(base + round_up(units * kMtN * 4, 256) + round_up(units * 4 + 4, 256));
+    GS_HIP_CHECK(hipMemsetAsync(flag, 0, sizeof(int), stream));
+    hipLaunchKernelGGL(mt_jump_kernel, dim3((unsigned)(n_seeds * (segments - 1))), dim3(kJT), 0, stream, seeds_dev, polys_dev,
+                       segments, states);
+    hipLaunchKernelGGL((zgen_normal_kernel<kZT, true>), dim3((unsigned)units), dim3(kZT), 0, stream, seeds_dev, count, staging,
+                       cap, kZG, states, segments, block_len, counts);
+    hipLaunchKernelGGL(zgen_compact_kernel, dim3(32, (unsigned)segments, (unsigned)n_seeds), dim3(256), 0, stream, staging, cap,
+                       counts, segments, count, out_dev, stride, flag);
+    GS_HIP_CHECK(hipGetLastError());
+    GS_HIP_CHECK(hipMemcpyAsync(shortfall_host, flag, sizeof(int), hipMemcpyDeviceToHost, stream));
+    GS_HIP_CHECK(hipStreamSynchronize(stream));
     return GS_OK;
 }
 

@@ -292,6 +292,19 @@ int gs_zgen_device(const uint32_t *seeds_dev, int64_t n_seeds, int64_t count, fl
                    int64_t stride, int kind, double log_cdf_a, double log_mass, float scale,
                    void *stream);
 
+/* The same normals with every stream cut into `segments` segments of `block_len` blocks of 624 draws, each on its own
+ * workgroup: MT19937 jump-ahead by the polynomials x^(i * block_len * 624) mod phi (polys_dev: uint32 [>= segments - 1][624],
+ * ganspace_amd/data/mt19937_jump_L<block_len>.npz, written and checked against NumPy by tools/make_mt_jump.py), then a
+ * compaction pass that puts the pairs of a segment behind those of the segments before it.  Replaces the serial
+ * RandomState(seed).standard_normal(n * dim) of models/wrappers.py:167-174 for launches with few, long streams (cfg2: 101
+ * streams of 5.12 M normals).  The caller plans `segments` so that segments * block_len blocks hold `count` values with a
+ * margin; *shortfall_host != 0 on return says a stream ran short (regenerate with gs_zgen_device).  Synchronises `stream`.
+ * scratch: gs_zgen_segmented_nbytes bytes of device memory. */
+int gs_zgen_segmented_nbytes(int64_t n_seeds, int segments, int block_len, int64_t *nbytes);
+int gs_zgen_device_segmented(const uint32_t *seeds_dev, int64_t n_seeds, int64_t count, float *out_dev, int64_t stride,
+                             const uint32_t *polys_dev, int block_len, int segments, void *scratch, int64_t scratch_bytes,
+                             int *shortfall_host, void *stream);
+
 /* z -> w: the StyleGAN2 mapping network `Generator.style` called from
  * models/wrappers.py:177,200 (PixelNorm + L x EqualLinear(dim, dim, lr_mul,
  * activation='fused_lrelu')); in-tree analogue models/stylegan/model.py:190-216.

@@ -106,3 +106,56 @@ def test_long_sample_latent_streams_come_from_the_device_generator(dev, monkeypa
     got = model.sample_latent(n, seed=77)
     assert got.is_cuda and got.shape == (n, 512)
     _check_rows(got.cpu().numpy(), want)
+
+
+def test_streams_cut_into_segments_equal_the_serial_streams_bit_for_bit(dev, monkeypatch):
+    """Few, long streams are cut into segments of 2 048 blocks that start from jumped-ahead MT19937 states
+    (gs_zgen_device_segmented; polynomials from ganspace_amd/data, checked against NumPy in the CPU suite).  Same arithmetic
+    per value as the one-workgroup-per-stream kernel: the rows are BIT-identical to it, whatever the number of segments, for
+    even and odd lengths, into a caller's array as well - and equal to NumPy up to the usual isolated float32 ulp."""
+    from ganspace_amd import _zgen
+    seeds = [5, 77, 2 ** 31 - 3]
+    for n, dim in [(2500, 512), (1000, 513), (10_000, 512)]:        # 3, 2 and 11 segments
+        count = n * dim
+        assert _zgen.plan_segments(count) >= 2
+        monkeypatch.setenv("GANSPACE_ZGEN_SEGMENTS", "0")
+        serial = [z.clone() for _, z in _zgen.device_batches("stylegan", seeds, n, dim, dev)]
+        monkeypatch.setenv("GANSPACE_ZGEN_SEGMENTS", "1")
+        out = torch.full((len(seeds), n, dim), float("nan"), device=dev)
+        cut = [z for _, z in _zgen.device_groups("stylegan", seeds, n, dim, dev, out=out)]
+        assert len(cut) == 1 and cut[0].data_ptr() == out.data_ptr()
+        for i, s in enumerate(seeds):
+            assert torch.equal(out[i], serial[i]), (n, dim, s)
+        _check_rows(out[1].cpu().numpy(), np.random.RandomState(seeds[1]).standard_normal(count).astype(np.float32).reshape(n, dim))
+    # an odd number of values per stream: the last pair is cut in two
+    n, dim = 1501, 333
+    assert (n * dim) % 2 == 1 and _zgen.plan_segments(n * dim) >= 2
+    got = {i: z.cpu().numpy() for i, z in _zgen.device_batches("stylegan", seeds, n, dim, dev)}
+    for i, s in enumerate(seeds):
+        _check_rows(got[i], np.random.RandomState(s).standard_normal(n * dim).astype(np.float32).reshape(n, dim))
+
+
+def test_segmented_generator_reports_a_stream_that_ran_short(dev):
+    """Two segments of 2 048 blocks hold about a million normals: asked for 1.2 M, the call must say so (the caller then
+    takes the serial kernel) instead of leaving the tail of the row unwritten."""
+    import ctypes as C
+    from ganspace_amd import _lib, _zgen
+    lib = _lib.load()
+    count = 1_200_000
+    seeds = torch.tensor([3, 4], dtype=torch.int32, device=dev)
+    out = torch.empty((2, count), device=dev)
+    nbytes = C.c_int64(0)
+    _lib.check(lib.gs_zgen_segmented_nbytes(2, 2, _zgen.JUMP_BLOCK_LEN, C.cast(C.byref(nbytes), C.c_void_p)))
+    scratch = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
+    polys = torch.from_numpy(_zgen.jump_polys_host().view(np.int32)).to(dev)
+    short = C.c_int(0)
+    _lib.check(lib.gs_zgen_device_segmented(C.c_void_p(seeds.data_ptr()), 2, count, C.c_void_p(out.data_ptr()), count,
+                                            C.c_void_p(polys.data_ptr()), _zgen.JUMP_BLOCK_LEN, 2, C.c_void_p(scratch.data_ptr()),
+                                            nbytes.value, C.cast(C.byref(short), C.c_void_p), _lib.current_stream_ptr()))
+    assert short.value == 1
+    short.value = 7
+    _lib.check(lib.gs_zgen_device_segmented(C.c_void_p(seeds.data_ptr()), 2, 900_000, C.c_void_p(out.data_ptr()), count,
+                                            C.c_void_p(polys.data_ptr()), _zgen.JUMP_BLOCK_LEN, 2, C.c_void_p(scratch.data_ptr()),
+                                            nbytes.value, C.cast(C.byref(short), C.c_void_p), _lib.current_stream_ptr()))
+    assert short.value == 0
+    _check_rows(out[1, :900_000].cpu().numpy(), np.random.RandomState(4).standard_normal(900_000).astype(np.float32))

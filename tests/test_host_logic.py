@@ -367,3 +367,36 @@ def test_bench_builds_the_launcher_line_for_multi_gpu_runs():
     assert cmd[i + 1:] == ["--gpus", "8", "--steps", "20", "--warmup", "5"]
     auto = bench.launcher_command([], 2)                       # a free port is picked when none is given
     assert 1024 <= int(auto[auto.index("--master-port") + 1]) <= 65535
+
+
+def test_mt19937_jump_polynomials_reach_the_states_numpy_reaches():
+    """ganspace_amd/data/mt19937_jump_L2048.npz (tools/make_mt_jump.py): polynomial i is x^(i * 2048 * 624) mod phi, and the
+    state block of a stream at that offset is the XOR of the windows words[k : k + 624] of its first 33 blocks over the set
+    bits k - checked here against the state ``RandomState(seed)`` has after that many draws.  Also the segment plan: enough
+    blocks for the values asked for, with the margin the generator relies on."""
+    from ganspace_amd import _zgen
+    polys = _zgen.jump_polys_host()
+    L = _zgen.JUMP_BLOCK_LEN
+    assert polys.shape == (63, 624) and polys.dtype == np.uint32
+    assert (polys[:, 623] >> 1 == 0).all()                       # degree < 19937: bits 19937 .. 19967 are clear
+    seed = 424242
+    rs = np.random.RandomState(seed)
+    words = []
+    for _ in range(33):
+        rs.random_sample(312)                                    # 624 draws = one block of state words
+        words.append(np.array(rs.get_state()[1], dtype=np.uint32))
+    words = np.concatenate(words)
+    for i in (1, 2, 17):
+        ks = np.nonzero(np.unpackbits(polys[i - 1].view(np.uint8), bitorder="little")[:19937])[0]
+        got = np.zeros(624, dtype=np.uint32)
+        for lo in range(0, len(ks), 2048):
+            got ^= np.bitwise_xor.reduce(words[ks[lo:lo + 2048, None] + np.arange(624)[None, :]], axis=0)
+        ref = np.random.RandomState(seed)
+        ref.random_sample((i * L + 1) * 312)
+        np.testing.assert_array_equal(got, np.array(ref.get_state()[1], dtype=np.uint32))
+    for count in (40_960, 512_000, 2_560_000, 5_120_000, 15_000_000):
+        s = _zgen.plan_segments(count)
+        assert s >= 1 and s * L * _zgen.VALUES_PER_BLOCK >= count * 1.004
+        assert (s - 1) * L * _zgen.VALUES_PER_BLOCK < count * 1.004 + 3 * _zgen.VALUES_PER_BLOCK
+    assert _zgen.plan_segments(40_960) == 1 and _zgen.plan_segments(5_120_000) == 11
+    assert _zgen.plan_segments(64 * L * 250) == 0                # beyond the file: the serial kernel takes it
