@@ -182,18 +182,18 @@ __global__ __launch_bounds__(T) void zgen_normal_kernel(const uint32_t *__restri
 // the characteristic polynomial of the word recurrence; tools/make_mt_jump.py derives it from the generator and checks every
 // c against NumPy),  w[J + n] = XOR over the set bits k of c of w[k + n].  The polynomials depend on J only: the data file
 // holds c for J = i * L * 624, i = 1 .. 63, L = 2 048 blocks.  Per (stream, segment i >= 1) one workgroup builds the first 33
-// blocks of the stream in LDS (82 KB) and XORs ~10 000 windows of 624 words: ~0.1 ms, against the 2 ms the segment then runs.
+// blocks of the stream in LDS (82 KB) and XORs ~10 000 windows of 624 words: 0.1-0.2 ms, against the 2-4 ms the segment then runs.
 constexpr int kJumpBlocks = (19937 + kMtN + kMtN - 1) / kMtN;      // 33 blocks hold every window
 constexpr int kJT = 1024;
 
 __global__ __launch_bounds__(kJT) void mt_jump_kernel(const uint32_t *__restrict__ seeds, const uint32_t *__restrict__ polys,
                                                       int segs, uint32_t *__restrict__ states) {
     __shared__ uint32_t seeded[kMtN];
-    __shared__ uint32_t w[(kJumpBlocks + 1) * kMtN];          // 33 blocks of the stream, then 624 zeros
+    __shared__ uint32_t w[kJumpBlocks * kMtN];                // the first 33 blocks of the stream
+    __shared__ uint32_t part[kJT / 64][640];
     const int tid = threadIdx.x;
     const unsigned stream = blockIdx.x / (unsigned)(segs - 1), seg = 1 + blockIdx.x % (unsigned)(segs - 1);
     if (tid == 0) mt_seed(seeded, seeds[stream]);
-    if (tid < kMtN) w[kJumpBlocks * kMtN + tid] = 0u;
     __syncthreads();
     mt_write_next<kJT>(seeded, w, tid);
     __syncthreads();
@@ -201,34 +201,33 @@ __global__ __launch_bounds__(kJT) void mt_jump_kernel(const uint32_t *__restrict
         mt_write_next<kJT>(w + (b - 1) * kMtN, w + b * kMtN, tid);
         __syncthreads();
     }
+    // Each of the 16 waves takes every 16th word of the polynomial and XORs the windows of ITS set bits for all 624 state
+    // words (lane l holds words l, l + 64, ..., l + 576: ten LDS reads with immediate offsets per set bit, so the scalar walk
+    // over the bits is paid once per ten words and ten reads are in flight); the 16 partial states meet in LDS.
     const uint32_t *c = polys + (int64_t)(seg - 1) * kMtN;
-    uint32_t r = 0;
-    const int n = tid < kMtN ? tid : 0;
-    const int lane = tid & 63;
-    if (tid < kMtN + 64 - kMtN % 64) {            // (the waves that hold a word of the state)
-        for (int w0 = 0; w0 < kMtN; w0 += 64) {
-            // 64 words of the polynomial per wave register (lane l holds word w0 + l), handed out with v_readlane: the walk
-            // over the set bits is scalar code with no memory access of its own.  Eight windows per step - positions past
-            // the last set bit of a word point at the block of zeros behind w - so that eight LDS reads are in flight.
-            const uint32_t cv = w0 + lane < kMtN ? c[w0 + lane] : 0u;
-            const int wn = kMtN - w0 < 64 ? kMtN - w0 : 64;
-            for (int j = 0; j < wn; ++j) {
-                uint32_t bits = __builtin_amdgcn_readlane(cv, j);
-                const int base = (w0 + j) * 32;
-                while (bits) {
-                    int k[8];
+    const int lane = tid & 63, wave = tid >> 6;
+    constexpr int kPW = kMtN / 16;                             // 39 polynomial words per wave
+    const uint32_t cv = lane < kPW ? c[wave + 16 * lane] : 0u;     // lane j holds word wave + 16 j
+    uint32_t rq[10];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        k[u] = bits ? base + __builtin_ctz(bits) : kJumpBlocks * kMtN;
-                        bits &= bits - 1;
-                    }
-                    uint32_t v[8];
+    for (int q = 0; q < 10; ++q) rq[q] = 0u;
+    for (int j = 0; j < kPW; ++j) {
+        uint32_t bits = __builtin_amdgcn_readlane(cv, j);
+        const int base = (wave + 16 * j) * 32;
+        while (bits) {
+            const uint32_t *p = w + base + __builtin_ctz(bits) + lane;
+            bits &= bits - 1;
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) v[u] = w[k[u] + n];
-                    r ^= ((v[0] ^ v[1]) ^ (v[2] ^ v[3])) ^ ((v[4] ^ v[5]) ^ (v[6] ^ v[7]));
-                }
-            }
+            for (int q = 0; q < 10; ++q) rq[q] ^= p[64 * q];
         }
+    }
+#pragma unroll
+    for (int q = 0; q < 10; ++q) part[wave][lane + 64 * q] = rq[q];
+    __syncthreads();
+    uint32_t r = 0;
+    if (tid < kMtN) {
+#pragma unroll
+        for (int v = 0; v < 16; ++v) r ^= part[v][tid];
     }
     if (tid < kMtN) states[((int64_t)stream * segs + seg) * kMtN + tid] = r;
 }

@@ -5,6 +5,7 @@ the command the rocprofv3 kernel traces under profiles/ are taken of.
     python tools/e2e_job.py cfg5 [n] [batch]      StyleGAN2 convs.2          (d = 131 072)
     python tools/e2e_job.py cfg2 [n] [batch]      StyleGAN2 W space, ipca-exact (d = 512; cfg2f: the faithful `ipca`)
     python tools/e2e_job.py cfg4 [n] [batch]      StyleGAN2-car Z space --layer=style, n = 8e6, ipca-exact (cfg4f: `ipca`)
+GS_E2E_PROFILE=0: wall time only (the phase timers synchronise the device between phases; without them the host runs ahead).
 """
 import contextlib, json, os, shutil, sys, tempfile, time
 from types import SimpleNamespace
@@ -37,7 +38,7 @@ run_dir = tempfile.mkdtemp(prefix="gs_e2e_")
 try:
     inst = get_instrumented_model(cfg.model, cfg.output_class, cfg.layer, dev, **({"use_w": True} if kw.get("use_w") else {}))
     torch.cuda.synchronize()
-    dec.PROFILE = True
+    dec.PROFILE = os.environ.get("GS_E2E_PROFILE", "1") != "0"     # 0: no phase timers, i.e. no synchronisation between the phases
     t0 = time.perf_counter()
     with contextlib.redirect_stdout(sys.stderr):
         dec.get_or_compute(cfg, inst, submit_config=SimpleNamespace(run_dir_root=run_dir, run_dir=run_dir))

@@ -9,6 +9,7 @@
 #   bench[:<extra flags>]                   python bench.py <flags>                            -> bench.json / bench.err
 #   benchprof[:<extra flags>]               rocprofv3 --kernel-trace --stats of bench.py       -> benchprof_kernel_stats.csv
 #   e2e:<job>[:n[:batch]]                   tools/e2e_job.py <job> (cfg2 cfg2f cfg3 cfg4 cfg4f cfg5) -> e2e_<job>.json
+#   e2ewall:<job>[:n[:batch]]               the same without the phase timers (no synchronisation between phases) -> e2ewall_<job>.json
 #   e2eprof:<job>[:n[:batch]]               the same under rocprofv3 --kernel-trace --stats    -> e2eprof_<job>_kernel_stats.csv
 #   py:<script>[:args...]                   python tools/<script> args (':'-separated)        -> <script>.log
 #   pyprof:<script>[:args...]               the same under rocprofv3 --kernel-trace --stats    -> <script>_kernel_stats.csv
@@ -45,6 +46,7 @@ for step in "$@"; do
       timeout 1500 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/benchprof" -o b -- python bench.py ${a1:-} ${rest//:/ } > "$O/benchprof.json" 2> "$O/benchprof.err"
       stats "$O/benchprof" "$O/benchprof_kernel_stats.csv" ;;
     e2e) timeout 1500 python tools/e2e_job.py $a1 ${rest//:/ } > "$O/e2e_$a1.json" 2> "$O/e2e_$a1.err"; cat "$O/e2e_$a1.json" ;;
+    e2ewall) GS_E2E_PROFILE=0 timeout 1500 python tools/e2e_job.py $a1 ${rest//:/ } > "$O/e2ewall_$a1.json" 2> "$O/e2ewall_$a1.err"; cat "$O/e2ewall_$a1.json" ;;
     e2eprof)
       timeout 1500 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/e2eprof_$a1" -o e -- python tools/e2e_job.py $a1 ${rest//:/ } > "$O/e2eprof_$a1.json" 2> "$O/e2eprof_$a1.err"
       cat "$O/e2eprof_$a1.json"; stats "$O/e2eprof_$a1" "$O/e2eprof_${a1}_kernel_stats.csv" ;;

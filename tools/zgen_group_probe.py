@@ -31,3 +31,20 @@ for kind, cnt, grp in [(0, count, g) for g in variants] + [(1, 2000 * 128, None)
         print(f"kind {kind} count {cnt}: {nseeds:5d} seeds in one launch: {best*1e3:7.2f} ms  = {best/nseeds*1e3:.3f} ms per seed, "
               f"{nseeds*cnt/best/1e9:.1f} G values/s", flush=True)
         del buf
+
+# few, long streams: every stream on one workgroup against streams cut into segments (gs_zgen_device_segmented)
+from ganspace_amd import _zgen
+for nseeds, rows in ((101, 10000), (1, 5000), (16, 10000), (400, 10000)):
+    seeds = list(range(1000, 1000 + nseeds))
+    out = torch.empty((nseeds, rows, 512), dtype=torch.float32, device=dev)
+    for mode in ("0", "1"):
+        os.environ["GANSPACE_ZGEN_SEGMENTS"] = mode
+        best = None
+        for rep in range(4):
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            for _ in _zgen.device_groups("stylegan", seeds, rows, 512, dev, out=out): pass
+            torch.cuda.synchronize(); dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+        print(f"{nseeds:4d} streams of {rows} x 512 normals, segments {'on ' if mode == '1' else 'off'} "
+              f"({_zgen.plan_segments(rows * 512) if mode == '1' else 1:2d} per stream): {best*1e3:7.2f} ms", flush=True)
+    del out
