@@ -21,6 +21,8 @@
 #include <new>
 #include <vector>
 
+#include <mutex>
+
 #include "gs_common.h"
 
 namespace gs {
@@ -1265,45 +1267,83 @@ int gs_gram_accumulate(const float *X, int64_t rows, int64_t ld, int64_t d, cons
     return gs_gram_accumulate_prec(X, rows, ld, d, shift, G, colsum, GS_PREC_F32, stream_);
 }
 
+// The workspace of the handle-less accumulate call (slabs, pacing counters, the float64 scratch accumulators) is kept between
+// calls of the same width on the same device: the regression flushes [A|Z] rows 120 times per cfg4 job, and a dozen
+// hipMalloc / hipFree plus a stream synchronisation per flush were 2-4 ms of host time each - more than the flush's kernels.
+namespace {
+struct AccumulateCache {
+    GramWorkspace ws;
+    float *shp = nullptr;
+    double *G64 = nullptr, *S1 = nullptr;
+    int64_t d = 0;
+    int device = -1;
+    hipStream_t last = nullptr;
+    bool live = false;
+    void release() {
+        if (!live) return;
+        (void)hipStreamSynchronize(last);
+        gram_workspace_free(ws);
+        if (shp) (void)hipFree(shp);
+        if (G64) (void)hipFree(G64);
+        if (S1) (void)hipFree(S1);
+        ws = GramWorkspace();
+        shp = nullptr;
+        G64 = S1 = nullptr;
+        live = false;
+    }
+};
+AccumulateCache g_acc;
+std::mutex g_acc_mutex;
+}  // namespace
+
 int gs_gram_accumulate_prec(const float *X, int64_t rows, int64_t ld, int64_t d, const float *shift, double *G,
                             double *colsum, int precision, void *stream_) {
     GS_REQUIRE(precision >= GS_PREC_F32 && precision <= GS_PREC_BF16, GS_EINVAL, "gs_gram_accumulate: bad precision");
     GS_REQUIRE(X && G && colsum, GS_EINVAL, "gs_gram_accumulate: NULL argument");
     GS_REQUIRE(d >= 1 && d <= 8192 && rows >= 0 && ld >= d, GS_EINVAL, "gs_gram_accumulate: bad shape");
     hipStream_t stream = (hipStream_t)stream_;
-    GramWorkspace ws;
-    int rc = gram_workspace_alloc(ws, d);
-    if (rc != GS_OK) return rc;
+    int device = 0;
+    GS_HIP_CHECK(hipGetDevice(&device));
+    std::lock_guard<std::mutex> lock(g_acc_mutex);
+    AccumulateCache &c = g_acc;
+    if (c.live && (c.d != d || c.device != device)) c.release();
+    if (!c.live) {
+        int rc = gram_workspace_alloc(c.ws, d);
+        const int64_t dpn = c.ws.dp;
+        if (rc == GS_OK && (hipMalloc(&c.shp, sizeof(float) * dpn) != hipSuccess ||
+                            hipMalloc(&c.G64, sizeof(double) * dpn * dpn) != hipSuccess ||
+                            hipMalloc(&c.S1, sizeof(double) * dpn) != hipSuccess)) {
+            set_error("gs_gram_accumulate: hipMalloc failed");
+            rc = GS_ENOMEM;
+        }
+        c.d = d;
+        c.device = device;
+        c.last = stream;
+        c.live = true;
+        if (rc != GS_OK) {
+            c.release();
+            return rc;
+        }
+    } else if (c.last != stream) {
+        (void)hipStreamSynchronize(c.last);        // the scratch is reused in stream order: a new stream waits for the old one
+    }
+    c.last = stream;
+    GramWorkspace &ws = c.ws;
     ws.precision = precision;
     const int64_t dp = ws.dp;
-    float *shp = nullptr;
-    double *G64 = nullptr, *S1 = nullptr;
-    auto cleanup = [&]() {
-        (void)hipStreamSynchronize(stream);
-        gram_workspace_free(ws);
-        if (shp) (void)hipFree(shp);
-        if (G64) (void)hipFree(G64);
-        if (S1) (void)hipFree(S1);
-    };
-    if (hipMalloc(&shp, sizeof(float) * dp) != hipSuccess || hipMalloc(&G64, sizeof(double) * dp * dp) != hipSuccess ||
-        hipMalloc(&S1, sizeof(double) * dp) != hipSuccess) {
-        cleanup();
-        set_error("gs_gram_accumulate: hipMalloc failed");
-        return GS_ENOMEM;
-    }
-    (void)hipMemsetAsync(shp, 0, sizeof(float) * dp, stream);
-    (void)hipMemsetAsync(G64, 0, sizeof(double) * dp * dp, stream);
-    (void)hipMemsetAsync(S1, 0, sizeof(double) * dp, stream);
-    if (shift) (void)hipMemcpyAsync(shp, shift, sizeof(float) * d, hipMemcpyDeviceToDevice, stream);
-    rc = gram_update(ws, X, rows, ld, d, shp, G64, S1, false, /*defer=*/false, stream);
+    (void)hipMemsetAsync(c.shp, 0, sizeof(float) * dp, stream);
+    (void)hipMemsetAsync(c.G64, 0, sizeof(double) * dp * dp, stream);
+    (void)hipMemsetAsync(c.S1, 0, sizeof(double) * dp, stream);
+    if (shift) (void)hipMemcpyAsync(c.shp, shift, sizeof(float) * d, hipMemcpyDeviceToDevice, stream);
+    int rc = gram_update(ws, X, rows, ld, d, c.shp, c.G64, c.S1, false, /*defer=*/false, stream);
     if (rc == GS_OK) {
         hipLaunchKernelGGL(symmetrize_out_kernel, dim3((unsigned)ceil_div(d, 256), (unsigned)d), dim3(256), 0,
-                           stream, G64, G, (int)d, (int)dp, 1);
-        hipLaunchKernelGGL(add_vec_kernel, dim3((unsigned)ceil_div(d, 256)), dim3(256), 0, stream, S1, colsum,
+                           stream, c.G64, G, (int)d, (int)dp, 1);
+        hipLaunchKernelGGL(add_vec_kernel, dim3((unsigned)ceil_div(d, 256)), dim3(256), 0, stream, c.S1, colsum,
                            (int)d);
         if (hipGetLastError() != hipSuccess) rc = GS_EHIP;
     }
-    cleanup();
+    if (rc != GS_OK) c.release();
     return rc;
 }
 
