@@ -169,7 +169,12 @@ def test_eigh_topk_white_noise_falls_back(dev):
                                          # tall-skinny products (the small side's T Q shape class): ragged rows / columns / K,
                                          # transposed operands
                                          (2050, 37, 1030, True, True), (2081, 128, 2081, False, False),
-                                         (4100, 17, 1100, False, True), (2049, 113, 1025, True, False)])
+                                         (4100, 17, 1100, False, True), (2049, 113, 1025, True, False),
+                                         # more tall-times-narrow shapes with whole 16-column tiles, ragged K, every operand layout
+                                         (2080, 96, 2080, False, False), (2080, 80, 2080, False, False),
+                                         (1024, 16, 520, False, False), (4096, 48, 1000, False, True),
+                                         (2048, 64, 2048, True, False), (1056, 32, 515, True, True),
+                                         (2080, 128, 2080, False, False), (1024, 112, 777, False, True), (1030, 16, 2081, True, False)])
 def test_gemm_f64_mfma_matches_numpy(dev, M, N, K, ta, tb):
     """The f64 matrix-pipe product (`mm64_kernel`, v_mfma_f64_16x16x4_f64) of the solver chains, every operand layout
     (strided views: no transposed copies), ragged shapes, both tile arrangements and the split-K path."""

@@ -400,3 +400,32 @@ def test_mt19937_jump_polynomials_reach_the_states_numpy_reaches():
         assert (s - 1) * L * _zgen.VALUES_PER_BLOCK < count * 1.004 + 3 * _zgen.VALUES_PER_BLOCK
     assert _zgen.plan_segments(40_960) == 1 and _zgen.plan_segments(5_120_000) == 11
     assert _zgen.plan_segments(64 * L * 250) == 0                # beyond the file: the serial kernel takes it
+
+
+def test_parallel_npz_writer_is_a_drop_in_for_numpys(tmp_path):
+    """``_npz.savez_compressed`` (the component file of decomposition.py:331-341 with its members deflated piecewise on a thread
+    pool): a valid zip archive with the keys, dtypes, shapes and values ``np.savez_compressed`` would have written - members
+    longer than one piece, shorter than one, empty and 0-d included -, the ``.npz`` suffix added when missing."""
+    import zipfile
+    from ganspace_amd import _npz
+    rs = np.random.RandomState(5)
+    rec = dict(act_comp=rs.standard_normal((40, 16384)).astype(np.float32),          # 2.6 MB: three pieces
+               act_mean=rs.standard_normal((1, 16384)).astype(np.float32), act_stdev=rs.rand(40).astype(np.float32),
+               lat_comp=rs.standard_normal((40, 1, 128)).astype(np.float32), empty=np.zeros((0, 3), np.float32),
+               scalar=np.float32(3.5), counts=np.arange(7, dtype=np.int64))
+    for threads in (1, 3):
+        path = tmp_path / f"out{threads}"
+        _npz.savez_compressed(path, threads=threads, **rec)
+        path = tmp_path / f"out{threads}.npz"
+        assert path.exists()
+        with zipfile.ZipFile(path) as z:
+            assert z.testzip() is None
+            assert [i.filename for i in z.infolist()] == [k + ".npy" for k in rec]
+            assert all(i.compress_type == zipfile.ZIP_DEFLATED for i in z.infolist())
+        ref = tmp_path / "ref.npz"
+        np.savez_compressed(ref, **rec)
+        with np.load(path) as got, np.load(ref) as want:
+            assert got.files == want.files
+            for k in rec:
+                assert got[k].dtype == want[k].dtype and got[k].shape == want[k].shape
+                np.testing.assert_array_equal(got[k], want[k])

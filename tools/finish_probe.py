@@ -25,3 +25,18 @@ def wr():
     with tempfile.TemporaryDirectory() as td:
         np.savez_compressed(os.path.join(td, "x.npz"), **rec)
 T("savez_compressed 2x80x512", wr)
+from ganspace_amd import _npz
+big = {"act_comp": np.random.randn(80, 32768).astype(np.float32), "lat_comp": np.random.randn(80, 128).astype(np.float32)}
+def wr_np():
+    with tempfile.TemporaryDirectory() as td:
+        np.savez_compressed(os.path.join(td, "x.npz"), **big)
+def wr_par():
+    with tempfile.TemporaryDirectory() as td:
+        _npz.savez_compressed(os.path.join(td, "x.npz"), **big)
+T("np.savez_compressed 80x32768", wr_np)
+T("_npz.savez_compressed 80x32768 (deflate pieces on a thread pool)", wr_par)
+for th in (2, 4, 8, 16, 32):
+    def wr_t():
+        with tempfile.TemporaryDirectory() as td:
+            _npz.savez_compressed(os.path.join(td, "x.npz"), threads=th, **big)
+    T(f"   ... {th} threads", wr_t, reps=2)

@@ -18,6 +18,7 @@
 #   timeline                                rocprofv3 --kernel-trace of `bench.py --no-extras` -> job_timeline.md (tools/job_timeline.py)
 #   grampmc[:rows]                          FETCH_SIZE / WRITE_SIZE / SQ / LDS --pmc passes on tools/gram_probe.py (separate passes)
 #                                           -> rocprof_summary.md + gram_pmc_latest.json (tools/summarize_profiles.py)
+#   env:<NAME>:<VALUE>                      export NAME=VALUE for the following steps
 #   measure                                 export GANSPACE_HIP_LIB=lib_measure for the following steps
 set -u
 R=$GRAFT_REPO_ROOT
@@ -90,6 +91,7 @@ PYEOF
       python tools/summarize_profiles.py "$O" "profiles/${TAG}_rocprof_summary.md" > "$O/rocprof_summary.md"
       cp profiles/gram_pmc_latest.json "$O/gram_pmc_latest.json"; cat "$O/rocprof_summary.md"
       rm -rf "$O"/pmc_FETCH_SIZE "$O"/pmc_WRITE_SIZE "$O"/pmc_sq "$O"/pmc_lds "$O"/bench_trace ;;
+    env) export "$a1=${rest}" ;;        # env:NAME:VALUE for the following steps
     measure) export GANSPACE_HIP_LIB="$R/ganspace_amd/lib_measure/libganspace_hip.so" ;;
     *) echo "unknown step $step" ;;
   esac
