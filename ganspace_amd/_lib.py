@@ -51,6 +51,7 @@ SIGNATURES = {
     "gs_zgen_release": (_int, [_vp, _i64]),
     "gs_zgen_finish": (_int, [_vp]),
     "gs_zgen_device": (_int, [_vp, _i64, _i64, _vp, _i64, _int, C.c_double, C.c_double, _f32, _vp]),
+    "gs_linear_set_resident": (_int, [_int]),
     "gs_zgen_segmented_nbytes": (_int, [_i64, _int, _int, _vp]),
     "gs_zgen_device_segmented": (_int, [_vp, _i64, _i64, _vp, _i64, _vp, _int, _int, _vp, _i64, _vp, _vp]),
     "gs_gram_accumulate": (_int, [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp]),

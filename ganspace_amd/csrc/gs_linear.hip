@@ -15,6 +15,8 @@
 // into the epilogue.
 #include <utility>
 
+#include <atomic>
+
 #include "gs_common.h"
 
 namespace gs {
@@ -615,6 +617,9 @@ __global__ __launch_bounds__(256) void pixelnorm_kernel(const float *__restrict_
     }
 }
 
+// gs_linear_set_resident: see the C ABI at the end of the file
+static std::atomic<bool> g_linear_resident{true};
+
 static int launch_linear(const float *x, const float *W, const float *b, float *y, int64_t M, int N, int K,
                          float wscale, float bscale, float slope, float gain, int act, hipStream_t stream) {
     const int64_t ntm = ceil_div(M, kLT), ntn = ceil_div(N, kLT);
@@ -646,7 +651,8 @@ static int launch_linear(const float *x, const float *W, const float *b, float *
         // launches of more than two rounds of 128-row tiles: two workgroups per CU walk their tiles as one pipeline each
         // (R = 4: the tile height whose registers and LDS let two of them share a CU)
         const int64_t total4 = ceil_div(M, (int64_t)128) * ntn;
-        bool persist = total4 > 1024 && (uint64_t)M * N * 4u < 0xFFFFFFFFull;     // (y through a buffer resource)
+        bool persist = total4 > 1024 && (uint64_t)M * N * 4u < 0xFFFFFFFFull      // (y through a buffer resource)
+                       && g_linear_resident.load(std::memory_order_relaxed);
         if (const char *fp = gs_knob("GS_LINEAR_PERSIST")) persist = persist && fp[0] == '1';
         if (persist) {
             const int64_t pper = ceil_div(total4, 8);
@@ -690,6 +696,14 @@ static int project_splits(int64_t rows, int directions, int features) {
 using namespace gs;
 
 extern "C" {
+
+// The long launches of the mapping / Linear layers keep their workgroups RESIDENT (linear_act_persist_kernel: every workgroup
+// lives as long as the launch).  A caller that wants small dependent launches of another stream to slip in between - the
+// faithful block chain while the next group's generator call runs (decomposition._fit_blocks) - switches to the per-tile
+// kernel, whose workgroups come and go every ~50 us (2 % slower by itself).  Process-wide; returns the previous setting.
+int gs_linear_set_resident(int enable) {
+    return g_linear_resident.exchange(enable != 0) ? 1 : 0;
+}
 
 int gs_linear_forward(const float *x, const float *W, const float *b, float *y, int64_t rows, int in_features,
                       int out_features, void *stream) {

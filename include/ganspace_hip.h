@@ -305,6 +305,14 @@ int gs_zgen_device_segmented(const uint32_t *seeds_dev, int64_t n_seeds, int64_t
                              const uint32_t *polys_dev, int block_len, int segments, void *scratch, int64_t scratch_bytes,
                              int *shortfall_host, void *stream);
 
+/* Long launches of gs_linear_forward / gs_mapping_forward (more than 1 024 tiles of 128 rows) run on workgroups that stay
+ * resident for the whole launch (one software pipeline per workgroup).  0 selects the per-tile kernel instead, whose
+ * workgroups come and go every ~50 us: small dependent launches of ANOTHER stream - the sklearn-faithful block chain
+ * (estimators.py:68-76 -> IncrementalPCA.partial_fit) while the generator call of the next blocks runs
+ * (decomposition.py:241-267) - then find a CU in microseconds instead of waiting for the launch to end.  Process-wide
+ * switch, default 1; returns the previous setting. */
+int gs_linear_set_resident(int enable);
+
 /* z -> w: the StyleGAN2 mapping network `Generator.style` called from
  * models/wrappers.py:177,200 (PixelNorm + L x EqualLinear(dim, dim, lr_mul,
  * activation='fused_lrelu')); in-tree analogue models/stylegan/model.py:190-216.

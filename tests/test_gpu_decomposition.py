@@ -421,3 +421,39 @@ def test_pca_estimator_through_get_or_compute(dev, tmp_path):
     np.testing.assert_allclose(data["act_stdev"], ref_stdev, rtol=1e-3)
     np.testing.assert_allclose(data["act_mean"].ravel(), mean.ravel(), atol=1e-5)
     inst.close()
+
+
+def test_harvesting_the_next_group_on_a_second_stream_changes_nothing(dev, monkeypatch):
+    """Faithful Gram-side fits of a generator layer issue the NEXT group's ``partial_forward`` on a second stream before
+    fitting the current one (and switch the long Linear launches to the per-tile kernel meanwhile,
+    ``gs_linear_set_resident``).  Same rows to the same blocks in the same order: the last block's rows are bit-identical,
+    the fitted state equal to the in-order loop's (``GANSPACE_HARVEST_AHEAD=0``) to float64 reduction order - for groups
+    that alias the hooked activation and for groups assembled from several forward calls; and the switch is back on after."""
+    from ganspace_amd import _lib
+    from ganspace_amd import decomposition as dec
+    from ganspace_amd.estimators import get_estimator
+    from ganspace_amd.wrappers import get_instrumented_model
+    inst = get_instrumented_model("StyleGAN2", "car", "style", dev, use_w=False)
+    model = inst.model
+    inst.retain_layer("style")
+    lib = _lib.load()
+    for n, B, rows_per_call in ((24_000, 2000, 4000), (18_000, 768, 768)):      # aliased groups of 2 blocks / 3 calls per block
+        k = 12
+        plan = dec._Plan.make(n, B, k)
+        torch.manual_seed(dec.SEED_SAMPLING)
+        np.random.seed(dec.SEED_SAMPLING)
+        latents, _ = dec._presample(model, plan, model.get_latent_shape(), dev)
+        monkeypatch.setattr(dec, "FORWARD_ROWS", rows_per_call)
+        results = []
+        for ahead in ("1", "0"):
+            monkeypatch.setenv("GANSPACE_HARVEST_AHEAD", ahead)
+            est = get_estimator("ipca", k, 1.0)
+            last = dec._fit_blocks(est, inst, latents, plan, "style", 512, False, dev)
+            comp, stdev, _ = est.get_components()
+            results.append((np.array(comp), np.array(stdev), np.array(est.transformer.mean_), last.clone()))
+            assert lib.gs_linear_set_resident(1) == 1             # restored by _fit_blocks
+        (c0, s0, m0, l0), (c1, s1, m1, l1) = results
+        assert torch.equal(l0, l1)
+        np.testing.assert_allclose(c0, c1, rtol=0, atol=2e-8)
+        np.testing.assert_allclose(s0, s1, rtol=1e-9)
+        np.testing.assert_allclose(m0, m1, rtol=0, atol=1e-12 * max(1.0, float(np.abs(m1).max())))
