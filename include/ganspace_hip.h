@@ -172,7 +172,10 @@ int gs_ipca_components_device(gs_ipca_t *h, const float **components, const floa
 /* G[d*d] (float64, row-major, FULL symmetric) += sum_r (x_r - shift)(x_r - shift)^T and
  * colsum[d] (float64) += sum_r (x_r - shift); shift may be NULL (= 0).  Uses the same
  * kernels as gs_ipca_update.  G/colsum must be zero-initialised by the caller if a fresh
- * sum is wanted.                                                                         */
+ * sum is wanted.  Asynchronous on `stream` (X is read in stream order).  The workspace of
+ * the call (partial-sum slabs, scratch accumulators: ~230 MB at d = 592) is kept for the
+ * next call of the same width on the same device - the regression of decomposition.py:77-139
+ * flushes its [A|Z] rows here 120 times per cfg4 job - and replaced when the width changes. */
 int gs_gram_accumulate(const float *X, int64_t rows, int64_t ld, int64_t d,
                        const float *shift, double *G, double *colsum, void *stream);
 
