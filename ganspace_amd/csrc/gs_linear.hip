@@ -295,35 +295,61 @@ __device__ __forceinline__ void lgkm_wait() {
     asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int R, int K, int KS>
+// Operands come out of LDS as ds_read_b64: a row keeps the four k values of a quad in the order (k, k + 2, k + 1, k + 3), so
+// that lanes 0-31 (the k-even operand of a 32x32x2 MFMA) find the operands of TWO consecutive k-steps in one 8-byte read at
+// the start of the quad, lanes 32-63 (k-odd) theirs 8 bytes further.  Round 6 PMC on the ds_read_b32 form of rounds 4-6:
+// SQ_LDS_BANK_CONFLICT = 43 % of SQ_LDS_IDX_ACTIVE - a ds_read_b32 is banked modulo 32 dwords, and with rows 34 dwords apart
+// rows r and r + 16 of a fragment share a bank; ds_read_b64 is banked modulo 64 (rows 0..31 -> 32 distinct bank pairs), moves
+// twice the bytes per LDS cycle and halves the instruction count.  Same products in the same order per output element.
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+
+template <int OFF>
+__device__ __forceinline__ f32x2 lds_rd2(unsigned addr) {
+    f32x2 v;
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+    return v;
+}
+
+template <int R, int BASE, int STRIDE, int I = 0>
+struct ReadFrags2 {
+    static __device__ __forceinline__ void run(unsigned addr, f32x2 (&v)[R]) {
+        v[I] = lds_rd2<BASE + I * STRIDE>(addr);
+        ReadFrags2<R, BASE, STRIDE, I + 1>::run(addr, v);
+    }
+};
+template <int R, int BASE, int STRIDE>
+struct ReadFrags2<R, BASE, STRIDE, R> {
+    static __device__ __forceinline__ void run(unsigned, f32x2 (&)[R]) {}
+};
+
+template <int R, int P, int PS>
 struct LinPipe {
-    // a[] / b: operands of k-step K (issued two steps ago); p[] / pb: step K + 1, still in flight
-    static __device__ __forceinline__ void run(unsigned aaddr, unsigned baddr, const float (&a)[R], float b,
-                                               const float (&p)[R], float pb, f32x16 (&acc)[R]) {
+    // a[] / b: operands of k-step pair P (requested one pair ago); the reads of pair P + 1 are issued before its MFMAs
+    static __device__ __forceinline__ void run(unsigned aaddr, unsigned baddr, const f32x2 (&a)[R], f32x2 b,
+                                               f32x16 (&acc)[R]) {
         constexpr int kFrag = 32 * kFP * 4;   // byte distance between 32-row fragments
-        float q[R], qb = 0.f;
+        f32x2 q[R], qb = {0.f, 0.f};
 #pragma unroll
-        for (int r = 0; r < R; ++r) q[r] = 0.f;
-        if (K + 2 < KS) {
-            qb = lds_rd<(K + 2) * 8>(baddr);
-            ReadFrags<R, (K + 2) * 8, kFrag>::run(aaddr, q);
-            lgkm_wait<2 * (R + 1)>();
-        } else if (K + 1 < KS) {
+        for (int r = 0; r < R; ++r) q[r] = f32x2{0.f, 0.f};
+        if (P + 1 < PS) {
+            qb = lds_rd2<(P + 1) * 16>(baddr);
+            ReadFrags2<R, (P + 1) * 16, kFrag>::run(aaddr, q);
             lgkm_wait<R + 1>();
         } else {
             lgkm_wait<0>();
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int r = 0; r < R; ++r) acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[r], b, acc[r], 0, 0, 0);
+        for (int r = 0; r < R; ++r) acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[r].x, b.x, acc[r], 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[r].y, b.y, acc[r], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
-        LinPipe<R, K + 1, KS>::run(aaddr, baddr, p, pb, q, qb, acc);
+        LinPipe<R, P + 1, PS>::run(aaddr, baddr, q, qb, acc);
     }
 };
-template <int R, int KS>
-struct LinPipe<R, KS, KS> {
-    static __device__ __forceinline__ void run(unsigned, unsigned, const float (&)[R], float, const float (&)[R], float,
-                                               f32x16 (&)[R]) {}
+template <int R, int PS>
+struct LinPipe<R, PS, PS> {
+    static __device__ __forceinline__ void run(unsigned, unsigned, const f32x2 (&)[R], f32x2, f32x16 (&)[R]) {}
 };
 
 // K loop of one wave that owns RF row fragments (starting at fragment f0) of column fragment `cw`.  All 512
@@ -355,8 +381,8 @@ __device__ __forceinline__ void linear_fast_body(float (*lds)[32 * R + kLT][kFP]
         // opaque: keeps the stores (and the wait for the loads) behind the MFMA stream, see gs_gram.hip
         asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));
         uint2 *p = reinterpret_cast<uint2 *>(dst);
-        p[0] = make_uint2(v.x, v.y);
-        p[1] = make_uint2(v.z, v.w);
+        p[0] = make_uint2(v.x, v.z);       // quad order (k, k + 2, k + 1, k + 3): see LinPipe
+        p[1] = make_uint2(v.y, v.w);
     };
     auto stash = [&](int buf) {
 #pragma unroll
@@ -370,7 +396,7 @@ __device__ __forceinline__ void linear_fast_body(float (*lds)[32 * R + kLT][kFP]
 #pragma unroll
     for (int r = 0; r < (RF > 0 ? RF : 1); ++r) acc[r] = f32x16{0};
     const int nst = K / kLK;
-    const int frag = ((lane & 31) * kFP + (lane >> 5)) * 4;   // byte offset of this lane inside a 32-row fragment
+    const int frag = ((lane & 31) * kFP + 2 * (lane >> 5)) * 4;   // byte offset of this lane inside a 32-row fragment
     constexpr int kFrag = 32 * kFP * 4;
 
     fetch(0);
@@ -383,12 +409,10 @@ __device__ __forceinline__ void linear_fast_body(float (*lds)[32 * R + kLT][kFP]
         if constexpr (RF > 0) {
             const unsigned aaddr = (unsigned)(uintptr_t)&lds[buf][32 * f0][0] + frag;
             const unsigned baddr = (unsigned)(uintptr_t)&lds[buf][TM + cw * 32][0] + frag;
-            float a[RF], p[RF];
-            const float b0 = lds_rd<0>(baddr);
-            ReadFrags<RF, 0, kFrag>::run(aaddr, a);
-            const float pb = lds_rd<8>(baddr);
-            ReadFrags<RF, 8, kFrag>::run(aaddr, p);
-            LinPipe<RF, 0, kLK / 2>::run(aaddr, baddr, a, b0, p, pb, acc);
+            f32x2 a[RF];
+            const f32x2 b0 = lds_rd2<0>(baddr);
+            ReadFrags2<RF, 0, kFrag>::run(aaddr, a);
+            LinPipe<RF, 0, kLK / 4>::run(aaddr, baddr, a, b0, acc);
         }
         __builtin_amdgcn_sched_barrier(0);
         if (s + 1 < nst) stash(buf ^ 1);
@@ -444,8 +468,8 @@ __device__ __forceinline__ void linear_persist_body(float (*lds)[32 * R + kLT][k
     auto put = [&](float *dst, u32x4 v) {
         asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));
         uint2 *p = reinterpret_cast<uint2 *>(dst);
-        p[0] = make_uint2(v.x, v.y);
-        p[1] = make_uint2(v.z, v.w);
+        p[0] = make_uint2(v.x, v.z);       // quad order (k, k + 2, k + 1, k + 3): see LinPipe
+        p[1] = make_uint2(v.y, v.w);
     };
     auto stash = [&](int buf) {
 #pragma unroll
@@ -459,7 +483,7 @@ __device__ __forceinline__ void linear_persist_body(float (*lds)[32 * R + kLT][k
 #pragma unroll
     for (int r = 0; r < (RF > 0 ? RF : 1); ++r) acc[r] = f32x16{0};
     const int nst = K / kLK;
-    const int frag = ((lane & 31) * kFP + (lane >> 5)) * 4;
+    const int frag = ((lane & 31) * kFP + 2 * (lane >> 5)) * 4;
     constexpr int kFrag = 32 * kFP * 4;
 
     unsigned t = t_first;
@@ -491,12 +515,10 @@ __device__ __forceinline__ void linear_persist_body(float (*lds)[32 * R + kLT][k
             if constexpr (RF > 0) {
                 const unsigned aaddr = (unsigned)(uintptr_t)&lds[buf][32 * f0][0] + frag;
                 const unsigned baddr = (unsigned)(uintptr_t)&lds[buf][TM + cw * 32][0] + frag;
-                float a[RF], p[RF];
-                const float b0 = lds_rd<0>(baddr);
-                ReadFrags<RF, 0, kFrag>::run(aaddr, a);
-                const float pb = lds_rd<8>(baddr);
-                ReadFrags<RF, 8, kFrag>::run(aaddr, p);
-                LinPipe<RF, 0, kLK / 2>::run(aaddr, baddr, a, b0, p, pb, acc);
+                f32x2 a[RF];
+                const f32x2 b0 = lds_rd2<0>(baddr);
+                ReadFrags2<RF, 0, kFrag>::run(aaddr, a);
+                LinPipe<RF, 0, kLK / 4>::run(aaddr, baddr, a, b0, acc);
             }
             __builtin_amdgcn_sched_barrier(0);
             if (nxt) stash(buf ^ 1);
