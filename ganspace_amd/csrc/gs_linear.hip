@@ -262,32 +262,12 @@ __global__ __launch_bounds__(256) void project_reduce_kernel(const float *__rest
 //   * 8 waves: waves w and w + 4 (same SIMD) own output columns 32 w .. 32 w + 31 and split the R row fragments
 //     (RF + 1 operand reads feed RF MFMAs): one of them has MFMAs in flight while the other stores / restarts;
 //   * the tiles stay K-contiguous in LDS ([row][32 k + 2 pad]: rows 136 B apart make the 64 lanes of a fragment
-//     read - 32 rows x 2 consecutive k - hit 64 different banks), so staging is two ds_write_b64 per float4 instead
+//     read - 32 rows x an 8-byte operand pair - hit 32 distinct bank pairs), so staging is two ds_write_b64 per float4 instead
 //     of four scalar stores; loads go through buffer resources (row offsets in SGPRs, rows past M read as zeros);
-//   * operand reads run two k-steps ahead of the MFMAs (inline-asm ds_read_b32 with immediate offsets + counted
-//     s_waitcnt); one code path in the K loop.
+//   * operand reads run a pair of k-steps ahead of the MFMAs (inline-asm ds_read_b64 with immediate offsets + counted
+//     s_waitcnt: see LinPipe); one code path in the K loop.
 constexpr int kFP = kLK + 2;   // padded row length (floats)
 using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
-
-template <int OFF>
-__device__ __forceinline__ float lds_rd(unsigned addr) {
-    float v;
-    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
-    return v;
-}
-
-// v[i] = LDS dword at addr + BASE + i * STRIDE (immediate offsets), i = 0 .. R - 1
-template <int R, int BASE, int STRIDE, int I = 0>
-struct ReadFrags {
-    static __device__ __forceinline__ void run(unsigned addr, float (&v)[R]) {
-        v[I] = lds_rd<BASE + I * STRIDE>(addr);
-        ReadFrags<R, BASE, STRIDE, I + 1>::run(addr, v);
-    }
-};
-template <int R, int BASE, int STRIDE>
-struct ReadFrags<R, BASE, STRIDE, R> {
-    static __device__ __forceinline__ void run(unsigned, float (&)[R]) {}
-};
 
 template <int N>
 __device__ __forceinline__ void lgkm_wait() {
